@@ -1,0 +1,188 @@
+/* pynama_hip.h -- C ABI of libpynama_hip.so: the MI355X (gfx950) implementation of the
+ * Pynama finite/spectral-element hot path (element quadrature + global scatter + Krylov solve).
+ *
+ * Plain C: opaque context, plain pointers and sizes, int32 indices, float64 values.  No
+ * PyTorch / C++ types cross this boundary.  Every function returns 0 on success and a
+ * negative PYN_E* code on failure; the message is available from pyn_last_error().
+ * Host arrays are caller-owned, C-contiguous, borrowed for the duration of the call.
+ * Device memory is owned by the context.  A context is bound to ONE GPU and ONE process
+ * (one process per GPU; ranks are tied together with pyn_comm_init over RCCL).  A context is
+ * not re-entrant.
+ *
+ * Each entry point names the reference interface (file:line under /root/reference/) whose
+ * work it takes over.  The reference has no FFI: the boundary sits behind its Python classes
+ * (Spectral, DMPlexDom, Mat, KspSolver, FreeSlip); pynama_amd/ mirrors those classes on top of
+ * this header with ctypes.
+ */
+#ifndef PYNAMA_HIP_H
+#define PYNAMA_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct pyn_ctx pyn_ctx;
+
+enum {
+  PYN_OK = 0,
+  PYN_EINVAL = -1,   /* bad argument / wrong call order */
+  PYN_EHIP = -2,     /* HIP runtime error */
+  PYN_ENCCL = -3,    /* RCCL error */
+  PYN_ENOTCONV = -4, /* reserved */
+  PYN_ENOGPU = -5    /* no gfx950 device visible */
+};
+
+/* quadrature table slots -- src/elements/spectral.py:45-61 (H/Hrs/gps, HRed/..., HOp/...) */
+enum { PYN_Q_FULL = 0, PYN_Q_RED = 1, PYN_Q_NODAL = 2 };
+
+/* scalar forms for pyn_assemble_scalar / pyn_elem_local */
+enum {
+  PYN_FORM_LAPLACE = 0,   /* L_e = sum_full w detJ G^T G          spectral.py:125,131 (one component) */
+  PYN_FORM_MASS_NODAL = 1,/* M_e = sum_nodal w detJ H H^T         spectral.py:215 (elWeigMat)         */
+  PYN_FORM_MASS_FULL = 2, /* same on the full rule (consistent mass)                                   */
+  PYN_FORM_KLE = 3        /* K_e, Rw_e, Rd_e                       spectral.py:89-157                  */
+};
+
+/* Krylov method / preconditioner / norm (PETSc option names in comments) */
+enum { PYN_KSP_CG = 0, PYN_KSP_GMRES = 1 };                 /* -ksp_type cg | gmres            */
+enum { PYN_PC_NONE = 0, PYN_PC_JACOBI = 1 };                /* -pc_type none | jacobi          */
+enum { PYN_NORM_PRECONDITIONED = 0, PYN_NORM_UNPRECONDITIONED = 1, PYN_NORM_NATURAL = 2 };
+/* converged reasons, numbered as PETSc's KSPConvergedReason */
+enum { PYN_CONVERGED_RTOL = 2, PYN_CONVERGED_ATOL = 3, PYN_CONVERGED_ITS = 4,
+       PYN_DIVERGED_ITS = -3, PYN_DIVERGED_DTOL = -4, PYN_DIVERGED_BREAKDOWN = -5,
+       PYN_DIVERGED_NANORINF = -9 };
+
+const char* pyn_last_error(void);
+int pyn_version(void);
+int pyn_device_count(int* count);
+
+/* ---- context -------------------------------------------------------------------------- */
+int pyn_ctx_create(int device, pyn_ctx** out);
+int pyn_ctx_destroy(pyn_ctx* ctx);
+int pyn_sync(pyn_ctx* ctx);                       /* hipStreamSynchronize on the context stream */
+
+/* ---- multi-GPU (one process per GPU, RCCL over xGMI) ------------------------------------
+ * Replaces the MPI communicator the reference hands to PETSc (src/cases/base_problem.py:22,
+ * src/matrices/mat_generator.py:95-99) and the implicit collectives inside MatAssembly /
+ * KSPSolve. */
+int pyn_comm_unique_id(void* out, int nbytes);    /* rank 0: nbytes >= 128 */
+int pyn_comm_init(pyn_ctx* ctx, int rank, int nranks, const void* unique_id, int nbytes);
+int pyn_comm_barrier(pyn_ctx* ctx);               /* device + host barrier over all ranks */
+int pyn_comm_allreduce_f64(pyn_ctx* ctx, double* inout, int n, int op /*0 sum, 1 max*/);
+/* Row partition + halo plan of this rank.  Local node numbering: owned nodes
+ * [0, n_owned) in global order, then ghosts grouped by owning neighbour (recv order).
+ *   send_idx[send_ptr[k] .. send_ptr[k+1]) : owned local node ids sent to neigh[k]
+ *   ghosts from neigh[k] occupy local ids n_owned + recv_ptr[k] .. n_owned + recv_ptr[k+1]
+ * Must be called BEFORE pyn_mesh_set when nranks > 1 (default: everything owned). */
+int pyn_halo_set(pyn_ctx* ctx, int64_t n_owned, int64_t n_ghost, int n_neigh, const int32_t* neigh,
+                 const int64_t* send_ptr, const int32_t* send_idx, const int64_t* recv_ptr);
+
+/* ---- mesh, element tables, boundary condition ------------------------------------------- */
+/* Connectivity + coordinates of the LOCAL mesh (owned + ghost nodes).  Takes over
+ * DMPlexDom.getCellCornersCoords (src/domain/dmplex.py:97-104) and getGlobalNodesFromCell
+ * (dmplex.py:197-200 -> src/domain/indices.py:66-88) for every cell at once:
+ * conn[e*nn + a] = local node id of element-local node a (reference order; the
+ * first 2^dim entries are the corners in DMPlex closure order), xyz[n*dim + d]. */
+int pyn_mesh_set(pyn_ctx* ctx, int dim, int nn, int64_t n_elem, int64_t n_node,
+                 const int32_t* conn, const double* xyz);
+/* One quadrature's tables -- Spectral.computeMats2D/3D output (spectral.py:220-344):
+ * w[ngp], H[ngp*nn], Hrs[ngp*dim*nn], HrsCoo[ngp*dim*2^dim] (geometry basis, spectral.py:54-61). */
+int pyn_elem_tables_set(pyn_ctx* ctx, int which, int ngp, const double* w, const double* H,
+                        const double* Hrs, const double* HrsCoo);
+/* Dirichlet mask per LOCAL velocity DOF (node*ndof + d): 1 = value imposed.  Takes over the
+ * set algebra of FreeSlip.buildKLEMats (src/cases/base_problem.py:512-528).  ndof = dim for the
+ * KLE forms, 1 for scalar forms.  mask == NULL clears it. */
+int pyn_bc_set(pyn_ctx* ctx, int ndof, const uint8_t* mask);
+
+/* ---- symbolic phase ----------------------------------------------------------------------
+ * Node adjacency graph -> CSR row pointers / column indices on the device (rows = owned
+ * nodes, columns = local node ids, sorted).  Takes over DMPlexDom.getMatIndices
+ * (dmplex.py:305-333) and the nnz preallocation of Mat.createEmptyKLEMats
+ * (src/matrices/mat_generator.py:32-99).  All matrices share this one graph; a matrix with
+ * block shape (br, bc) stores, for node-row i and component p, the scalar row
+ * [(i,p) ; (col_k, q)] contiguously:  val[(rowptr[i]*br + p*len_i + k)*bc + q]. */
+int pyn_csr_symbolic(pyn_ctx* ctx);
+int pyn_csr_info(pyn_ctx* ctx, int64_t* n_rows, int64_t* nnz_blocks);
+int pyn_csr_get(pyn_ctx* ctx, int32_t* rowptr, int32_t* colidx);
+
+/* ---- matrices and vectors (device resident) ---------------------------------------------
+ * Handles are small non-negative ints.  A vector with block size b has (n_owned+n_ghost)*b
+ * entries; only the owned part is meaningful to the caller. */
+int pyn_mat_create(pyn_ctx* ctx, int br, int bc, int* mat_id);      /* mat_generator.py:95-99 */
+int pyn_mat_zero(pyn_ctx* ctx, int mat_id);
+int pyn_mat_get_values(pyn_ctx* ctx, int mat_id, double* val);      /* layout above */
+int pyn_mat_get_diagonal(pyn_ctx* ctx, int mat_id, int vec_id);
+int pyn_mat_axpy(pyn_ctx* ctx, int y_mat, double a, int x_mat);     /* Y += a X (base_problem.py:318) */
+int pyn_mat_row_scale(pyn_ctx* ctx, int mat_id, int vec_id);        /* diagonalScale(L=) mat_generator.py:176 */
+int pyn_vec_create(pyn_ctx* ctx, int bs, int* vec_id);
+int pyn_vec_destroy(pyn_ctx* ctx, int vec_id);
+int pyn_vec_set_host(pyn_ctx* ctx, int vec_id, const double* src);  /* owned part, n_owned*bs */
+int pyn_vec_get_host(pyn_ctx* ctx, int vec_id, double* dst);
+int pyn_vec_fill(pyn_ctx* ctx, int vec_id, double value);
+int pyn_vec_scatter_host(pyn_ctx* ctx, int vec_id, int64_t n, const int32_t* idx, const double* vals,
+                         int add);                                   /* Vec.setValues */
+/* w = a*x + b*y (x,y,w may alias) ; w = x.*y ; w = 1./x ; reductions over owned entries,
+ * all-reduced across ranks */
+int pyn_vec_axpby(pyn_ctx* ctx, int w, double a, int x, double b, int y);
+int pyn_vec_pointwise_mult(pyn_ctx* ctx, int w, int x, int y);
+int pyn_vec_reciprocal(pyn_ctx* ctx, int x);
+int pyn_vec_dot(pyn_ctx* ctx, int x, int y, double* out);
+int pyn_vec_norm(pyn_ctx* ctx, int x, int type /*1, 2, 3=inf (PETSc NormType)*/, double* out);
+
+/* ---- numeric phase (HOT LOOP 1) -----------------------------------------------------------
+ * One device pass over all local elements: quadrature (spectral.py:89-157) + scatter-add with
+ * Dirichlet elimination (base_problem.py:499-552) + unit diagonal on imposed DOFs
+ * (mat_generator.py:113-118).  Matrices are zeroed first.  Any id may be -1 (skipped).
+ *   K   [dim,dim]  += K_e[free,free]         Krhs[dim,dim] += -K_e[free,bc]
+ *   Rw  [dim,dim_w]+= Rw_e[free,:]           Rd  [dim,1]   += Rd_e[free,:]
+ * variant: 0 = wave-per-element + FP64 atomics (any mesh), 1 = auto (fastest available). */
+int pyn_assemble_kle(pyn_ctx* ctx, double alpha_d, double alpha_w, int K, int Krhs, int Rw, int Rd,
+                     int variant);
+/* Scalar forms with the same elimination rule: A[1,1] += A_e[free,free], Arhs += -A_e[free,bc]. */
+int pyn_assemble_scalar(pyn_ctx* ctx, int form, int A, int Arhs, int variant);
+/* Single-element entry used for fixture parity: runs the SAME device element routine on one
+ * element given by its corner coordinates and returns dense row-major matrices
+ * (spectral.py:89-157 signature: coords -> K_e, Rw_e, Rd_e; any of the outputs may be NULL).
+ * PYN_FORM_KLE: out0 = K_e[dim nn, dim nn], out1 = Rw_e[dim nn, dim_w nn], out2 = Rd_e[dim nn, nn];
+ * scalar forms: out0 = A_e[nn, nn]. */
+int pyn_elem_local(pyn_ctx* ctx, int form, double alpha_d, double alpha_w, const double* corners,
+                   double* out0, double* out1, double* out2);
+
+/* ---- SpMV and Krylov solve (HOT LOOP 2) ---------------------------------------------------
+ * y = A x with halo exchange of x over RCCL when nranks > 1 (PETSc MatMult,
+ * base_problem.py:481 "Rw*vort + Krhs*vel"). */
+int pyn_spmv(pyn_ctx* ctx, int mat_id, int x_vec, int y_vec);
+typedef struct pyn_solve_opts {
+  int method;        /* PYN_KSP_*  */
+  int pc;            /* PYN_PC_*   */
+  int norm_type;     /* PYN_NORM_* */
+  int maxit;         /* PETSc default 10000 */
+  int restart;       /* GMRES(m), PETSc default 30 */
+  int fixed_iters;   /* >0: run exactly this many iterations, no convergence exit (benchmarking) */
+  double rtol, atol, dtol;   /* PETSc defaults 1e-5, 1e-50, 1e5 */
+} pyn_solve_opts;
+typedef struct pyn_solve_info {
+  int iters;
+  int reason;
+  double rnorm;       /* last residual norm in the solver's norm type */
+  double rnorm0;
+  double true_resid;  /* ||b - A x||_2 / ||b||_2 recomputed at exit */
+  double solve_ms;    /* device time of the iteration loop (HIP events) */
+} pyn_solve_info;
+/* Solve A x = b (x0 = 0).  Takes over KspSolver.createSolver + KSP.__call__
+ * (src/solver/ksp_solver.py:9-19, call site base_problem.py:481). */
+int pyn_solve(pyn_ctx* ctx, int mat_id, int b_vec, int x_vec, const pyn_solve_opts* opts,
+              pyn_solve_info* info);
+
+/* ---- timers -------------------------------------------------------------------------------
+ * Device time (HIP events on the context stream) of the last call of each phase, in ms.
+ * Replaces the tic/toc log of src/run_case.py:156-162. */
+enum { PYN_T_SYMBOLIC = 0, PYN_T_ASSEMBLE = 1, PYN_T_SPMV = 2, PYN_T_SOLVE = 3, PYN_T_COUNT = 8 };
+int pyn_timers_get(pyn_ctx* ctx, double* ms, int n);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PYNAMA_HIP_H */

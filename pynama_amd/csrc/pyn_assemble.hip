@@ -1,0 +1,521 @@
+// Numeric phase (HOT LOOP 1): per-element quadrature + global scatter with Dirichlet elimination.
+//
+// Reference: Spectral.getElemKLEMatrices (src/elements/spectral.py:89-157) called per cell by
+// FreeSlip.buildKLEMats (src/cases/base_problem.py:499-552), then Mat.setIndices2One
+// (src/matrices/mat_generator.py:113-118).
+//
+// Closed forms used by the kernels (derived from the B-matrix products of spectral.py:124-156;
+// G = J^-1 Hrs are physical gradients at a point, c = w detJ, eps = Levi-Civita):
+//   K [(a,p),(b,q)] = d_pq sum_full c G_a.G_b
+//                   + sum_red c ( alpha_d G_pa G_qb + alpha_w ( d_pq G_a.G_b - G_qa G_pb ) )
+//   Rw[(a,p),(b,k)] = sum_full c H_a curlsel(p,k;G_b) + sum_red alpha_w c curlsel(k,p;G_a)^T H_b
+//   Rd[(a,p), b   ] = -sum_full c H_a G_pb + sum_red alpha_d c G_pa H_b
+// where curlsel encodes (curl w)_p = eps_pmk d_m w_k (3D) and (d_y w, -d_x w) (2D).
+#include "pyn_internal.h"
+
+namespace {
+
+struct AsmArgs {
+  // mesh
+  const int32_t* conn;
+  const double* xyz;
+  int64_t n_elem, n_owned;
+  int dim, nn, nc;
+  // tables: 0 = full, 1 = reduced, 2 = nodal
+  int ngp[3];
+  const double* w[3];
+  const double* H[3];
+  const double* Hrs[3];
+  const double* HrsCoo[3];
+  // graph
+  const int32_t* rowptr;
+  const int32_t* colidx;
+  // bc
+  const uint8_t* bcmask;  // may be null
+  // form
+  int form;
+  double alpha_d, alpha_w;
+  // outputs (scatter mode) -- null when skipped
+  double *K, *Krhs, *Rw, *Rd;
+  // dense mode
+  const double* corners;  // single element
+  double *out0, *out1, *out2;
+  // scratch for high order
+  double* gscratch;
+  int64_t gscratch_stride;  // doubles per block
+};
+
+__device__ inline int find_slot(const int32_t* __restrict__ colidx, int lo, int len, int col) {
+  // lower_bound over a sorted row; the column is guaranteed to be present
+  int l = 0, h = len;
+  while (l < h) {
+    int m = (l + h) >> 1;
+    if (colidx[lo + m] < col)
+      l = m + 1;
+    else
+      h = m;
+  }
+  return l;
+}
+
+__device__ inline double inv_det(const double* J, double* Ji, int dim) {
+  if (dim == 2) {
+    double det = J[0] * J[3] - J[1] * J[2];
+    double r = 1.0 / det;
+    Ji[0] = J[3] * r;
+    Ji[1] = -J[1] * r;
+    Ji[2] = -J[2] * r;
+    Ji[3] = J[0] * r;
+    return det;
+  }
+  double c00 = J[4] * J[8] - J[5] * J[7];
+  double c01 = J[5] * J[6] - J[3] * J[8];
+  double c02 = J[3] * J[7] - J[4] * J[6];
+  double det = J[0] * c00 + J[1] * c01 + J[2] * c02;
+  double r = 1.0 / det;
+  Ji[0] = c00 * r;
+  Ji[1] = (J[2] * J[7] - J[1] * J[8]) * r;
+  Ji[2] = (J[1] * J[5] - J[2] * J[4]) * r;
+  Ji[3] = c01 * r;
+  Ji[4] = (J[0] * J[8] - J[2] * J[6]) * r;
+  Ji[5] = (J[2] * J[3] - J[0] * J[5]) * r;
+  Ji[6] = c02 * r;
+  Ji[7] = (J[1] * J[6] - J[0] * J[7]) * r;
+  Ji[8] = (J[0] * J[4] - J[1] * J[3]) * r;
+  return det;
+}
+
+// (curl w)_p = sum_{m,k} cs(p,m,k) d_m w_k ; returns the sign and the derivative index m for (p,k), 0 if none
+__device__ inline int curl_term(int dim, int p, int k, int* m) {
+  if (dim == 2) {  // w scalar (k = 0): (curl w)_x = d_y w, (curl w)_y = -d_x w
+    *m = 1 - p;
+    return p == 0 ? 1 : -1;
+  }
+  if (p == k) return 0;
+  *m = 3 - p - k;
+  // eps_{p m k}
+  return ((m[0] - p + 3) % 3 == 1) ? 1 : -1;
+}
+
+// Generic element kernel: one workgroup per element (grid-stride).  All per-point data
+// (J^-1, c, G) live in `pt` -- LDS when it fits (PT_LDS), per-block global scratch otherwise.
+template <int BLOCK, bool PT_LDS, bool DENSE>
+__global__ void __launch_bounds__(BLOCK) assemble_generic_kernel(AsmArgs A) {
+  extern __shared__ __align__(16) unsigned char smem_raw[];
+  const int dim = A.dim, nn = A.nn, nc = A.nc;
+  const int dd = dim * dim;
+  // which rules this form integrates on
+  const int qa = (A.form == PYN_FORM_MASS_NODAL) ? 2 : 0;  // primary rule
+  const bool kle = A.form == PYN_FORM_KLE;
+  const int nga = A.ngp[qa];
+  const int ngb = kle ? A.ngp[1] : 0;  // reduced rule only for KLE
+  const int ngt = nga + ngb;
+
+  double* Xs = reinterpret_cast<double*>(smem_raw);  // [nc*dim]
+  int32_t* ids = reinterpret_cast<int32_t*>(Xs + nc * dim);  // [nn] (padded to even)
+  double* pt_lds = reinterpret_cast<double*>(ids + ((nn + 1) & ~1));
+  const int pt_stride = dd + 1 + dim * nn;  // per point: Jinv[dd], c, G[dim][nn]
+  double* pt = PT_LDS ? pt_lds : (A.gscratch + (int64_t)blockIdx.x * A.gscratch_stride);
+
+  const int tid = threadIdx.x;
+  const int dw = dim == 2 ? 1 : 3;
+  const int64_t e_end = DENSE ? 1 : A.n_elem;
+
+  for (int64_t e = blockIdx.x; e < e_end; e += gridDim.x) {
+    __syncthreads();
+    // ---- gather corners + connectivity
+    for (int t = tid; t < nn; t += BLOCK) ids[t] = DENSE ? t : A.conn[e * nn + t];
+    for (int t = tid; t < nc * dim; t += BLOCK) {
+      if (DENSE) {
+        Xs[t] = A.corners[t];
+      } else {
+        int cn = t / dim, x = t - cn * dim;
+        Xs[t] = A.xyz[(int64_t)A.conn[e * nn + cn] * dim + x];
+      }
+    }
+    __syncthreads();
+    // ---- geometry at every point: J = HrsCoo.X (spectral.py:120,140), inverse, c = w detJ (:122,142)
+    for (int g = tid; g < ngt; g += BLOCK) {
+      const int q = g < nga ? qa : 1;
+      const int gl = g < nga ? g : g - nga;
+      const double* hc = A.HrsCoo[q] + (int64_t)gl * dim * nc;
+      double J[9], Ji[9];
+      for (int d = 0; d < dim; ++d)
+        for (int x = 0; x < dim; ++x) {
+          double s = 0.0;
+          for (int cn = 0; cn < nc; ++cn) s += hc[d * nc + cn] * Xs[cn * dim + x];
+          J[d * dim + x] = s;
+        }
+      double det = inv_det(J, Ji, dim);
+      double* P = pt + (int64_t)g * pt_stride;
+      for (int i = 0; i < dd; ++i) P[i] = Ji[i];
+      P[dd] = A.w[q][gl] * det;
+    }
+    __syncthreads();
+    // ---- physical gradients G = J^-1 Hrs (spectral.py:121,141)
+    for (int t = tid; t < ngt * dim * nn; t += BLOCK) {
+      int g = t / (dim * nn);
+      int r = t - g * dim * nn;
+      int d = r / nn, a = r - d * nn;
+      const int q = g < nga ? qa : 1;
+      const int gl = g < nga ? g : g - nga;
+      const double* hrs = A.Hrs[q] + (int64_t)gl * dim * nn;
+      double* P = pt + (int64_t)g * pt_stride;
+      double s = 0.0;
+      for (int x = 0; x < dim; ++x) s += P[d * dim + x] * hrs[x * nn + a];
+      P[dd + 1 + d * nn + a] = s;
+    }
+    __syncthreads();
+
+    // ---- entries.  ab (node pair) is the fast index so that a thread keeps the same pair
+    //      across components when nn*nn is a multiple of BLOCK (Q1 hex: 64 pairs = 64 lanes).
+    const int npair = nn * nn;
+    int last_ab = -1, slot = 0, r_lo = 0, r_len = 0;
+    auto locate = [&](int ab, int a, int b) {
+      if (ab != last_ab) {
+        last_ab = ab;
+        int row = ids[a];
+        if (row < A.n_owned) {
+          r_lo = A.rowptr[row];
+          r_len = A.rowptr[row + 1] - r_lo;
+          slot = find_slot(A.colidx, r_lo, r_len, ids[b]);
+        } else {
+          r_len = -1;
+        }
+      }
+    };
+
+    if (!kle) {
+      // scalar forms: A_ab = sum c G_a.G_b (Laplace) or sum c H_a H_b (mass)
+      for (int ab = tid; ab < npair; ab += BLOCK) {
+        int a = ab / nn, b = ab - a * nn;
+        double v = 0.0;
+        for (int g = 0; g < nga; ++g) {
+          const double* P = pt + (int64_t)g * pt_stride;
+          double cg = P[dd];
+          if (A.form == PYN_FORM_LAPLACE) {
+            double s = 0.0;
+            for (int d = 0; d < dim; ++d) s += P[dd + 1 + d * nn + a] * P[dd + 1 + d * nn + b];
+            v += cg * s;
+          } else {
+            const double* Hq = A.H[qa] + (int64_t)g * nn;
+            v += cg * Hq[a] * Hq[b];
+          }
+        }
+        if (DENSE) {
+          A.out0[ab] = v;
+        } else {
+          locate(ab, a, b);
+          if (r_len < 0) continue;
+          int ra = ids[a], cb = ids[b];
+          bool mr = A.bcmask && A.bcmask[ra], mc = A.bcmask && A.bcmask[cb];
+          if (mr) continue;
+          int64_t off = (int64_t)r_lo + slot;
+          if (mc) {
+            if (A.Krhs) atomicAdd(&A.Krhs[off], -v);
+          } else if (A.K) {
+            atomicAdd(&A.K[off], v);
+          }
+        }
+      }
+      continue;
+    }
+
+    // ---- KLE stiffness K (dim x dim blocks)
+    if (DENSE ? (A.out0 != nullptr) : (A.K != nullptr || A.Krhs != nullptr)) {
+      for (int t = tid; t < npair * dd; t += BLOCK) {
+        int pq = t / npair, ab = t - pq * npair;
+        int a = ab / nn, b = ab - a * nn;
+        int p = pq / dim, q = pq - p * dim;
+        double v = 0.0;
+        if (p == q) {
+          for (int g = 0; g < nga; ++g) {
+            const double* P = pt + (int64_t)g * pt_stride;
+            double s = 0.0;
+            for (int d = 0; d < dim; ++d) s += P[dd + 1 + d * nn + a] * P[dd + 1 + d * nn + b];
+            v += P[dd] * s;
+          }
+        }
+        for (int g = nga; g < ngt; ++g) {
+          const double* P = pt + (int64_t)g * pt_stride;
+          const double* G = P + dd + 1;
+          double pen = A.alpha_d * G[p * nn + a] * G[q * nn + b] - A.alpha_w * G[q * nn + a] * G[p * nn + b];
+          if (p == q) {
+            double s = 0.0;
+            for (int d = 0; d < dim; ++d) s += G[d * nn + a] * G[d * nn + b];
+            pen += A.alpha_w * s;
+          }
+          v += P[dd] * pen;
+        }
+        if (DENSE) {
+          A.out0[(int64_t)(a * dim + p) * (dim * nn) + b * dim + q] = v;
+        } else {
+          locate(ab, a, b);
+          if (r_len < 0) continue;
+          int64_t rd = (int64_t)ids[a] * dim + p, cd = (int64_t)ids[b] * dim + q;
+          bool mr = A.bcmask && A.bcmask[rd], mc = A.bcmask && A.bcmask[cd];
+          if (mr) continue;
+          int64_t off = ((int64_t)r_lo * dim + (int64_t)p * r_len + slot) * dim + q;
+          if (mc) {
+            if (A.Krhs) atomicAdd(&A.Krhs[off], -v);
+          } else if (A.K) {
+            atomicAdd(&A.K[off], v);
+          }
+        }
+      }
+    }
+    // ---- Rw (dim x dim_w blocks)
+    if (DENSE ? (A.out1 != nullptr) : (A.Rw != nullptr)) {
+      for (int t = tid; t < npair * dim * dw; t += BLOCK) {
+        int pk = t / npair, ab = t - pk * npair;
+        int a = ab / nn, b = ab - a * nn;
+        int p = pk / dw, k = pk - p * dw;
+        double v = 0.0;
+        int m = 0;
+        int sg = curl_term(dim, p, k, &m);  // (curl w)_p picks  sg * d_m w_k
+        if (sg != 0) {
+          for (int g = 0; g < nga; ++g) {
+            const double* P = pt + (int64_t)g * pt_stride;
+            v += P[dd] * A.H[0][(int64_t)g * nn + a] * (double)sg * P[dd + 1 + m * nn + b];
+          }
+          // reduced: alpha_w c Bc[k][(a,p)] H_b with (curl v)_k = eps_{k m p} d_m v_p
+          int m2 = 0;
+          int sg2;
+          if (dim == 2) {  // w = d_x v_y - d_y v_x
+            m2 = 1 - p;
+            sg2 = p == 0 ? -1 : 1;
+          } else {
+            sg2 = curl_term(3, k, p, &m2);
+          }
+          for (int g = nga; g < ngt; ++g) {
+            const double* P = pt + (int64_t)g * pt_stride;
+            v += P[dd] * A.alpha_w * (double)sg2 * P[dd + 1 + m2 * nn + a] * A.H[1][(int64_t)(g - nga) * nn + b];
+          }
+        }
+        if (DENSE) {
+          A.out1[(int64_t)(a * dim + p) * (dw * nn) + b * dw + k] = v;
+        } else {
+          locate(ab, a, b);
+          if (r_len < 0) continue;
+          int64_t rd = (int64_t)ids[a] * dim + p;
+          if (A.bcmask && A.bcmask[rd]) continue;
+          int64_t off = ((int64_t)r_lo * dim + (int64_t)p * r_len + slot) * dw + k;
+          if (v != 0.0) atomicAdd(&A.Rw[off], v);
+        }
+      }
+    }
+    // ---- Rd (dim x 1 blocks)
+    if (DENSE ? (A.out2 != nullptr) : (A.Rd != nullptr)) {
+      for (int t = tid; t < npair * dim; t += BLOCK) {
+        int p = t / npair, ab = t - p * npair;
+        int a = ab / nn, b = ab - a * nn;
+        double v = 0.0;
+        for (int g = 0; g < nga; ++g) {
+          const double* P = pt + (int64_t)g * pt_stride;
+          v -= P[dd] * A.H[0][(int64_t)g * nn + a] * P[dd + 1 + p * nn + b];
+        }
+        for (int g = nga; g < ngt; ++g) {
+          const double* P = pt + (int64_t)g * pt_stride;
+          v += P[dd] * A.alpha_d * P[dd + 1 + p * nn + a] * A.H[1][(int64_t)(g - nga) * nn + b];
+        }
+        if (DENSE) {
+          A.out2[(int64_t)(a * dim + p) * nn + b] = v;
+        } else {
+          locate(ab, a, b);
+          if (r_len < 0) continue;
+          int64_t rd = (int64_t)ids[a] * dim + p;
+          if (A.bcmask && A.bcmask[rd]) continue;
+          int64_t off = (int64_t)r_lo * dim + (int64_t)p * r_len + slot;
+          atomicAdd(&A.Rd[off], v);
+        }
+      }
+    }
+  }
+}
+
+// Unit diagonal on imposed DOFs: Mat.setIndices2One (mat_generator.py:113-118), single-rank
+// semantics (diag = 1).  One thread per owned DOF.
+__global__ void bc_identity_kernel(const int32_t* __restrict__ rowptr, const int32_t* __restrict__ colidx,
+                                   const uint8_t* __restrict__ mask, int64_t n_owned, int ndof, double* __restrict__ K,
+                                   double* __restrict__ Krhs) {
+  for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < n_owned * ndof; t += (int64_t)gridDim.x * blockDim.x) {
+    if (!mask[t]) continue;
+    int64_t i = t / ndof;
+    int p = (int)(t - i * ndof);
+    int lo = rowptr[i], len = rowptr[i + 1] - lo;
+    int slot = find_slot(colidx, lo, len, (int)i);
+    int64_t off = ((int64_t)lo * ndof + (int64_t)p * len + slot) * ndof + p;
+    if (K) K[off] = 1.0;
+    if (Krhs) Krhs[off] = 1.0;
+  }
+}
+
+size_t generic_smem(const pyn_ctx* c, int ngt, bool pt_lds) {
+  size_t s = (size_t)c->nc * c->dim * sizeof(double) + (size_t)((c->nn + 1) & ~1) * sizeof(int32_t);
+  if (pt_lds) s += (size_t)ngt * (c->dim * c->dim + 1 + c->dim * c->nn) * sizeof(double);
+  return s;
+}
+
+int fill_args(pyn_ctx* c, AsmArgs& A, int form) {
+  A.conn = c->d_conn;
+  A.xyz = c->d_xyz;
+  A.n_elem = c->n_elem;
+  A.n_owned = c->n_owned;
+  A.dim = c->dim;
+  A.nn = c->nn;
+  A.nc = c->nc;
+  for (int q = 0; q < 3; ++q) {
+    A.ngp[q] = c->quad[q].ngp;
+    A.w[q] = c->quad[q].w;
+    A.H[q] = c->quad[q].H;
+    A.Hrs[q] = c->quad[q].Hrs;
+    A.HrsCoo[q] = c->quad[q].HrsCoo;
+  }
+  A.rowptr = c->d_rowptr;
+  A.colidx = c->d_colidx;
+  A.bcmask = nullptr;
+  A.form = form;
+  A.alpha_d = A.alpha_w = 0.0;
+  A.K = A.Krhs = A.Rw = A.Rd = nullptr;
+  A.corners = nullptr;
+  A.out0 = A.out1 = A.out2 = nullptr;
+  A.gscratch = nullptr;
+  A.gscratch_stride = 0;
+  const int qa = form == PYN_FORM_MASS_NODAL ? 2 : 0;
+  PYN_CHECK(c->quad[qa].ngp > 0, "element tables for rule %d not set", qa);
+  if (form == PYN_FORM_KLE) PYN_CHECK(c->quad[1].ngp > 0, "reduced-rule tables not set");
+  return PYN_OK;
+}
+
+template <bool DENSE>
+int launch_generic(pyn_ctx* c, AsmArgs& A, int64_t n_work) {
+  const int qa = A.form == PYN_FORM_MASS_NODAL ? 2 : 0;
+  const int ngt = A.ngp[qa] + (A.form == PYN_FORM_KLE ? A.ngp[1] : 0);
+  const size_t pt_bytes = (size_t)ngt * (c->dim * c->dim + 1 + c->dim * c->nn) * sizeof(double);
+  const bool pt_lds = pt_bytes <= 40 * 1024;
+  const bool small = c->nn <= 8;
+  int grid = (int)std::min<int64_t>(n_work, small ? 256 * 32 : 256 * 4);
+  if (!pt_lds) {
+    A.gscratch_stride = (int64_t)(pt_bytes / sizeof(double));
+    PYN_TRY(pyn_ensure_work(c, (size_t)grid * pt_bytes));
+    A.gscratch = c->d_work;
+  }
+  size_t smem = generic_smem(c, ngt, pt_lds);
+  if (small) {
+    assemble_generic_kernel<64, true, DENSE><<<grid, 64, smem, c->stream>>>(A);
+  } else if (pt_lds) {
+    assemble_generic_kernel<256, true, DENSE><<<grid, 256, smem, c->stream>>>(A);
+  } else {
+    assemble_generic_kernel<256, false, DENSE><<<grid, 256, smem, c->stream>>>(A);
+  }
+  PYN_HIP(hipGetLastError());
+  return PYN_OK;
+}
+
+}  // namespace
+
+int pyn_assemble_q1_tiled(pyn_ctx* c, int form, double alpha_d, double alpha_w, double* K, double* Krhs, double* Rw,
+                          double* Rd, bool* handled);
+
+static int mat_ptr(pyn_ctx* c, int id, int br, int bc, const char* name, double** out) {
+  *out = nullptr;
+  if (id < 0) return PYN_OK;
+  PYN_TRY(pyn_check_mat(c, id, name));
+  DMat& m = c->mats[id];
+  PYN_CHECK(m.br == br && m.bc == bc, "%s must have block shape %dx%d (has %dx%d)", name, br, bc, m.br, m.bc);
+  PYN_HIP(hipMemsetAsync(m.val, 0, (size_t)c->nnzb * br * bc * sizeof(double), c->stream));
+  *out = m.val;
+  return PYN_OK;
+}
+
+static int run_assembly(pyn_ctx* c, int form, double alpha_d, double alpha_w, double* K, double* Krhs, double* Rw,
+                        double* Rd, int variant) {
+  PYN_CHECK(c->d_rowptr, "pyn_csr_symbolic first");
+  const int ndof = form == PYN_FORM_KLE ? c->dim : 1;
+  if (c->d_bcmask) PYN_CHECK(c->bc_ndof == ndof, "bc mask has ndof=%d, form needs %d", c->bc_ndof, ndof);
+  AsmArgs A;
+  PYN_TRY(fill_args(c, A, form));
+  A.bcmask = c->d_bcmask;
+  A.alpha_d = alpha_d;
+  A.alpha_w = alpha_w;
+  A.K = K;
+  A.Krhs = Krhs;
+  A.Rw = Rw;
+  A.Rd = Rd;
+  PYN_HIP(hipEventRecord(c->ev0, c->stream));
+  bool handled = false;
+  if (variant != 0) PYN_TRY(pyn_assemble_q1_tiled(c, form, alpha_d, alpha_w, K, Krhs, Rw, Rd, &handled));
+  if (!handled) PYN_TRY(launch_generic<false>(c, A, c->n_elem));
+  if (c->d_bcmask && (K || Krhs)) {
+    int64_t n = c->n_owned * ndof;
+    int grid = (int)std::min<int64_t>((n + 255) / 256, 4096);
+    bc_identity_kernel<<<grid, 256, 0, c->stream>>>(c->d_rowptr, c->d_colidx, c->d_bcmask, c->n_owned, ndof, K, Krhs);
+  }
+  PYN_HIP(hipEventRecord(c->ev1, c->stream));
+  PYN_HIP(hipStreamSynchronize(c->stream));
+  float ms = 0;
+  PYN_HIP(hipEventElapsedTime(&ms, c->ev0, c->ev1));
+  c->timers[PYN_T_ASSEMBLE] = ms;
+  return PYN_OK;
+}
+
+extern "C" int pyn_assemble_kle(pyn_ctx* c, double alpha_d, double alpha_w, int K, int Krhs, int Rw, int Rd, int variant) {
+  PYN_CHECK(c, "ctx is NULL");
+  PYN_HIP(hipSetDevice(c->device));
+  const int dim = c->dim, dw = dim == 2 ? 1 : 3;
+  double *pK, *pKr, *pRw, *pRd;
+  PYN_TRY(mat_ptr(c, K, dim, dim, "K", &pK));
+  PYN_TRY(mat_ptr(c, Krhs, dim, dim, "Krhs", &pKr));
+  PYN_TRY(mat_ptr(c, Rw, dim, dw, "Rw", &pRw));
+  PYN_TRY(mat_ptr(c, Rd, dim, 1, "Rd", &pRd));
+  return run_assembly(c, PYN_FORM_KLE, alpha_d, alpha_w, pK, pKr, pRw, pRd, variant);
+}
+
+extern "C" int pyn_assemble_scalar(pyn_ctx* c, int form, int Aid, int Arhs, int variant) {
+  PYN_CHECK(c, "ctx is NULL");
+  PYN_CHECK(form == PYN_FORM_LAPLACE || form == PYN_FORM_MASS_NODAL || form == PYN_FORM_MASS_FULL, "bad scalar form");
+  PYN_HIP(hipSetDevice(c->device));
+  double *pA, *pAr;
+  PYN_TRY(mat_ptr(c, Aid, 1, 1, "A", &pA));
+  PYN_TRY(mat_ptr(c, Arhs, 1, 1, "Arhs", &pAr));
+  return run_assembly(c, form, 0.0, 0.0, pA, pAr, nullptr, nullptr, variant);
+}
+
+extern "C" int pyn_elem_local(pyn_ctx* c, int form, double alpha_d, double alpha_w, const double* corners, double* out0,
+                              double* out1, double* out2) {
+  PYN_CHECK(c && corners, "NULL argument");
+  PYN_CHECK(c->nn > 0, "pyn_mesh_set first (it fixes dim / nn)");
+  PYN_HIP(hipSetDevice(c->device));
+  const int dim = c->dim, nn = c->nn, dw = dim == 2 ? 1 : 3;
+  const bool kle = form == PYN_FORM_KLE;
+  size_t n0 = kle ? (size_t)dim * nn * dim * nn : (size_t)nn * nn;
+  size_t n1 = kle ? (size_t)dim * nn * dw * nn : 0;
+  size_t n2 = kle ? (size_t)dim * nn * nn : 0;
+  size_t ncor = (size_t)c->nc * dim;
+  size_t need = (n0 + n1 + n2 + ncor) * sizeof(double);
+  if (need > c->eloc_bytes) {
+    if (c->d_eloc) PYN_HIP(hipFree(c->d_eloc));
+    c->d_eloc = nullptr;
+    PYN_HIP(hipMalloc((void**)&c->d_eloc, need));
+    c->eloc_bytes = need;
+  }
+  double* d_cor = c->d_eloc;
+  double* d0 = d_cor + ncor;
+  double* d1 = d0 + n0;
+  double* d2 = d1 + n1;
+  PYN_HIP(hipMemcpyAsync(d_cor, corners, ncor * sizeof(double), hipMemcpyHostToDevice, c->stream));
+  AsmArgs A;
+  PYN_TRY(fill_args(c, A, form));
+  A.alpha_d = alpha_d;
+  A.alpha_w = alpha_w;
+  A.corners = d_cor;
+  A.out0 = out0 ? d0 : nullptr;
+  A.out1 = (kle && out1) ? d1 : nullptr;
+  A.out2 = (kle && out2) ? d2 : nullptr;
+  PYN_TRY(launch_generic<true>(c, A, 1));
+  if (out0) PYN_HIP(hipMemcpyAsync(out0, d0, n0 * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+  if (kle && out1) PYN_HIP(hipMemcpyAsync(out1, d1, n1 * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+  if (kle && out2) PYN_HIP(hipMemcpyAsync(out2, d2, n2 * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+  PYN_HIP(hipStreamSynchronize(c->stream));
+  return PYN_OK;
+}

@@ -1,0 +1,566 @@
+// Context, communicator, mesh/table upload, device vectors and matrices of libpynama_hip.so.
+#include <cstdarg>
+#include <cstring>
+
+#include "pyn_internal.h"
+
+// ---------------------------------------------------------------------------------------------
+static thread_local char g_err[1024] = "";
+
+void pyn_set_error(const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof(g_err), fmt, ap);
+  va_end(ap);
+}
+
+extern "C" const char* pyn_last_error(void) { return g_err; }
+extern "C" int pyn_version(void) { return 100; }
+
+extern "C" int pyn_device_count(int* count) {
+  PYN_CHECK(count, "count is NULL");
+  int n = 0;
+  hipError_t e = hipGetDeviceCount(&n);
+  if (e != hipSuccess) {
+    (void)hipGetLastError();
+    n = 0;
+  }
+  *count = n;
+  return PYN_OK;
+}
+
+template <typename T>
+static int dev_upload(T** dst, const T* src, size_t n, hipStream_t s) {
+  if (*dst) {
+    PYN_HIP(hipFree(*dst));
+    *dst = nullptr;
+  }
+  if (n == 0) return PYN_OK;
+  PYN_HIP(hipMalloc((void**)dst, n * sizeof(T)));
+  if (src) PYN_HIP(hipMemcpyAsync(*dst, src, n * sizeof(T), hipMemcpyHostToDevice, s));
+  return PYN_OK;
+}
+
+extern "C" int pyn_ctx_create(int device, pyn_ctx** out) {
+  PYN_CHECK(out, "out is NULL");
+  int n = 0;
+  PYN_TRY(pyn_device_count(&n));
+  if (n <= 0) {
+    pyn_set_error("no HIP device visible: libpynama_hip.so has no CPU fallback");
+    return PYN_ENOGPU;
+  }
+  PYN_CHECK(device >= 0 && device < n, "device %d out of range [0,%d)", device, n);
+  PYN_HIP(hipSetDevice(device));
+  hipDeviceProp_t prop;
+  PYN_HIP(hipGetDeviceProperties(&prop, device));
+  if (strncmp(prop.gcnArchName, "gfx950", 6) != 0) {
+    pyn_set_error("device %d is %s; this library is built for gfx950 (MI355X) only", device, prop.gcnArchName);
+    return PYN_ENOGPU;
+  }
+  pyn_ctx* c = new pyn_ctx();
+  c->device = device;
+  PYN_HIP(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+  PYN_HIP(hipEventCreate(&c->ev0));
+  PYN_HIP(hipEventCreate(&c->ev1));
+  PYN_HIP(hipMalloc((void**)&c->d_part, 8 * PYN_MAX_PARTIALS * sizeof(double)));
+  PYN_HIP(hipMalloc((void**)&c->d_scal, 64 * sizeof(double)));
+  PYN_HIP(hipMalloc((void**)&c->d_flag, 8 * sizeof(int)));
+  PYN_HIP(hipMemset(c->d_scal, 0, 64 * sizeof(double)));
+  PYN_HIP(hipMemset(c->d_flag, 0, 8 * sizeof(int)));
+  PYN_HIP(hipHostMalloc((void**)&c->h_scal, 64 * sizeof(double), hipHostMallocDefault));
+  PYN_HIP(hipHostMalloc((void**)&c->h_flag, 8 * sizeof(int), hipHostMallocDefault));
+  *out = c;
+  return PYN_OK;
+}
+
+static void free_quad(QuadTab& q) {
+  (void)hipFree(q.w);
+  (void)hipFree(q.H);
+  (void)hipFree(q.Hrs);
+  (void)hipFree(q.HrsCoo);
+  q = QuadTab();
+}
+
+extern "C" int pyn_ctx_destroy(pyn_ctx* c) {
+  if (!c) return PYN_OK;
+  (void)hipSetDevice(c->device);
+  (void)hipStreamSynchronize(c->stream);
+  if (c->comm) ncclCommDestroy(c->comm);
+  for (auto& m : c->mats) (void)hipFree(m.val);
+  for (auto& v : c->vecs) (void)hipFree(v.d);
+  for (auto& q : c->quad) free_quad(q);
+  (void)hipFree(c->d_conn);
+  (void)hipFree(c->d_xyz);
+  (void)hipFree(c->d_bcmask);
+  (void)hipFree(c->d_rowptr);
+  (void)hipFree(c->d_colidx);
+  (void)hipFree(c->d_send_idx);
+  (void)hipFree(c->d_send_buf);
+  (void)hipFree(c->d_part);
+  (void)hipFree(c->d_scal);
+  (void)hipFree(c->d_flag);
+  (void)hipFree(c->d_work);
+  (void)hipFree(c->d_eloc);
+  (void)hipHostFree(c->h_scal);
+  (void)hipHostFree(c->h_flag);
+  (void)hipEventDestroy(c->ev0);
+  (void)hipEventDestroy(c->ev1);
+  (void)hipStreamDestroy(c->stream);
+  delete c;
+  return PYN_OK;
+}
+
+extern "C" int pyn_sync(pyn_ctx* c) {
+  PYN_CHECK(c, "ctx is NULL");
+  PYN_HIP(hipStreamSynchronize(c->stream));
+  return PYN_OK;
+}
+
+int pyn_ensure_work(pyn_ctx* c, size_t bytes) {
+  if (bytes <= c->work_bytes) return PYN_OK;
+  if (c->d_work) PYN_HIP(hipFree(c->d_work));
+  c->d_work = nullptr;
+  PYN_HIP(hipMalloc((void**)&c->d_work, bytes));
+  c->work_bytes = bytes;
+  return PYN_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// communicator
+extern "C" int pyn_comm_unique_id(void* out, int nbytes) {
+  PYN_CHECK(out && nbytes >= (int)sizeof(ncclUniqueId), "need >= %d bytes", (int)sizeof(ncclUniqueId));
+  ncclUniqueId id;
+  PYN_NCCL(ncclGetUniqueId(&id));
+  memcpy(out, &id, sizeof(id));
+  return PYN_OK;
+}
+
+extern "C" int pyn_comm_init(pyn_ctx* c, int rank, int nranks, const void* uid, int nbytes) {
+  PYN_CHECK(c, "ctx is NULL");
+  PYN_CHECK(nranks >= 1 && rank >= 0 && rank < nranks, "bad rank %d / %d", rank, nranks);
+  c->rank = rank;
+  c->nranks = nranks;
+  if (nranks == 1) return PYN_OK;
+  PYN_CHECK(uid && nbytes >= (int)sizeof(ncclUniqueId), "unique id missing");
+  ncclUniqueId id;
+  memcpy(&id, uid, sizeof(id));
+  PYN_HIP(hipSetDevice(c->device));
+  PYN_NCCL(ncclCommInitRank(&c->comm, nranks, id, rank));
+  return PYN_OK;
+}
+
+extern "C" int pyn_comm_allreduce_f64(pyn_ctx* c, double* inout, int n, int op) {
+  PYN_CHECK(c && inout && n > 0 && n <= 32, "bad arguments");
+  if (c->nranks == 1) return PYN_OK;
+  PYN_HIP(hipMemcpyAsync(c->d_scal + 32, inout, n * sizeof(double), hipMemcpyHostToDevice, c->stream));
+  PYN_NCCL(ncclAllReduce(c->d_scal + 32, c->d_scal + 32, n, ncclDouble, op == 1 ? ncclMax : ncclSum, c->comm,
+                         c->stream));
+  PYN_HIP(hipMemcpyAsync(inout, c->d_scal + 32, n * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+  PYN_HIP(hipStreamSynchronize(c->stream));
+  return PYN_OK;
+}
+
+extern "C" int pyn_comm_barrier(pyn_ctx* c) {
+  PYN_CHECK(c, "ctx is NULL");
+  PYN_HIP(hipStreamSynchronize(c->stream));
+  double one = 1.0;
+  return pyn_comm_allreduce_f64(c, &one, 1, 0);
+}
+
+extern "C" int pyn_halo_set(pyn_ctx* c, int64_t n_owned, int64_t n_ghost, int n_neigh, const int32_t* neigh,
+                            const int64_t* send_ptr, const int32_t* send_idx, const int64_t* recv_ptr) {
+  PYN_CHECK(c, "ctx is NULL");
+  PYN_CHECK(n_owned >= 0 && n_ghost >= 0 && n_neigh >= 0, "negative sizes");
+  PYN_CHECK(c->n_node == 0, "pyn_halo_set must precede pyn_mesh_set");
+  c->n_owned = n_owned;
+  c->n_ghost = n_ghost;
+  c->neigh.assign(neigh, neigh + n_neigh);
+  c->send_ptr.assign(send_ptr, send_ptr + n_neigh + 1);
+  c->recv_ptr.assign(recv_ptr, recv_ptr + n_neigh + 1);
+  PYN_CHECK(c->recv_ptr[n_neigh] == n_ghost, "recv_ptr does not cover the ghosts");
+  c->n_send = c->send_ptr[n_neigh];
+  for (int k = 0; k < n_neigh; ++k) PYN_CHECK(neigh[k] >= 0 && neigh[k] < c->nranks && neigh[k] != c->rank, "bad neighbour");
+  for (int64_t i = 0; i < c->n_send; ++i) PYN_CHECK(send_idx[i] >= 0 && send_idx[i] < n_owned, "send_idx out of range");
+  PYN_TRY(dev_upload(&c->d_send_idx, send_idx, (size_t)c->n_send, c->stream));
+  if (c->d_send_buf) PYN_HIP(hipFree(c->d_send_buf));
+  c->d_send_buf = nullptr;
+  if (c->n_send) PYN_HIP(hipMalloc((void**)&c->d_send_buf, (size_t)c->n_send * 6 * sizeof(double)));
+  PYN_HIP(hipStreamSynchronize(c->stream));
+  c->halo_set = true;
+  return PYN_OK;
+}
+
+__global__ void pack_send_kernel(const double* __restrict__ x, const int32_t* __restrict__ idx, double* __restrict__ buf,
+                                 int64_t n, int bs) {
+  int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (; t < n * bs; t += stride) {
+    int64_t i = t / bs;
+    int q = (int)(t - i * bs);
+    buf[t] = x[(int64_t)idx[i] * bs + q];
+  }
+}
+
+int pyn_halo_exchange(pyn_ctx* c, double* x, int bs) {
+  if (c->nranks == 1 || c->neigh.empty()) return PYN_OK;
+  PYN_CHECK(bs <= 6, "block size too large for the halo buffer");
+  if (c->n_send) {
+    int64_t tot = c->n_send * bs;
+    int grid = (int)std::min<int64_t>((tot + 255) / 256, 1024);
+    pack_send_kernel<<<grid, 256, 0, c->stream>>>(x, c->d_send_idx, c->d_send_buf, c->n_send, bs);
+  }
+  PYN_NCCL(ncclGroupStart());
+  for (size_t k = 0; k < c->neigh.size(); ++k) {
+    int64_t ns = c->send_ptr[k + 1] - c->send_ptr[k];
+    int64_t nr = c->recv_ptr[k + 1] - c->recv_ptr[k];
+    if (ns) PYN_NCCL(ncclSend(c->d_send_buf + c->send_ptr[k] * bs, (size_t)ns * bs, ncclDouble, c->neigh[k], c->comm, c->stream));
+    if (nr) PYN_NCCL(ncclRecv(x + (c->n_owned + c->recv_ptr[k]) * bs, (size_t)nr * bs, ncclDouble, c->neigh[k], c->comm, c->stream));
+  }
+  PYN_NCCL(ncclGroupEnd());
+  return PYN_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// mesh / tables / bc
+extern "C" int pyn_mesh_set(pyn_ctx* c, int dim, int nn, int64_t n_elem, int64_t n_node, const int32_t* conn,
+                            const double* xyz) {
+  PYN_CHECK(c && conn && xyz, "NULL argument");
+  PYN_CHECK(dim == 2 || dim == 3, "dim must be 2 or 3");
+  int ngl = 0;
+  for (int g = 2; g <= 32; ++g) {
+    int p = 1;
+    for (int d = 0; d < dim; ++d) p *= g;
+    if (p == nn) ngl = g;
+  }
+  PYN_CHECK(ngl >= 2, "nn=%d is not ngl^dim", nn);
+  PYN_CHECK(n_elem > 0 && n_node > 0 && n_node < (int64_t)INT32_MAX, "bad sizes");
+  if (!c->halo_set) {
+    c->n_owned = n_node;
+    c->n_ghost = 0;
+  }
+  PYN_CHECK(c->n_owned + c->n_ghost == n_node, "n_node %lld != owned+ghost %lld", (long long)n_node,
+            (long long)(c->n_owned + c->n_ghost));
+  for (int64_t i = 0; i < n_elem * nn; ++i)
+    PYN_CHECK(conn[i] >= 0 && conn[i] < n_node, "conn[%lld]=%d out of range", (long long)i, conn[i]);
+  c->dim = dim;
+  c->nn = nn;
+  c->nc = 1 << dim;
+  c->ngl = ngl;
+  c->n_elem = n_elem;
+  c->n_node = n_node;
+  PYN_HIP(hipSetDevice(c->device));
+  PYN_TRY(dev_upload(&c->d_conn, conn, (size_t)n_elem * nn, c->stream));
+  PYN_TRY(dev_upload(&c->d_xyz, xyz, (size_t)n_node * dim, c->stream));
+  PYN_HIP(hipStreamSynchronize(c->stream));
+  // graph + matrices depend on the mesh
+  (void)hipFree(c->d_rowptr);
+  (void)hipFree(c->d_colidx);
+  c->d_rowptr = nullptr;
+  c->d_colidx = nullptr;
+  c->nnzb = 0;
+  return PYN_OK;
+}
+
+extern "C" int pyn_elem_tables_set(pyn_ctx* c, int which, int ngp, const double* w, const double* H, const double* Hrs,
+                                   const double* HrsCoo) {
+  PYN_CHECK(c && w && H && Hrs && HrsCoo, "NULL argument");
+  PYN_CHECK(which >= 0 && which < 3, "bad table slot");
+  PYN_CHECK(c->nn > 0, "pyn_mesh_set first");
+  PYN_CHECK(ngp > 0, "ngp must be positive");
+  QuadTab& q = c->quad[which];
+  q.ngp = ngp;
+  PYN_TRY(dev_upload(&q.w, w, (size_t)ngp, c->stream));
+  PYN_TRY(dev_upload(&q.H, H, (size_t)ngp * c->nn, c->stream));
+  PYN_TRY(dev_upload(&q.Hrs, Hrs, (size_t)ngp * c->dim * c->nn, c->stream));
+  PYN_TRY(dev_upload(&q.HrsCoo, HrsCoo, (size_t)ngp * c->dim * c->nc, c->stream));
+  PYN_HIP(hipStreamSynchronize(c->stream));
+  return PYN_OK;
+}
+
+extern "C" int pyn_bc_set(pyn_ctx* c, int ndof, const uint8_t* mask) {
+  PYN_CHECK(c, "ctx is NULL");
+  PYN_CHECK(c->n_node > 0, "pyn_mesh_set first");
+  if (!mask) {
+    (void)hipFree(c->d_bcmask);
+    c->d_bcmask = nullptr;
+    c->bc_ndof = 0;
+    return PYN_OK;
+  }
+  PYN_CHECK(ndof >= 1 && ndof <= 3, "ndof must be 1..3");
+  PYN_TRY(dev_upload(&c->d_bcmask, mask, (size_t)c->n_node * ndof, c->stream));
+  PYN_HIP(hipStreamSynchronize(c->stream));
+  c->bc_ndof = ndof;
+  return PYN_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// matrices / vectors
+int pyn_check_mat(pyn_ctx* c, int id, const char* what) {
+  PYN_CHECK(c, "ctx is NULL");
+  PYN_CHECK(id >= 0 && id < (int)c->mats.size() && c->mats[id].live, "%s: invalid matrix handle %d", what, id);
+  return PYN_OK;
+}
+int pyn_check_vec(pyn_ctx* c, int id, const char* what) {
+  PYN_CHECK(c, "ctx is NULL");
+  PYN_CHECK(id >= 0 && id < (int)c->vecs.size() && c->vecs[id].live, "%s: invalid vector handle %d", what, id);
+  return PYN_OK;
+}
+
+extern "C" int pyn_mat_create(pyn_ctx* c, int br, int bc, int* mat_id) {
+  PYN_CHECK(c && mat_id, "NULL argument");
+  PYN_CHECK(c->d_rowptr, "pyn_csr_symbolic first");
+  PYN_CHECK(br >= 1 && br <= 6 && bc >= 1 && bc <= 6, "block shape out of range");
+  DMat m;
+  m.br = br;
+  m.bc = bc;
+  size_t n = (size_t)c->nnzb * br * bc;
+  PYN_HIP(hipMalloc((void**)&m.val, n * sizeof(double)));
+  PYN_HIP(hipMemsetAsync(m.val, 0, n * sizeof(double), c->stream));
+  m.live = true;
+  c->mats.push_back(m);
+  *mat_id = (int)c->mats.size() - 1;
+  return PYN_OK;
+}
+
+extern "C" int pyn_mat_zero(pyn_ctx* c, int id) {
+  PYN_TRY(pyn_check_mat(c, id, "pyn_mat_zero"));
+  DMat& m = c->mats[id];
+  PYN_HIP(hipMemsetAsync(m.val, 0, (size_t)c->nnzb * m.br * m.bc * sizeof(double), c->stream));
+  return PYN_OK;
+}
+
+extern "C" int pyn_mat_get_values(pyn_ctx* c, int id, double* val) {
+  PYN_TRY(pyn_check_mat(c, id, "pyn_mat_get_values"));
+  PYN_CHECK(val, "val is NULL");
+  DMat& m = c->mats[id];
+  PYN_HIP(hipMemcpyAsync(val, m.val, (size_t)c->nnzb * m.br * m.bc * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+  PYN_HIP(hipStreamSynchronize(c->stream));
+  return PYN_OK;
+}
+
+extern "C" int pyn_vec_create(pyn_ctx* c, int bs, int* vec_id) {
+  PYN_CHECK(c && vec_id, "NULL argument");
+  PYN_CHECK(c->n_node > 0, "pyn_mesh_set first");
+  PYN_CHECK(bs >= 1 && bs <= 6, "block size out of range");
+  DVec v;
+  v.bs = bs;
+  size_t n = (size_t)n_local(c) * bs;
+  PYN_HIP(hipMalloc((void**)&v.d, n * sizeof(double)));
+  PYN_HIP(hipMemsetAsync(v.d, 0, n * sizeof(double), c->stream));
+  v.live = true;
+  for (size_t i = 0; i < c->vecs.size(); ++i)
+    if (!c->vecs[i].live) {
+      c->vecs[i] = v;
+      *vec_id = (int)i;
+      return PYN_OK;
+    }
+  c->vecs.push_back(v);
+  *vec_id = (int)c->vecs.size() - 1;
+  return PYN_OK;
+}
+
+extern "C" int pyn_vec_destroy(pyn_ctx* c, int id) {
+  PYN_TRY(pyn_check_vec(c, id, "pyn_vec_destroy"));
+  PYN_HIP(hipStreamSynchronize(c->stream));
+  PYN_HIP(hipFree(c->vecs[id].d));
+  c->vecs[id] = DVec();
+  return PYN_OK;
+}
+
+extern "C" int pyn_vec_set_host(pyn_ctx* c, int id, const double* src) {
+  PYN_TRY(pyn_check_vec(c, id, "pyn_vec_set_host"));
+  PYN_CHECK(src, "src is NULL");
+  DVec& v = c->vecs[id];
+  PYN_HIP(hipMemcpyAsync(v.d, src, (size_t)c->n_owned * v.bs * sizeof(double), hipMemcpyHostToDevice, c->stream));
+  PYN_HIP(hipStreamSynchronize(c->stream));
+  return PYN_OK;
+}
+
+extern "C" int pyn_vec_get_host(pyn_ctx* c, int id, double* dst) {
+  PYN_TRY(pyn_check_vec(c, id, "pyn_vec_get_host"));
+  PYN_CHECK(dst, "dst is NULL");
+  DVec& v = c->vecs[id];
+  PYN_HIP(hipMemcpyAsync(dst, v.d, (size_t)c->n_owned * v.bs * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+  PYN_HIP(hipStreamSynchronize(c->stream));
+  return PYN_OK;
+}
+
+static inline int ew_grid(int64_t n) { return (int)std::max<int64_t>(1, std::min<int64_t>((n + 511) / 512, PYN_MAX_PARTIALS)); }
+
+__global__ void fill_kernel(double* __restrict__ x, int64_t n, double v) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) x[i] = v;
+}
+
+extern "C" int pyn_vec_fill(pyn_ctx* c, int id, double value) {
+  PYN_TRY(pyn_check_vec(c, id, "pyn_vec_fill"));
+  DVec& v = c->vecs[id];
+  int64_t n = n_local(c) * v.bs;
+  fill_kernel<<<ew_grid(n), 256, 0, c->stream>>>(v.d, n, value);
+  return PYN_OK;
+}
+
+__global__ void scatter_kernel(double* __restrict__ x, const int32_t* __restrict__ idx, const double* __restrict__ vals,
+                               int64_t n, int add) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    if (add)
+      atomicAdd(&x[idx[i]], vals[i]);
+    else
+      x[idx[i]] = vals[i];
+  }
+}
+
+extern "C" int pyn_vec_scatter_host(pyn_ctx* c, int id, int64_t n, const int32_t* idx, const double* vals, int add) {
+  PYN_TRY(pyn_check_vec(c, id, "pyn_vec_scatter_host"));
+  if (n == 0) return PYN_OK;
+  PYN_CHECK(idx && vals, "NULL argument");
+  DVec& v = c->vecs[id];
+  int64_t lim = c->n_owned * v.bs;
+  for (int64_t i = 0; i < n; ++i) PYN_CHECK(idx[i] >= 0 && idx[i] < lim, "index %d out of range [0,%lld)", idx[i], (long long)lim);
+  size_t bytes = (size_t)n * (sizeof(int32_t) + sizeof(double)) + 16;
+  PYN_TRY(pyn_ensure_work(c, bytes));
+  double* dv = c->d_work;
+  int32_t* di = (int32_t*)(dv + n);
+  PYN_HIP(hipMemcpyAsync(dv, vals, n * sizeof(double), hipMemcpyHostToDevice, c->stream));
+  PYN_HIP(hipMemcpyAsync(di, idx, n * sizeof(int32_t), hipMemcpyHostToDevice, c->stream));
+  scatter_kernel<<<ew_grid(n), 256, 0, c->stream>>>(v.d, di, dv, n, add);
+  PYN_HIP(hipStreamSynchronize(c->stream));
+  return PYN_OK;
+}
+
+__global__ void axpby_kernel(double* __restrict__ w, double a, const double* __restrict__ x, double b,
+                             const double* __restrict__ y, int64_t n) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    double r = 0.0;
+    if (a != 0.0) r += a * x[i];
+    if (b != 0.0) r += b * y[i];
+    w[i] = r;
+  }
+}
+
+extern "C" int pyn_vec_axpby(pyn_ctx* c, int w, double a, int x, double b, int y) {
+  PYN_TRY(pyn_check_vec(c, w, "axpby w"));
+  PYN_TRY(pyn_check_vec(c, x, "axpby x"));
+  PYN_TRY(pyn_check_vec(c, y, "axpby y"));
+  PYN_CHECK(c->vecs[w].bs == c->vecs[x].bs && c->vecs[w].bs == c->vecs[y].bs, "block size mismatch");
+  int64_t n = c->n_owned * c->vecs[w].bs;
+  axpby_kernel<<<ew_grid(n), 256, 0, c->stream>>>(c->vecs[w].d, a, c->vecs[x].d, b, c->vecs[y].d, n);
+  return PYN_OK;
+}
+
+__global__ void pmult_kernel(double* __restrict__ w, const double* __restrict__ x, const double* __restrict__ y, int64_t n,
+                             int recip) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+    w[i] = recip ? 1.0 / x[i] : x[i] * y[i];
+}
+
+extern "C" int pyn_vec_pointwise_mult(pyn_ctx* c, int w, int x, int y) {
+  PYN_TRY(pyn_check_vec(c, w, "pmult w"));
+  PYN_TRY(pyn_check_vec(c, x, "pmult x"));
+  PYN_TRY(pyn_check_vec(c, y, "pmult y"));
+  PYN_CHECK(c->vecs[w].bs == c->vecs[x].bs && c->vecs[w].bs == c->vecs[y].bs, "block size mismatch");
+  int64_t n = c->n_owned * c->vecs[w].bs;
+  pmult_kernel<<<ew_grid(n), 256, 0, c->stream>>>(c->vecs[w].d, c->vecs[x].d, c->vecs[y].d, n, 0);
+  return PYN_OK;
+}
+
+extern "C" int pyn_vec_reciprocal(pyn_ctx* c, int x) {
+  PYN_TRY(pyn_check_vec(c, x, "reciprocal"));
+  int64_t n = c->n_owned * c->vecs[x].bs;
+  pmult_kernel<<<ew_grid(n), 256, 0, c->stream>>>(c->vecs[x].d, c->vecs[x].d, c->vecs[x].d, n, 1);
+  return PYN_OK;
+}
+
+// ---- reductions ------------------------------------------------------------------------------
+__device__ inline double wave_sum(double v) {
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+__device__ inline double wave_max(double v) {
+  for (int o = 32; o > 0; o >>= 1) v = fmax(v, __shfl_xor(v, o, 64));
+  return v;
+}
+
+// mode 0: sum x*y ; 1: sum |x| ; 2: max |x|
+__global__ void __launch_bounds__(256) reduce_kernel(const double* __restrict__ x, const double* __restrict__ y, int64_t n,
+                                                     int mode, double* __restrict__ part) {
+  __shared__ double sm[4];
+  double acc = 0.0;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    double a = x[i];
+    if (mode == 0)
+      acc += a * y[i];
+    else if (mode == 1)
+      acc += fabs(a);
+    else
+      acc = fmax(acc, fabs(a));
+  }
+  acc = mode == 2 ? wave_max(acc) : wave_sum(acc);
+  int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+  if (lane == 0) sm[wid] = acc;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    double r = sm[0];
+    for (int k = 1; k < 4; ++k) r = mode == 2 ? fmax(r, sm[k]) : r + sm[k];
+    part[blockIdx.x] = r;
+  }
+}
+
+// one block: out[s] = reduce(part[s*PYN_MAX_PARTIALS + 0..nblocks))
+__global__ void __launch_bounds__(256) finish_kernel(const double* __restrict__ part, int nslots, int nblocks, int op,
+                                                     double* __restrict__ out) {
+  __shared__ double sm[4];
+  for (int s = 0; s < nslots; ++s) {
+    double acc = 0.0;
+    for (int i = threadIdx.x; i < nblocks; i += 256) {
+      double v = part[s * PYN_MAX_PARTIALS + i];
+      acc = op == 1 ? fmax(acc, v) : acc + v;
+    }
+    acc = op == 1 ? wave_max(acc) : wave_sum(acc);
+    if ((threadIdx.x & 63) == 0) sm[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      double r = sm[0];
+      for (int k = 1; k < 4; ++k) r = op == 1 ? fmax(r, sm[k]) : r + sm[k];
+      out[s] = r;
+    }
+    __syncthreads();
+  }
+}
+
+int pyn_reduce_host(pyn_ctx* c, int nslots, int nblocks, int op, double* out) {
+  finish_kernel<<<1, 256, 0, c->stream>>>(c->d_part, nslots, nblocks, op, c->d_scal + 40);
+  if (c->nranks > 1)
+    PYN_NCCL(ncclAllReduce(c->d_scal + 40, c->d_scal + 40, nslots, ncclDouble, op == 1 ? ncclMax : ncclSum, c->comm, c->stream));
+  PYN_HIP(hipMemcpyAsync(c->h_scal, c->d_scal + 40, nslots * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+  PYN_HIP(hipStreamSynchronize(c->stream));
+  for (int s = 0; s < nslots; ++s) out[s] = c->h_scal[s];
+  return PYN_OK;
+}
+
+extern "C" int pyn_vec_dot(pyn_ctx* c, int x, int y, double* out) {
+  PYN_TRY(pyn_check_vec(c, x, "dot x"));
+  PYN_TRY(pyn_check_vec(c, y, "dot y"));
+  PYN_CHECK(out && c->vecs[x].bs == c->vecs[y].bs, "bad arguments");
+  int64_t n = c->n_owned * c->vecs[x].bs;
+  int g = ew_grid(n);
+  reduce_kernel<<<g, 256, 0, c->stream>>>(c->vecs[x].d, c->vecs[y].d, n, 0, c->d_part);
+  return pyn_reduce_host(c, 1, g, 0, out);
+}
+
+extern "C" int pyn_vec_norm(pyn_ctx* c, int x, int type, double* out) {
+  PYN_TRY(pyn_check_vec(c, x, "norm"));
+  PYN_CHECK(out && (type == 1 || type == 2 || type == 3), "norm type must be 1, 2 or 3 (inf)");
+  int64_t n = c->n_owned * c->vecs[x].bs;
+  int g = ew_grid(n);
+  int mode = type == 2 ? 0 : (type == 1 ? 1 : 2);
+  reduce_kernel<<<g, 256, 0, c->stream>>>(c->vecs[x].d, c->vecs[x].d, n, mode, c->d_part);
+  PYN_TRY(pyn_reduce_host(c, 1, g, type == 3 ? 1 : 0, out));
+  if (type == 2) *out = sqrt(*out);
+  return PYN_OK;
+}
+
+extern "C" int pyn_timers_get(pyn_ctx* c, double* ms, int n) {
+  PYN_CHECK(c && ms && n > 0, "bad arguments");
+  for (int i = 0; i < n && i < PYN_T_COUNT; ++i) ms[i] = c->timers[i];
+  return PYN_OK;
+}

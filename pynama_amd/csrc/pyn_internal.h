@@ -1,0 +1,129 @@
+// Internal declarations shared by the translation units of libpynama_hip.so (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <rccl/rccl.h>
+
+#include <cstdint>
+#include <cstdio>
+#include <string>
+#include <vector>
+
+#include "../../include/pynama_hip.h"
+
+void pyn_set_error(const char* fmt, ...);
+
+#define PYN_HIP(call)                                                                         \
+  do {                                                                                        \
+    hipError_t e_ = (call);                                                                   \
+    if (e_ != hipSuccess) {                                                                   \
+      pyn_set_error("%s:%d %s -> %s", __FILE__, __LINE__, #call, hipGetErrorString(e_));      \
+      return PYN_EHIP;                                                                        \
+    }                                                                                         \
+  } while (0)
+
+#define PYN_NCCL(call)                                                                        \
+  do {                                                                                        \
+    ncclResult_t r_ = (call);                                                                 \
+    if (r_ != ncclSuccess) {                                                                  \
+      pyn_set_error("%s:%d %s -> %s", __FILE__, __LINE__, #call, ncclGetErrorString(r_));     \
+      return PYN_ENCCL;                                                                       \
+    }                                                                                         \
+  } while (0)
+
+#define PYN_CHECK(cond, ...)                                                                  \
+  do {                                                                                        \
+    if (!(cond)) {                                                                            \
+      pyn_set_error(__VA_ARGS__);                                                             \
+      return PYN_EINVAL;                                                                      \
+    }                                                                                         \
+  } while (0)
+
+#define PYN_TRY(call)                                                                         \
+  do {                                                                                        \
+    int rc_ = (call);                                                                         \
+    if (rc_ != PYN_OK) return rc_;                                                            \
+  } while (0)
+
+struct QuadTab {
+  int ngp = 0;
+  double* w = nullptr;       // [ngp]
+  double* H = nullptr;       // [ngp][nn]
+  double* Hrs = nullptr;     // [ngp][dim][nn]
+  double* HrsCoo = nullptr;  // [ngp][dim][nc]
+};
+
+struct DMat {
+  int br = 0, bc = 0;
+  double* val = nullptr;  // [nnzb*br*bc], layout in pynama_hip.h
+  bool live = false;
+};
+
+struct DVec {
+  int bs = 0;
+  double* d = nullptr;  // [(n_owned+n_ghost)*bs]
+  bool live = false;
+};
+
+constexpr int PYN_MAX_PARTIALS = 2048;  // grid cap of every reducing kernel
+
+struct pyn_ctx {
+  int device = 0;
+  hipStream_t stream = nullptr;
+  hipEvent_t ev0 = nullptr, ev1 = nullptr;
+  double timers[PYN_T_COUNT] = {0};
+
+  // communicator
+  int rank = 0, nranks = 1;
+  ncclComm_t comm = nullptr;
+  // halo plan
+  int64_t n_owned = 0, n_ghost = 0;
+  std::vector<int> neigh;
+  std::vector<int64_t> send_ptr, recv_ptr;
+  int32_t* d_send_idx = nullptr;
+  double* d_send_buf = nullptr;  // [n_send * max_bs]
+  int64_t n_send = 0;
+  bool halo_set = false;
+
+  // mesh
+  int dim = 0, nn = 0, nc = 0, ngl = 0;
+  int64_t n_elem = 0, n_node = 0;
+  int32_t* d_conn = nullptr;
+  double* d_xyz = nullptr;
+  QuadTab quad[3];
+
+  // boundary condition
+  int bc_ndof = 0;
+  uint8_t* d_bcmask = nullptr;
+
+  // node graph
+  int32_t* d_rowptr = nullptr;
+  int32_t* d_colidx = nullptr;
+  int64_t nnzb = 0;
+
+  std::vector<DMat> mats;
+  std::vector<DVec> vecs;
+
+  // reduction / solver scratch
+  double* d_part = nullptr;    // [8][PYN_MAX_PARTIALS]
+  double* d_scal = nullptr;    // [64] device scalars
+  int* d_flag = nullptr;       // [8]  device flags (done, iters, reason ...)
+  double* h_scal = nullptr;    // pinned host mirror [64]
+  int* h_flag = nullptr;       // pinned host mirror [8]
+  // CG work vectors (length n_local*bs_max), reallocated on demand
+  double* d_work = nullptr;
+  size_t work_bytes = 0;
+  // element-local scratch for pyn_elem_local
+  double* d_eloc = nullptr;
+  size_t eloc_bytes = 0;
+};
+
+inline int64_t n_local(const pyn_ctx* c) { return c->n_owned + c->n_ghost; }
+
+// ---- cross-TU helpers ---------------------------------------------------------------------
+int pyn_ensure_work(pyn_ctx* c, size_t bytes);
+int pyn_halo_exchange(pyn_ctx* c, double* x, int bs);  // fills ghost part of x (stream ordered)
+int pyn_check_mat(pyn_ctx* c, int id, const char* what);
+int pyn_check_vec(pyn_ctx* c, int id, const char* what);
+int pyn_reduce_host(pyn_ctx* c, int nslots, int nblocks, int op, double* out);  // partials -> host, allreduced
+int pyn_spmv_raw(pyn_ctx* c, const DMat& A, const double* x, double* y);        // no halo exchange
+int pyn_extract_diag_inv(pyn_ctx* c, const DMat& A, double* dinv, bool invert);

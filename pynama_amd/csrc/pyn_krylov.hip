@@ -1,0 +1,549 @@
+// SpMV and Krylov solve (HOT LOOP 2).
+//
+// Reference: FreeSlip.solveKLE (src/cases/base_problem.py:479-481): rhs = Rw*vort + Krhs*vel
+// (two MatMult + axpy) then KSP solve; KspSolver.createSolver (src/solver/ksp_solver.py:9-19)
+// selects the method from PETSc options (-ksp_type cg|gmres -pc_type jacobi).  Convergence test
+// follows KSPConvergedDefault: rnorm <= max(rtol*rnorm0, atol); divergence at rnorm >= dtol*rnorm0.
+//
+// CG runs without host round trips: alpha/beta/residual norms live in device scalars, reductions
+// are two-stage deterministic (per-block partials -> one finishing block), a device "done" flag
+// turns the remaining enqueued kernels into no-ops once converged.  The host polls the flag every
+// `chunk` iterations.
+#include <algorithm>
+#include <cmath>
+
+#include "pyn_internal.h"
+
+namespace {
+
+enum { S_RZ = 0, S_PAP = 1, S_RZNEW = 2, S_ALPHA = 3, S_BETA = 4, S_RNORM = 5, S_RNORM0 = 6, S_TTOL = 7, S_DLIM = 8, S_ATOL = 9,
+       S_TMP0 = 16, S_TMP1 = 17 };
+enum { F_DONE = 0, F_ITERS = 1, F_REASON = 2 };
+
+__device__ inline double wsum(double v) {
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+
+// block-level sum of `acc` -> part[blockIdx.x]
+__device__ inline void block_partial(double acc, double* __restrict__ part) {
+  __shared__ double sm_[4];
+  acc = wsum(acc);
+  if ((threadIdx.x & 63) == 0) sm_[threadIdx.x >> 6] = acc;
+  __syncthreads();
+  if (threadIdx.x == 0) part[blockIdx.x] = sm_[0] + sm_[1] + sm_[2] + sm_[3];
+}
+
+// ---- SpMV: LPR lanes per scalar row, rows of one node are contiguous in `val` -----------------
+// y[(i,p)] = sum_k sum_q val[(rowptr[i]*br + p*len + k)*bc + q] * x[colidx[rowptr[i]+k]*bc + q]
+template <int LPR, bool DOT>
+__global__ void __launch_bounds__(256) spmv_kernel(const int32_t* __restrict__ rowptr, const int32_t* __restrict__ colidx,
+                                                   const double* __restrict__ val, const double* __restrict__ x,
+                                                   double* __restrict__ y, int64_t n_rows, int br, int bc,
+                                                   const int* __restrict__ flag, double* __restrict__ part) {
+  if (flag && flag[F_DONE]) return;
+  const int lane = threadIdx.x % LPR;
+  const int64_t grp = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) / LPR;
+  const int64_t ngrp = (int64_t)gridDim.x * blockDim.x / LPR;
+  double dot = 0.0;
+  for (int64_t r = grp; r < n_rows; r += ngrp) {
+    int64_t i = r / br;
+    int p = (int)(r - i * br);
+    int lo = rowptr[i];
+    int len = rowptr[i + 1] - lo;
+    const double* v = val + ((int64_t)lo * br + (int64_t)p * len) * bc;
+    const int n = len * bc;
+    double acc = 0.0;
+    if (bc == 1) {
+      for (int idx = lane; idx < n; idx += LPR) acc += v[idx] * x[colidx[lo + idx]];
+    } else {
+      for (int idx = lane; idx < n; idx += LPR) {
+        int k = idx / bc, q = idx - k * bc;
+        acc += v[idx] * x[(int64_t)colidx[lo + k] * bc + q];
+      }
+    }
+    for (int o = LPR / 2; o > 0; o >>= 1) acc += __shfl_xor(acc, o, LPR);
+    if (lane == 0) {
+      y[r] = acc;
+      if (DOT) dot += acc * x[r];
+    }
+  }
+  if (DOT) block_partial(dot, part);
+}
+
+__global__ void diag_kernel(const int32_t* __restrict__ rowptr, const int32_t* __restrict__ colidx,
+                            const double* __restrict__ val, int64_t n_nodes, int br, int invert, double* __restrict__ d) {
+  for (int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; r < n_nodes * br; r += (int64_t)gridDim.x * blockDim.x) {
+    int64_t i = r / br;
+    int p = (int)(r - i * br);
+    int lo = rowptr[i], len = rowptr[i + 1] - lo;
+    int l = 0, h = len;
+    while (l < h) {
+      int m = (l + h) >> 1;
+      if (colidx[lo + m] < (int)i)
+        l = m + 1;
+      else
+        h = m;
+    }
+    double a = val[((int64_t)lo * br + (int64_t)p * len + l) * br + p];
+    d[r] = invert ? 1.0 / a : a;
+  }
+}
+
+// ---- CG kernels -------------------------------------------------------------------------------
+// r = b, z = dinv r, p = z, x = 0 ; partials: [0] r.z  [1] norm^2 (by type)
+__global__ void __launch_bounds__(256) cg_init_kernel(const double* __restrict__ b, const double* __restrict__ dinv,
+                                                      double* __restrict__ x, double* __restrict__ r, double* __restrict__ p,
+                                                      int64_t n, int norm_type, double* __restrict__ part) {
+  double rz = 0.0, nn = 0.0;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    double ri = b[i];
+    double zi = dinv ? dinv[i] * ri : ri;
+    x[i] = 0.0;
+    r[i] = ri;
+    p[i] = zi;
+    rz += ri * zi;
+    nn += norm_type == PYN_NORM_PRECONDITIONED ? zi * zi : ri * ri;
+  }
+  block_partial(rz, part);
+  __syncthreads();
+  block_partial(nn, part + PYN_MAX_PARTIALS);
+}
+
+// x += alpha p ; r -= alpha Ap ; z = dinv r ; partials: [0] r.z  [1] norm^2
+__global__ void __launch_bounds__(256) cg_update_kernel(const double* __restrict__ scal, const int* __restrict__ flag,
+                                                        const double* __restrict__ dinv, const double* __restrict__ p,
+                                                        const double* __restrict__ Ap, double* __restrict__ x,
+                                                        double* __restrict__ r, int64_t n, int norm_type,
+                                                        double* __restrict__ part) {
+  if (flag[F_DONE]) return;
+  const double alpha = scal[S_ALPHA];
+  double rz = 0.0, nn = 0.0;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    x[i] += alpha * p[i];
+    double ri = r[i] - alpha * Ap[i];
+    r[i] = ri;
+    double zi = dinv ? dinv[i] * ri : ri;
+    rz += ri * zi;
+    nn += norm_type == PYN_NORM_PRECONDITIONED ? zi * zi : ri * ri;
+  }
+  block_partial(rz, part);
+  __syncthreads();
+  block_partial(nn, part + PYN_MAX_PARTIALS);
+}
+
+// p = dinv r + beta p
+__global__ void __launch_bounds__(256) cg_p_kernel(const double* __restrict__ scal, const int* __restrict__ flag,
+                                                   const double* __restrict__ dinv, const double* __restrict__ r,
+                                                   double* __restrict__ p, int64_t n) {
+  if (flag[F_DONE]) return;
+  const double beta = scal[S_BETA];
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    double zi = dinv ? dinv[i] * r[i] : r[i];
+    p[i] = zi + beta * p[i];
+  }
+}
+
+// one block: out[s] = sum(part[s][0..nblocks))
+__global__ void __launch_bounds__(256) sum_partials_kernel(const double* __restrict__ part, int nslots, int nblocks,
+                                                           double* __restrict__ out, const int* __restrict__ flag) {
+  if (flag && flag[F_DONE]) return;
+  __shared__ double sm[4];
+  for (int s = 0; s < nslots; ++s) {
+    double acc = 0.0;
+    for (int i = threadIdx.x; i < nblocks; i += 256) acc += part[s * PYN_MAX_PARTIALS + i];
+    acc = wsum(acc);
+    if ((threadIdx.x & 63) == 0) sm[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) out[s] = sm[0] + sm[1] + sm[2] + sm[3];
+    __syncthreads();
+  }
+}
+
+__global__ void cg_scalar_init_kernel(double* scal, int* flag, double rtol, double atol, double dtol, int norm_type,
+                                      double* hist) {
+  double rz = scal[S_TMP0], nn = scal[S_TMP1];
+  double rn = norm_type == PYN_NORM_NATURAL ? sqrt(fabs(rz)) : sqrt(nn);
+  scal[S_RZ] = rz;
+  scal[S_RNORM] = rn;
+  scal[S_RNORM0] = rn;
+  double ttol = fmax(rtol * rn, atol);
+  scal[S_TTOL] = ttol;
+  scal[S_DLIM] = dtol * rn;
+  scal[S_ATOL] = atol;
+  flag[F_ITERS] = 0;
+  flag[F_DONE] = 0;
+  flag[F_REASON] = 0;
+  if (hist) hist[0] = rn;
+  if (!(rn == rn)) {
+    flag[F_DONE] = 1;
+    flag[F_REASON] = PYN_DIVERGED_NANORINF;
+  } else if (rn <= ttol) {
+    flag[F_DONE] = 1;
+    flag[F_REASON] = rn <= atol ? PYN_CONVERGED_ATOL : PYN_CONVERGED_RTOL;
+  }
+}
+
+__global__ void cg_scalar_alpha_kernel(double* scal, int* flag) {
+  if (flag[F_DONE]) return;
+  double pap = scal[S_TMP0];
+  scal[S_PAP] = pap;
+  if (!(pap > 0.0)) {  // indefinite matrix / breakdown (also catches NaN)
+    flag[F_DONE] = 1;
+    flag[F_REASON] = pap == pap ? PYN_DIVERGED_BREAKDOWN : PYN_DIVERGED_NANORINF;
+    scal[S_ALPHA] = 0.0;
+    return;
+  }
+  scal[S_ALPHA] = scal[S_RZ] / pap;
+}
+
+__global__ void cg_scalar_beta_kernel(double* scal, int* flag, int norm_type, int maxit, int check, double* hist,
+                                      int hist_cap) {
+  if (flag[F_DONE]) return;
+  double rz_new = scal[S_TMP0], nn = scal[S_TMP1];
+  double rn = norm_type == PYN_NORM_NATURAL ? sqrt(fabs(rz_new)) : sqrt(nn);
+  int it = flag[F_ITERS] + 1;
+  flag[F_ITERS] = it;
+  scal[S_RNORM] = rn;
+  if (hist && it < hist_cap) hist[it] = rn;
+  scal[S_BETA] = rz_new / scal[S_RZ];
+  scal[S_RZ] = rz_new;
+  if (check) {
+    if (!(rn == rn)) {
+      flag[F_DONE] = 1;
+      flag[F_REASON] = PYN_DIVERGED_NANORINF;
+    } else if (rn <= scal[S_TTOL]) {
+      flag[F_DONE] = 1;
+      flag[F_REASON] = rn <= scal[S_ATOL] ? PYN_CONVERGED_ATOL : PYN_CONVERGED_RTOL;
+    } else if (rn >= scal[S_DLIM]) {
+      flag[F_DONE] = 1;
+      flag[F_REASON] = PYN_DIVERGED_DTOL;
+    } else if (it >= maxit) {
+      flag[F_DONE] = 1;
+      flag[F_REASON] = PYN_DIVERGED_ITS;
+    }
+  } else if (it >= maxit) {
+    flag[F_DONE] = 1;
+    flag[F_REASON] = PYN_CONVERGED_ITS;
+  }
+}
+
+// generic helpers on raw device pointers (GMRES, residual check)
+__global__ void __launch_bounds__(256) dot2_kernel(const double* __restrict__ x, const double* __restrict__ y, int64_t n,
+                                                   double* __restrict__ part) {
+  double acc = 0.0;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) acc += x[i] * y[i];
+  block_partial(acc, part);
+}
+__global__ void waxpby_kernel(double* __restrict__ w, double a, const double* __restrict__ x, double b,
+                              const double* __restrict__ y, int64_t n) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+    w[i] = a * x[i] + (b != 0.0 ? b * y[i] : 0.0);
+}
+__global__ void wmul_kernel(double* __restrict__ w, const double* __restrict__ d, const double* __restrict__ x, int64_t n) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+    w[i] = d ? d[i] * x[i] : x[i];
+}
+
+inline int vgrid(int64_t n) { return (int)std::max<int64_t>(1, std::min<int64_t>((n + 511) / 512, PYN_MAX_PARTIALS)); }
+
+int dev_dot(pyn_ctx* c, const double* x, const double* y, int64_t n, double* out) {
+  int g = vgrid(n);
+  dot2_kernel<<<g, 256, 0, c->stream>>>(x, y, n, c->d_part);
+  return pyn_reduce_host(c, 1, g, 0, out);
+}
+
+}  // namespace
+
+int pyn_spmv_raw(pyn_ctx* c, const DMat& A, const double* x, double* y) {
+  int64_t rows = c->n_owned * A.br;
+  int grid = (int)std::max<int64_t>(1, std::min<int64_t>((rows * 32 + 255) / 256, PYN_MAX_PARTIALS));
+  spmv_kernel<32, false><<<grid, 256, 0, c->stream>>>(c->d_rowptr, c->d_colidx, A.val, x, y, rows, A.br, A.bc, nullptr, nullptr);
+  PYN_HIP(hipGetLastError());
+  return PYN_OK;
+}
+
+int pyn_extract_diag_inv(pyn_ctx* c, const DMat& A, double* d, bool invert) {
+  PYN_CHECK(A.br == A.bc, "diagonal of a non-square block matrix");
+  int64_t n = c->n_owned * A.br;
+  diag_kernel<<<vgrid(n), 256, 0, c->stream>>>(c->d_rowptr, c->d_colidx, A.val, c->n_owned, A.br, invert ? 1 : 0, d);
+  PYN_HIP(hipGetLastError());
+  return PYN_OK;
+}
+
+extern "C" int pyn_mat_get_diagonal(pyn_ctx* c, int mat_id, int vec_id) {
+  PYN_TRY(pyn_check_mat(c, mat_id, "get_diagonal"));
+  PYN_TRY(pyn_check_vec(c, vec_id, "get_diagonal"));
+  PYN_CHECK(c->vecs[vec_id].bs == c->mats[mat_id].br, "block size mismatch");
+  return pyn_extract_diag_inv(c, c->mats[mat_id], c->vecs[vec_id].d, false);
+}
+
+__global__ void mat_axpy_kernel(double* __restrict__ y, double a, const double* __restrict__ x, int64_t n) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) y[i] += a * x[i];
+}
+
+extern "C" int pyn_mat_axpy(pyn_ctx* c, int ym, double a, int xm) {
+  PYN_TRY(pyn_check_mat(c, ym, "mat_axpy y"));
+  PYN_TRY(pyn_check_mat(c, xm, "mat_axpy x"));
+  DMat &Y = c->mats[ym], &X = c->mats[xm];
+  PYN_CHECK(Y.br == X.br && Y.bc == X.bc, "block shape mismatch");
+  int64_t n = c->nnzb * Y.br * Y.bc;
+  mat_axpy_kernel<<<vgrid(n), 256, 0, c->stream>>>(Y.val, a, X.val, n);
+  return PYN_OK;
+}
+
+__global__ void row_scale_kernel(const int32_t* __restrict__ rowptr, double* __restrict__ val, const double* __restrict__ s,
+                                 int64_t n_nodes, int br, int bc) {
+  // one wave per scalar row
+  int lane = threadIdx.x & 63;
+  int64_t w = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  int64_t nw = ((int64_t)gridDim.x * blockDim.x) >> 6;
+  for (int64_t r = w; r < n_nodes * br; r += nw) {
+    int64_t i = r / br;
+    int p = (int)(r - i * br);
+    int lo = rowptr[i], len = rowptr[i + 1] - lo;
+    double* v = val + ((int64_t)lo * br + (int64_t)p * len) * bc;
+    double f = s[r];
+    for (int k = lane; k < len * bc; k += 64) v[k] *= f;
+  }
+}
+
+extern "C" int pyn_mat_row_scale(pyn_ctx* c, int mat_id, int vec_id) {
+  PYN_TRY(pyn_check_mat(c, mat_id, "row_scale"));
+  PYN_TRY(pyn_check_vec(c, vec_id, "row_scale"));
+  DMat& A = c->mats[mat_id];
+  PYN_CHECK(c->vecs[vec_id].bs == A.br, "block size mismatch");
+  int64_t rows = c->n_owned * A.br;
+  int grid = (int)std::max<int64_t>(1, std::min<int64_t>((rows * 64 + 255) / 256, 8192));
+  row_scale_kernel<<<grid, 256, 0, c->stream>>>(c->d_rowptr, A.val, c->vecs[vec_id].d, c->n_owned, A.br, A.bc);
+  return PYN_OK;
+}
+
+extern "C" int pyn_spmv(pyn_ctx* c, int mat_id, int xv, int yv) {
+  PYN_TRY(pyn_check_mat(c, mat_id, "pyn_spmv"));
+  PYN_TRY(pyn_check_vec(c, xv, "pyn_spmv x"));
+  PYN_TRY(pyn_check_vec(c, yv, "pyn_spmv y"));
+  PYN_CHECK(xv != yv, "x and y must differ");
+  DMat& A = c->mats[mat_id];
+  PYN_CHECK(c->vecs[xv].bs == A.bc && c->vecs[yv].bs == A.br, "vector block sizes do not match the matrix (%dx%d)", A.br, A.bc);
+  PYN_HIP(hipSetDevice(c->device));
+  PYN_HIP(hipEventRecord(c->ev0, c->stream));
+  PYN_TRY(pyn_halo_exchange(c, c->vecs[xv].d, A.bc));
+  PYN_TRY(pyn_spmv_raw(c, A, c->vecs[xv].d, c->vecs[yv].d));
+  PYN_HIP(hipEventRecord(c->ev1, c->stream));
+  PYN_HIP(hipStreamSynchronize(c->stream));
+  float ms = 0;
+  PYN_HIP(hipEventElapsedTime(&ms, c->ev0, c->ev1));
+  c->timers[PYN_T_SPMV] = ms;
+  return PYN_OK;
+}
+
+// -----------------------------------------------------------------------------------------------
+static int allreduce_tmp(pyn_ctx* c, int n) {
+  if (c->nranks > 1)
+    PYN_NCCL(ncclAllReduce(c->d_scal + S_TMP0, c->d_scal + S_TMP0, n, ncclDouble, ncclSum, c->comm, c->stream));
+  return PYN_OK;
+}
+
+static int solve_cg(pyn_ctx* c, const DMat& A, const double* b, double* x, const pyn_solve_opts& o, pyn_solve_info* info) {
+  const int64_t n = c->n_owned * A.br;
+  const int64_t nl = n_local(c) * A.br;
+  // work: r[n] p[nl] Ap[n] dinv[n] hist
+  const int hist_cap = 4096;
+  size_t need = (size_t)(3 * n + nl + hist_cap) * sizeof(double);
+  PYN_TRY(pyn_ensure_work(c, need));
+  double* r = c->d_work;
+  double* p = r + n;
+  double* Ap = p + nl;
+  double* dinv = Ap + n;
+  double* hist = dinv + n;
+  const bool jac = o.pc == PYN_PC_JACOBI;
+  if (jac) PYN_TRY(pyn_extract_diag_inv(c, A, dinv, true));
+  const double* dv = jac ? dinv : nullptr;
+  const int g = vgrid(n);
+  const int64_t rows = n;
+  const int gs = (int)std::max<int64_t>(1, std::min<int64_t>((rows * 32 + 255) / 256, PYN_MAX_PARTIALS));
+  hipStream_t s = c->stream;
+  const int maxit = o.fixed_iters > 0 ? o.fixed_iters : o.maxit;
+  const int check = o.fixed_iters > 0 ? 0 : 1;
+
+  cg_init_kernel<<<g, 256, 0, s>>>(b, dv, x, r, p, n, o.norm_type, c->d_part);
+  sum_partials_kernel<<<1, 256, 0, s>>>(c->d_part, 2, g, c->d_scal + S_TMP0, nullptr);
+  PYN_TRY(allreduce_tmp(c, 2));
+  cg_scalar_init_kernel<<<1, 1, 0, s>>>(c->d_scal, c->d_flag, check ? o.rtol : 0.0, check ? o.atol : 0.0, o.dtol, o.norm_type, hist);
+  PYN_HIP(hipMemcpyAsync(c->h_flag, c->d_flag, 8 * sizeof(int), hipMemcpyDeviceToHost, s));
+  PYN_HIP(hipStreamSynchronize(s));
+  PYN_HIP(hipEventRecord(c->ev0, s));
+  int done = check ? c->h_flag[F_DONE] : 0;
+  if (!check) {  // fixed-iteration mode ignores "already converged"
+    PYN_HIP(hipMemsetAsync(c->d_flag, 0, sizeof(int), s));
+  }
+  int issued = 0;
+  const int chunk = 32;
+  while (!done && issued < maxit) {
+    int todo = std::min(chunk, maxit - issued);
+    for (int k = 0; k < todo; ++k) {
+      PYN_TRY(pyn_halo_exchange(c, p, A.bc));
+      spmv_kernel<32, true><<<gs, 256, 0, s>>>(c->d_rowptr, c->d_colidx, A.val, p, Ap, rows, A.br, A.bc, c->d_flag, c->d_part);
+      sum_partials_kernel<<<1, 256, 0, s>>>(c->d_part, 1, gs, c->d_scal + S_TMP0, c->d_flag);
+      PYN_TRY(allreduce_tmp(c, 1));
+      cg_scalar_alpha_kernel<<<1, 1, 0, s>>>(c->d_scal, c->d_flag);
+      cg_update_kernel<<<g, 256, 0, s>>>(c->d_scal, c->d_flag, dv, p, Ap, x, r, n, o.norm_type, c->d_part);
+      sum_partials_kernel<<<1, 256, 0, s>>>(c->d_part, 2, g, c->d_scal + S_TMP0, c->d_flag);
+      PYN_TRY(allreduce_tmp(c, 2));
+      cg_scalar_beta_kernel<<<1, 1, 0, s>>>(c->d_scal, c->d_flag, o.norm_type, maxit, check, hist, hist_cap);
+      cg_p_kernel<<<g, 256, 0, s>>>(c->d_scal, c->d_flag, dv, r, p, n);
+    }
+    issued += todo;
+    PYN_HIP(hipMemcpyAsync(c->h_flag, c->d_flag, 8 * sizeof(int), hipMemcpyDeviceToHost, s));
+    PYN_HIP(hipStreamSynchronize(s));
+    done = c->h_flag[F_DONE];
+  }
+  PYN_HIP(hipEventRecord(c->ev1, s));
+  PYN_HIP(hipMemcpyAsync(c->h_flag, c->d_flag, 8 * sizeof(int), hipMemcpyDeviceToHost, s));
+  PYN_HIP(hipMemcpyAsync(c->h_scal, c->d_scal, 16 * sizeof(double), hipMemcpyDeviceToHost, s));
+  PYN_HIP(hipStreamSynchronize(s));
+  float ms = 0;
+  PYN_HIP(hipEventElapsedTime(&ms, c->ev0, c->ev1));
+  info->solve_ms = ms;
+  info->iters = c->h_flag[F_ITERS];
+  info->reason = c->h_flag[F_REASON] ? c->h_flag[F_REASON] : PYN_DIVERGED_ITS;
+  info->rnorm = c->h_scal[S_RNORM];
+  info->rnorm0 = c->h_scal[S_RNORM0];
+  return PYN_OK;
+}
+
+// Left-preconditioned restarted GMRES(m), modified Gram-Schmidt, Givens rotations on the host.
+static int solve_gmres(pyn_ctx* c, const DMat& A, const double* b, double* x, const pyn_solve_opts& o, pyn_solve_info* info) {
+  const int64_t n = c->n_owned * A.br;
+  const int64_t nl = n_local(c) * A.br;
+  const int m = std::max(1, o.restart);
+  size_t need = (size_t)((int64_t)(m + 1) * nl + 2 * nl + n) * sizeof(double);
+  PYN_TRY(pyn_ensure_work(c, need));
+  double* V = c->d_work;            // (m+1) x nl
+  double* w = V + (int64_t)(m + 1) * nl;  // nl (needs ghost space as SpMV input? no: output) -> n used
+  double* t = w + nl;               // nl  (SpMV input with ghosts)
+  double* dinv = t + nl;
+  const bool jac = o.pc == PYN_PC_JACOBI;
+  if (jac) PYN_TRY(pyn_extract_diag_inv(c, A, dinv, true));
+  const double* dv = jac ? dinv : nullptr;
+  hipStream_t s = c->stream;
+  const int g = vgrid(n);
+  PYN_HIP(hipMemsetAsync(x, 0, n * sizeof(double), s));
+  std::vector<double> H((size_t)(m + 1) * m), cs(m), sn(m), gg(m + 1), yv(m);
+  int its = 0;
+  double ttol = -1.0, rnorm0 = 0.0, rn = 0.0;
+  int reason = 0;
+  PYN_HIP(hipEventRecord(c->ev0, s));
+  const int maxit = o.fixed_iters > 0 ? o.fixed_iters : o.maxit;
+  while (true) {
+    // r = dinv (b - A x)
+    PYN_HIP(hipMemcpyAsync(t, x, n * sizeof(double), hipMemcpyDeviceToDevice, s));
+    PYN_TRY(pyn_halo_exchange(c, t, A.bc));
+    PYN_TRY(pyn_spmv_raw(c, A, t, w));
+    waxpby_kernel<<<g, 256, 0, s>>>(w, 1.0, b, -1.0, w, n);
+    wmul_kernel<<<g, 256, 0, s>>>(V, dv, w, n);
+    double bb = 0;
+    PYN_TRY(dev_dot(c, V, V, n, &bb));
+    double beta = sqrt(bb);
+    if (ttol < 0) {
+      rnorm0 = beta;
+      ttol = o.fixed_iters > 0 ? 0.0 : std::max(o.rtol * beta, o.atol);
+    }
+    rn = beta;
+    if (!(beta == beta)) { reason = PYN_DIVERGED_NANORINF; break; }
+    if (beta <= ttol) { reason = PYN_CONVERGED_RTOL; break; }
+    if (its >= maxit) { reason = o.fixed_iters > 0 ? PYN_CONVERGED_ITS : PYN_DIVERGED_ITS; break; }
+    waxpby_kernel<<<g, 256, 0, s>>>(V, 1.0 / beta, V, 0.0, V, n);
+    std::fill(gg.begin(), gg.end(), 0.0);
+    gg[0] = beta;
+    int kused = 0;
+    for (int k = 0; k < m; ++k) {
+      double* vk = V + (int64_t)k * nl;
+      double* vn = V + (int64_t)(k + 1) * nl;
+      PYN_TRY(pyn_halo_exchange(c, vk, A.bc));
+      PYN_TRY(pyn_spmv_raw(c, A, vk, w));
+      wmul_kernel<<<g, 256, 0, s>>>(vn, dv, w, n);
+      for (int j = 0; j <= k; ++j) {
+        double h = 0;
+        PYN_TRY(dev_dot(c, vn, V + (int64_t)j * nl, n, &h));
+        H[(size_t)j * m + k] = h;
+        waxpby_kernel<<<g, 256, 0, s>>>(vn, 1.0, vn, -h, V + (int64_t)j * nl, n);
+      }
+      double hh = 0;
+      PYN_TRY(dev_dot(c, vn, vn, n, &hh));
+      hh = sqrt(hh);
+      H[(size_t)(k + 1) * m + k] = hh;
+      if (hh > 0) waxpby_kernel<<<g, 256, 0, s>>>(vn, 1.0 / hh, vn, 0.0, vn, n);
+      for (int j = 0; j < k; ++j) {
+        double a = cs[j] * H[(size_t)j * m + k] + sn[j] * H[(size_t)(j + 1) * m + k];
+        H[(size_t)(j + 1) * m + k] = -sn[j] * H[(size_t)j * m + k] + cs[j] * H[(size_t)(j + 1) * m + k];
+        H[(size_t)j * m + k] = a;
+      }
+      double den = std::hypot(H[(size_t)k * m + k], H[(size_t)(k + 1) * m + k]);
+      cs[k] = H[(size_t)k * m + k] / den;
+      sn[k] = H[(size_t)(k + 1) * m + k] / den;
+      H[(size_t)k * m + k] = den;
+      H[(size_t)(k + 1) * m + k] = 0.0;
+      gg[k + 1] = -sn[k] * gg[k];
+      gg[k] = cs[k] * gg[k];
+      ++its;
+      kused = k + 1;
+      rn = std::fabs(gg[k + 1]);
+      if (rn <= ttol || its >= maxit || hh == 0.0) break;
+    }
+    for (int i = kused - 1; i >= 0; --i) {
+      double sacc = gg[i];
+      for (int j = i + 1; j < kused; ++j) sacc -= H[(size_t)i * m + j] * yv[j];
+      yv[i] = sacc / H[(size_t)i * m + i];
+    }
+    for (int j = 0; j < kused; ++j) waxpby_kernel<<<g, 256, 0, s>>>(x, 1.0, x, yv[j], V + (int64_t)j * nl, n);
+    if (rn <= ttol) { reason = PYN_CONVERGED_RTOL; break; }
+    if (its >= maxit) { reason = o.fixed_iters > 0 ? PYN_CONVERGED_ITS : PYN_DIVERGED_ITS; break; }
+  }
+  PYN_HIP(hipEventRecord(c->ev1, s));
+  PYN_HIP(hipStreamSynchronize(s));
+  float ms = 0;
+  PYN_HIP(hipEventElapsedTime(&ms, c->ev0, c->ev1));
+  info->solve_ms = ms;
+  info->iters = its;
+  info->reason = reason;
+  info->rnorm = rn;
+  info->rnorm0 = rnorm0;
+  return PYN_OK;
+}
+
+extern "C" int pyn_solve(pyn_ctx* c, int mat_id, int bv, int xv, const pyn_solve_opts* opts, pyn_solve_info* info) {
+  PYN_TRY(pyn_check_mat(c, mat_id, "pyn_solve"));
+  PYN_TRY(pyn_check_vec(c, bv, "pyn_solve b"));
+  PYN_TRY(pyn_check_vec(c, xv, "pyn_solve x"));
+  PYN_CHECK(opts && info, "NULL argument");
+  PYN_CHECK(bv != xv, "b and x must differ");
+  DMat& A = c->mats[mat_id];
+  PYN_CHECK(A.br == A.bc, "matrix must be square");
+  PYN_CHECK(c->vecs[bv].bs == A.br && c->vecs[xv].bs == A.br, "vector block size mismatch");
+  PYN_CHECK(opts->method == PYN_KSP_CG || opts->method == PYN_KSP_GMRES, "unknown method %d", opts->method);
+  PYN_CHECK(opts->pc == PYN_PC_NONE || opts->pc == PYN_PC_JACOBI, "unknown preconditioner %d", opts->pc);
+  PYN_CHECK(opts->maxit > 0 || opts->fixed_iters > 0, "maxit must be positive");
+  PYN_HIP(hipSetDevice(c->device));
+  double* b = c->vecs[bv].d;
+  double* x = c->vecs[xv].d;
+  *info = pyn_solve_info();
+  if (opts->method == PYN_KSP_CG)
+    PYN_TRY(solve_cg(c, A, b, x, *opts, info));
+  else
+    PYN_TRY(solve_gmres(c, A, b, x, *opts, info));
+  c->timers[PYN_T_SOLVE] = info->solve_ms;
+  // true residual ||b - A x|| / ||b|| (x lives in a vector with ghost space)
+  const int64_t n = c->n_owned * A.br;
+  PYN_TRY(pyn_ensure_work(c, (size_t)n * sizeof(double)));
+  double* w = c->d_work;
+  PYN_TRY(pyn_halo_exchange(c, x, A.bc));
+  PYN_TRY(pyn_spmv_raw(c, A, x, w));
+  waxpby_kernel<<<vgrid(n), 256, 0, c->stream>>>(w, 1.0, b, -1.0, w, n);
+  double rr = 0, bb = 0;
+  PYN_TRY(dev_dot(c, w, w, n, &rr));
+  PYN_TRY(dev_dot(c, b, b, n, &bb));
+  info->true_resid = bb > 0 ? sqrt(rr / bb) : sqrt(rr);
+  return PYN_OK;
+}

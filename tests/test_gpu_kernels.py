@@ -1,0 +1,255 @@
+"""GPU parity tests (run on a real MI355X with `-m gpu`): every result of the HIP path, called
+through the C ABI (pynama_amd._lib.Context == include/pynama_hip.h), is compared with the CPU
+oracle (oracle/fem_oracle.py) and with the reference's golden vectors (tests/golden)."""
+import numpy as np
+import pytest
+
+from oracle import fem_oracle as fo
+from tests.util import mat_to_scipy, rel_err, sp_rel_err
+
+pytestmark = pytest.mark.gpu
+
+FP_TOL = 2e-13      # relative, FP64 with atomics (summation order differs from numpy)
+
+
+@pytest.fixture(scope="module")
+def lib():
+    from pynama_amd import _lib
+    assert _lib.device_count() > 0, "GPU tests need an MI355X"
+    return _lib
+
+
+def make_ctx(lib, mesh, ngl, bc_ndof=None, bc_nodes=None):
+    from pynama_amd.elements.spectral import Spectral
+    ctx = lib.Context(0)
+    ctx.mesh_set(mesh.dim, mesh.conn, mesh.xyz)
+    sp = Spectral(ngl, mesh.dim)
+    for t in sp.deviceTables():
+        ctx.tables_set(*t)
+    if bc_ndof:
+        mask = np.zeros((mesh.n_node, bc_ndof), np.uint8)
+        mask[bc_nodes] = 1
+        ctx.bc_set(bc_ndof, mask)
+    ctx.csr_symbolic()
+    return ctx
+
+
+# ---- element level vs the reference's golden vectors ------------------------------------------
+@pytest.mark.parametrize("dim,ngl", [(2, 2), (2, 3), (2, 5), (3, 2), (3, 3)])
+def test_elem_local_vs_reference_golden(lib, golden, dim, ngl):
+    from pynama_amd.elements.spectral import Spectral
+    g = golden["g3_elem"]
+    sp = Spectral(ngl, dim)
+    for case in ("unit", "reftest", "brick128", "stretched", "jitter"):
+        key = f"d{dim}_n{ngl}_{case}"
+        K, Rw, Rd = sp.getElemKLEMatrices(g[key + "_coords"].copy())
+        assert rel_err(K, g[key + "_K"]) < FP_TOL, (case, "K")
+        assert rel_err(Rw, g[key + "_Rw"]) < FP_TOL, (case, "Rw")
+        assert rel_err(Rd, g[key + "_Rd"]) < FP_TOL, (case, "Rd")
+
+
+@pytest.mark.parametrize("dim,ngl", [(2, 2), (3, 2), (2, 4), (3, 3)])
+def test_elem_scalar_forms_vs_oracle(lib, golden, dim, ngl):
+    from pynama_amd.elements.spectral import Spectral
+    c = golden["g3_elem"][f"d{dim}_n2_jitter_coords"]
+    sp = Spectral(ngl, dim)
+    tb = fo.Tables(ngl, dim)
+    assert rel_err(sp.getElemLaplace(c), fo.elem_laplace(tb, c)[0]) < FP_TOL
+    assert rel_err(sp.getElemMass(c, nodal=True), fo.elem_mass(tb, c, "nodal")[0]) < FP_TOL
+    assert rel_err(sp.getElemMass(c, nodal=False), fo.elem_mass(tb, c, "full")[0]) < FP_TOL
+
+
+# ---- symbolic phase: bit exact ------------------------------------------------------------------
+@pytest.mark.parametrize("nelem,ngl", [([5, 4], 2), ([4, 3, 5], 2), ([3, 2], 4), ([2, 2, 3], 3)])
+def test_csr_symbolic_bit_exact(lib, nelem, ngl):
+    dim = len(nelem)
+    mesh = fo.box_mesh(nelem, [0.0] * dim, [1.0] * dim, ngl)
+    ctx = make_ctx(lib, mesh, ngl)
+    rp, ci = ctx.csr_get()
+    rp_o, ci_o = fo.node_graph(mesh)
+    assert np.array_equal(rp, rp_o) and np.array_equal(ci, ci_o)
+    ctx.close()
+
+
+def test_csr_symbolic_permuted_elements(lib):
+    """element order must not matter (irregular-indexing stress)"""
+    mesh = fo.box_mesh([6, 5, 4], [0, 0, 0], [1, 1, 1], 2)
+    rng = np.random.default_rng(2024)
+    mesh.conn = mesh.conn[rng.permutation(mesh.n_elem)]
+    ctx = make_ctx(lib, mesh, 2)
+    rp, ci = ctx.csr_get()
+    rp_o, ci_o = fo.node_graph(mesh)
+    assert np.array_equal(rp, rp_o) and np.array_equal(ci, ci_o)
+    ctx.close()
+
+
+# ---- numeric phase --------------------------------------------------------------------------------
+@pytest.mark.parametrize("nelem,ngl,jitter,variant", [
+    ([7, 6], 2, 0.2, 0), ([6, 5, 4], 2, 0.2, 0), ([6, 5, 4], 2, 0.2, 1), ([3, 4], 3, 0.0, 0),
+    ([2, 3, 2], 3, 0.0, 0), ([2, 2], 6, 0.0, 0), ([16, 16, 16], 2, 0.2, 1)])
+def test_assemble_kle_vs_oracle(lib, nelem, ngl, jitter, variant):
+    dim = len(nelem)
+    dw = 1 if dim == 2 else 3
+    mesh = fo.box_mesh(nelem, [0.0] * dim, [1.0, 0.8, 1.2][:dim], ngl, jitter=jitter)
+    ctx = make_ctx(lib, mesh, ngl, bc_ndof=dim, bc_nodes=mesh.boundary)
+    K, Krhs, Rw, Rd = (ctx.mat_create(dim, dim), ctx.mat_create(dim, dim), ctx.mat_create(dim, dw),
+                       ctx.mat_create(dim, 1))
+    ctx.assemble_kle(1e3, 1e2, K, Krhs, Rw, Rd, variant=variant)
+    ref = fo.assemble_kle_freeslip(mesh, fo.Tables(ngl, dim), with_rd=True)
+    assert sp_rel_err(mat_to_scipy(ctx, K, dim, dim), ref["K"]) < FP_TOL
+    assert sp_rel_err(mat_to_scipy(ctx, Krhs, dim, dim), ref["Krhs"]) < FP_TOL
+    assert sp_rel_err(mat_to_scipy(ctx, Rw, dim, dw), ref["Rw"]) < FP_TOL
+    assert sp_rel_err(mat_to_scipy(ctx, Rd, dim, 1), ref["Rd"]) < FP_TOL
+    ctx.close()
+
+
+@pytest.mark.parametrize("nelem,form,variant", [([9, 7], "laplace", 0), ([6, 5, 7], "laplace", 0),
+                                                ([6, 5, 7], "laplace", 1), ([6, 5, 7], "mass", 0),
+                                                ([24, 16, 8], "laplace", 1)])
+def test_assemble_scalar_vs_oracle(lib, nelem, form, variant):
+    dim = len(nelem)
+    mesh = fo.box_mesh(nelem, [0.0] * dim, [1.0] * dim, 2, jitter=0.2)
+    ctx = make_ctx(lib, mesh, 2, bc_ndof=1, bc_nodes=mesh.boundary)
+    A, Arhs = ctx.mat_create(1, 1), ctx.mat_create(1, 1)
+    ctx.assemble_scalar(lib.FORM_LAPLACE if form == "laplace" else lib.FORM_MASS_NODAL, A, Arhs, variant=variant)
+    ref = fo.assemble_scalar(mesh, fo.Tables(2, dim), form, dirichlet=mesh.boundary)
+    assert sp_rel_err(mat_to_scipy(ctx, A, 1, 1), ref["A"]) < FP_TOL
+    assert sp_rel_err(mat_to_scipy(ctx, Arhs, 1, 1), ref["Arhs"]) < FP_TOL
+    ctx.close()
+
+
+def test_assemble_empty_bc_and_idempotent(lib):
+    """no Dirichlet mask -> pure scatter; assembling twice gives the same matrix (zeroed first)"""
+    mesh = fo.box_mesh([5, 4, 3], [0, 0, 0], [1, 1, 1], 2)
+    ctx = make_ctx(lib, mesh, 2)
+    A = ctx.mat_create(1, 1)
+    ctx.assemble_scalar(lib.FORM_LAPLACE, A)
+    v1 = ctx.mat_values(A, 1, 1)
+    ctx.assemble_scalar(lib.FORM_LAPLACE, A)
+    v2 = ctx.mat_values(A, 1, 1)
+    assert rel_err(v1, v2) < 1e-14
+    S = mat_to_scipy(ctx, A, 1, 1)
+    assert abs(S @ np.ones(mesh.n_node)).max() < 1e-12      # Laplacian kills constants
+    ctx.close()
+
+
+# ---- SpMV / vectors ----------------------------------------------------------------------------
+@pytest.mark.parametrize("dim", [2, 3])
+def test_spmv_and_vec_ops(lib, dim):
+    dw = 1 if dim == 2 else 3
+    nelem = [9, 8, 7][:dim]
+    mesh = fo.box_mesh(nelem, [0.0] * dim, [1.0] * dim, 2, jitter=0.1)
+    ctx = make_ctx(lib, mesh, 2, bc_ndof=dim, bc_nodes=mesh.boundary)
+    K, Rw = ctx.mat_create(dim, dim), ctx.mat_create(dim, dw)
+    ctx.assemble_kle(1e3, 1e2, K, -1, Rw, -1)
+    rng = np.random.default_rng(7)
+    xv, xw = rng.standard_normal(mesh.n_node * dim), rng.standard_normal(mesh.n_node * dw)
+    vx, vw, vy = ctx.vec_create(dim), ctx.vec_create(dw), ctx.vec_create(dim)
+    ctx.vec_set(vx, xv)
+    ctx.vec_set(vw, xw)
+    ctx.spmv(K, vx, vy)
+    assert rel_err(ctx.vec_get(vy, dim), mat_to_scipy(ctx, K, dim, dim) @ xv) < 1e-13
+    ctx.spmv(Rw, vw, vy)
+    assert rel_err(ctx.vec_get(vy, dim), mat_to_scipy(ctx, Rw, dim, dw) @ xw) < 1e-13
+    # vector algebra
+    y = ctx.vec_get(vy, dim)
+    assert abs(ctx.vec_dot(vx, vy) - xv @ y) < 1e-10 * abs(xv @ y)
+    assert abs(ctx.vec_norm(vx, 2) - np.linalg.norm(xv)) < 1e-12 * np.linalg.norm(xv)
+    assert abs(ctx.vec_norm(vx, 1) - np.abs(xv).sum()) < 1e-12 * np.abs(xv).sum()
+    assert ctx.vec_norm(vx, 3) == np.abs(xv).max()
+    ctx.vec_axpby(vy, 2.0, vx, -0.5, vy)
+    assert rel_err(ctx.vec_get(vy, dim), 2.0 * xv - 0.5 * y) < 1e-15
+    ctx.vec_scatter(vy, [0, 5], [3.0, 4.0])
+    got = ctx.vec_get(vy, dim)
+    assert got[0] == 3.0 and got[5] == 4.0
+    ctx.close()
+
+
+# ---- Krylov ------------------------------------------------------------------------------------
+def _poisson(lib, nelem, jitter=0.1):
+    dim = len(nelem)
+    mesh = fo.box_mesh(nelem, [0.0] * dim, [1.0] * dim, 2, jitter=jitter)
+    ctx = make_ctx(lib, mesh, 2, bc_ndof=1, bc_nodes=mesh.boundary)
+    A, M = ctx.mat_create(1, 1), ctx.mat_create(1, 1)
+    ctx.assemble_scalar(lib.FORM_LAPLACE, A)
+    ctx.bc_set(1, None)
+    ctx.assemble_scalar(lib.FORM_MASS_FULL, M)
+    f = dim * np.pi ** 2 * np.prod(np.sin(np.pi * mesh.xyz), axis=1)
+    vf, vb, vx = ctx.vec_create(1), ctx.vec_create(1), ctx.vec_create(1)
+    ctx.vec_set(vf, f)
+    ctx.spmv(M, vf, vb)
+    b = ctx.vec_get(vb, 1)
+    b[mesh.boundary] = 0.0
+    ctx.vec_set(vb, b)
+    return mesh, ctx, A, vb, vx, b
+
+
+@pytest.mark.parametrize("norm", [0, 1, 2])
+def test_cg_matches_oracle_iterates(lib, norm):
+    mesh, ctx, A, vb, vx, b = _poisson(lib, [12, 10, 8])
+    S = mat_to_scipy(ctx, A, 1, 1)
+    info = ctx.solve(A, vb, vx, method=lib.KSP_CG, pc=lib.PC_JACOBI, rtol=1e-10, norm_type=norm)
+    x_o, it_o, hist = fo.pcg(S, b, rtol=1e-10, norm_type=norm)
+    assert info.reason == 2
+    assert abs(info.iters - it_o) <= 1
+    x = ctx.vec_get(vx, 1)
+    assert rel_err(x, x_o) < 1e-8
+    assert info.true_resid < 1e-8
+    assert abs(info.rnorm0 - hist[0]) < 1e-12 * hist[0]
+    ctx.close()
+
+
+def test_cg_poisson_exact_solution(lib):
+    """manufactured solution u = prod sin(pi x): discretisation error O(h^2), residual <= 1e-10"""
+    mesh, ctx, A, vb, vx, b = _poisson(lib, [24, 24, 24], jitter=0.0)
+    info = ctx.solve(A, vb, vx, rtol=1e-12, norm_type=lib.NORM_UNPRECONDITIONED)
+    assert info.reason == 2 and info.true_resid < 1e-10
+    u = ctx.vec_get(vx, 1)
+    exact = np.prod(np.sin(np.pi * mesh.xyz), axis=1)
+    assert np.abs(u - exact).max() < 5e-3
+    ctx.close()
+
+
+def test_cg_zero_rhs_and_maxit(lib):
+    mesh, ctx, A, vb, vx, b = _poisson(lib, [6, 6, 6])
+    ctx.vec_fill(vb, 0.0)
+    info = ctx.solve(A, vb, vx)
+    assert info.iters == 0 and info.reason in (2, 3)
+    assert np.all(ctx.vec_get(vx, 1) == 0.0)
+    ctx.vec_set(vb, b)
+    info = ctx.solve(A, vb, vx, rtol=1e-14, maxit=3)
+    assert info.iters == 3 and info.reason == -3
+    info = ctx.solve(A, vb, vx, fixed_iters=7)
+    assert info.iters == 7 and info.reason == 4
+    ctx.close()
+
+
+def test_gmres_matches_oracle(lib):
+    mesh, ctx, A, vb, vx, b = _poisson(lib, [8, 7, 6])
+    S = mat_to_scipy(ctx, A, 1, 1)
+    info = ctx.solve(A, vb, vx, method=lib.KSP_GMRES, pc=lib.PC_JACOBI, rtol=1e-10, restart=30)
+    x_o, it_o, hist = fo.gmres(S, b, rtol=1e-10, restart=30)
+    assert info.reason == 2 and abs(info.iters - it_o) <= 1
+    assert rel_err(ctx.vec_get(vx, 1), x_o) < 1e-7
+    ctx.close()
+
+
+# ---- end-to-end: the reference's analytic assertions (src/tests/test_solver.py:20-27,52-62) ----
+@pytest.mark.parametrize("nelem,ngl,tol", [([10, 10], 3, 1e-12), ([3, 3, 3], 3, 2e-13)])
+def test_uniform_flow_kle(lib, nelem, ngl, tol):
+    dim = len(nelem)
+    dw = 1 if dim == 2 else 3
+    mesh = fo.box_mesh(nelem, [0.0] * dim, [1.0] * dim, ngl)
+    ctx = make_ctx(lib, mesh, ngl, bc_ndof=dim, bc_nodes=mesh.boundary)
+    K, Krhs, Rw = ctx.mat_create(dim, dim), ctx.mat_create(dim, dim), ctx.mat_create(dim, dw)
+    ctx.assemble_kle(1e3, 1e2, K, Krhs, Rw, -1)
+    cte = np.array([1.0, 0.0, 0.0][:dim])
+    vel = np.zeros((mesh.n_node, dim))
+    vel[mesh.boundary] = cte
+    vvel, vrhs, vx = ctx.vec_create(dim), ctx.vec_create(dim), ctx.vec_create(dim)
+    ctx.vec_set(vvel, vel.ravel())
+    ctx.spmv(Krhs, vvel, vrhs)                      # vort = 0 -> rhs = Krhs * vel
+    info = ctx.solve(K, vrhs, vx, rtol=1e-15, atol=1e-14, norm_type=lib.NORM_UNPRECONDITIONED, maxit=20000)
+    err = np.linalg.norm(ctx.vec_get(vx, dim) - np.tile(cte, mesh.n_node))
+    assert err < max(tol, 50 * 1e-14), (err, info.iters, info.reason)
+    ctx.close()
