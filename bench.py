@@ -1,0 +1,203 @@
+#!/usr/bin/env python3
+"""Headline benchmark of the Pynama hot path on MI355X (contract: see the driver's prompt).
+
+    python bench.py --gpus N --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+Workload (BASELINE.json metric): 3-D Poisson, Q1 hexahedra, 215^3 elements = 216^3 =
+10,077,696 DOFs, FP64, synthetic structured box mesh, homogeneous Dirichlet on all faces.
+One *step* = one pass of the hot path over that mesh:
+    (1) numeric assembly  (zero values + per-element quadrature + scatter with Dirichlet
+        elimination; symbolic phase excluded)           -> element-DOFs/s
+    (2) `--cg-iters` Jacobi-PCG iterations on the assembled matrix    -> CG iterations/s
+Inputs (connectivity, coordinates, CSR pattern, vectors) are resident in HBM before timing.
+N > 1: the SAME mesh is row-partitioned in z-slabs over the ranks ("scaling": "strong"), halo
+planes and dot products go over RCCL inside libpynama_hip.so.
+
+The product path is torch-free: ranks/LOCAL_RANK come from the launcher's environment, the RCCL
+id is exchanged through a node-local file (pynama_amd/common/comm.py).
+Only the `cpu_baseline` leg touches oracle/ (the C restatement, as the thing timed on the CPU).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0       # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s (spec)
+
+
+def algorithmic_bytes(n_elem, n_node, nnz, nn=8, dim=3):
+    """compulsory traffic, FP64 values, int32 indices."""
+    asm = 4 * nn * n_elem + 8 * dim * n_node + 4 * (n_node + 1) + 4 * nnz + 8 * nnz
+    spmv = 12 * nnz + 4 * (n_node + 1) + 16 * n_node
+    cg_iter = 12 * nnz + 148 * n_node
+    return asm, spmv, cg_iter
+
+
+def cpu_baseline(dom, rp, ci, bmask, b, cg_iters=5, budget_s=12.0):
+    """C/OpenMP restatement of the same path (oracle/c/fem_oracle.c) on the host cores, on a
+    bounded sample: a leading range of the SAME elements for assembly, `cg_iters` PCG iterations
+    on the SAME matrix."""
+    from oracle import c_oracle as co
+    from oracle import fem_oracle as fo
+
+    class M:
+        pass
+    m = M()
+    m.conn, m.xyz, m.n_elem, m.n_node = dom.conn, dom.xyz, dom.conn.shape[0], dom.xyz.shape[0]
+    tb = fo.Tables(2, dom.dim)
+    # the GPU box advertises every host core but grants a share (16 per GPU): do not oversubscribe
+    cores = co.set_threads(min(co.usable_cores(), int(os.environ.get("PYNAMA_CPU_THREADS", "16"))))
+    # calibrate on 1/64 of the elements, then size the sample to ~budget_s
+    e_cal = max(1, m.n_elem // 64)
+    t0 = time.perf_counter()
+    co.assemble_laplace(m, tb, rp, ci, bmask, e0=0, e1=e_cal, with_rhs=False)
+    t_cal = time.perf_counter() - t0
+    e_s = int(min(m.n_elem, max(e_cal, e_cal * budget_s / max(t_cal, 1e-6))))
+    t0 = time.perf_counter()
+    A, _ = co.assemble_laplace(m, tb, rp, ci, bmask, e0=0, e1=e_s, with_rhs=False)
+    t_asm = time.perf_counter() - t0
+    if e_s < m.n_elem:       # finish the matrix (untimed) so that CG runs on the real operator
+        A2, _ = co.assemble_laplace(m, tb, rp, ci, bmask, e0=e_s, e1=m.n_elem, with_rhs=False)
+        A = A + A2           # bc rows receive nothing in either call; their unit diagonal came with e0 == 0
+    t0 = time.perf_counter()
+    co.pcg(rp, ci, A, b, fixed_iters=cg_iters, norm_type=1)
+    t_cg = time.perf_counter() - t0
+    return {"value": e_s * 8 / t_asm, "unit": "element-DOFs/s", "cores": cores, "kind": "port",
+            "cg_iters_per_s": cg_iters / t_cg,
+            "sample": f"C/OpenMP oracle: assembly of the first {e_s} of {m.n_elem} elements "
+                      f"({t_asm:.2f} s) + {cg_iters} Jacobi-PCG iterations on the full {m.n_node}-row matrix ({t_cg:.2f} s)"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--nel", type=int, default=215, help="elements per side (215 -> 10,077,696 DOFs)")
+    ap.add_argument("--cg-iters", type=int, default=100, help="fixed CG iterations per step")
+    ap.add_argument("--variant", type=int, default=1, help="assembly kernel: 0 generic atomics, 1 auto")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-check", action="store_true")
+    args = ap.parse_args()
+
+    from pynama_amd import _lib
+    from pynama_amd.common.comm import get_world
+    from pynama_amd.domain.dmplex import DMPlexDom
+    from pynama_amd.elements.spectral import Spectral
+
+    world = get_world()
+    if world.size != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world.size}: launch with "
+                         f"python -m torch.distributed.run --nproc-per-node {args.gpus} bench.py ...")
+    n = args.nel
+    dom = DMPlexDom(boxMesh={"nelem": [n, n, n], "lower": [0, 0, 0], "upper": [1, 1, 1]})
+    dom.setFemIndexing(2)
+    ctx = dom.ctx                                     # creates the context, RCCL comm, uploads the mesh
+    for t in Spectral(2, 3).deviceTables():
+        ctx.tables_set(*t)
+    bmask = dom.boundaryMaskLocal()
+    ctx.bc_set(1, bmask)
+    n_rows, nnz = ctx.csr_symbolic()
+    symbolic_ms = ctx.timers()["symbolic_ms"]
+    A = ctx.mat_create(1, 1)
+    vb, vx = ctx.vec_create(1), ctx.vec_create(1)
+    h = 1.0 / n
+    X = dom.xyz[:dom.nOwned]
+    # lumped load of a smooth non-separable source (NOT a discrete eigenvector: with
+    # f = sin sin sin on a uniform grid CG would converge in one iteration)
+    f = (1.0 + X[:, 0] + 2.0 * X[:, 1] ** 2 + np.exp(X[:, 0] * X[:, 1] * X[:, 2]) * np.cos(3.0 * X[:, 2])) * h ** 3
+    f[bmask[:dom.nOwned] != 0] = 0.0
+    ctx.vec_set(vb, f)
+
+    n_elem_global = n ** 3
+    n_node_global = (n + 1) ** 3
+    nnz_global = int(ctx.allreduce([nnz])[0]) if world.size > 1 else nnz
+    # units processed per step by THIS rank (owner-computes: a rank also integrates the one
+    # element layer it shares with each neighbour; only globally distinct elements are counted)
+    elem_dofs_per_step = n_elem_global * 8
+
+    def step(profile):
+        ctx.assemble_scalar(_lib.FORM_LAPLACE, A, -1, variant=args.variant)
+        t_asm = ctx.timers()["assemble_ms"]
+        info = ctx.solve(A, vb, vx, method=_lib.KSP_CG, pc=_lib.PC_JACOBI, fixed_iters=args.cg_iters,
+                         norm_type=_lib.NORM_UNPRECONDITIONED, profile=1 if profile else 0)
+        return t_asm, info.solve_ms, info.spmv_ms
+
+    for _ in range(args.warmup):
+        step(False)
+    ctx.barrier()
+    ctx.sync()
+    t0 = time.perf_counter()
+    asm_ms, cg_ms, spmv_ms = [], [], []
+    for _ in range(args.steps):
+        a, c, s = step(True)
+        asm_ms.append(a)
+        cg_ms.append(c)
+        spmv_ms.append(s)
+    ctx.sync()
+    ctx.barrier()
+    wall = time.perf_counter() - t0
+    # max over ranks
+    red = ctx.allreduce([wall, np.mean(asm_ms), np.mean(cg_ms), np.mean(spmv_ms)], op="max") if world.size > 1 \
+        else np.array([wall, np.mean(asm_ms), np.mean(cg_ms), np.mean(spmv_ms)])
+    wall, asm_mean, cg_mean, spmv_mean = [float(v) for v in red]
+
+    # ---- correctness on the SAME workload (outside the timed region): solve to 1e-10
+    check = None
+    if not args.no_check:
+        info = ctx.solve(A, vb, vx, method=_lib.KSP_CG, pc=_lib.PC_JACOBI, rtol=1e-10, maxit=20000,
+                         norm_type=_lib.NORM_UNPRECONDITIONED)
+        check = {"cg_iters_to_rtol_1e-10": int(info.iters), "reason": int(info.reason),
+                 "true_residual": float(info.true_resid), "solve_ms": float(info.solve_ms)}
+
+    cpu = None
+    if world.rank == 0 and world.size == 1 and not args.no_cpu_baseline:
+        rp, ci = ctx.csr_get()
+        cpu = cpu_baseline(dom, rp, ci, bmask, f)
+
+    if world.rank == 0:
+        B_asm, B_spmv, B_cg = algorithmic_bytes(n_elem_global, n_node_global, nnz_global)
+        # per-rank share of the algorithmic bytes (strong scaling: each GPU streams 1/N of them)
+        share = 1.0 / world.size
+        asm_gbs = B_asm * share / (asm_mean * 1e-3) / 1e9
+        spmv_gbs = B_spmv * share / (spmv_mean * 1e-3) / 1e9 if spmv_mean > 0 else 0.0
+        cg_gbs = B_cg * share / (cg_mean / args.cg_iters * 1e-3) / 1e9
+        out = {
+            "metric": "assembled element-DOFs/sec + CG iterations/sec, 10M-DOF Poisson, 1/2/4/8 MI355X",
+            "value": elem_dofs_per_step / (asm_mean * 1e-3),
+            "unit": "element-DOFs/s (assembly phase); cg_iters_per_s alongside",
+            "cg_iters_per_s": args.cg_iters / (cg_mean * 1e-3),
+            "n_gpus": world.size, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": wall / args.steps * 1e3,
+            "breakdown_ms": {"assembly": asm_mean, "cg": cg_mean, "cg_iters": args.cg_iters,
+                             "spmv_kernel": spmv_mean, "symbolic_once": symbolic_ms},
+            "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+            "dtype": "f64", "data": "synthetic",
+            "config": {"workload": f"3D Poisson, {n}^3 Q1 hex elements, {n_node_global} DOFs, nnz {nnz_global}, "
+                                   f"FP64 assembly + Jacobi-PCG ({args.cg_iters} its/step)",
+                       "partition": f"z-slabs x{world.size}", "assembly_variant": args.variant},
+            "roofline": {"kernel": "spmv_kernel (CSR SpMV inside CG)", "bound": "hbm", "achieved": spmv_gbs,
+                         "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": spmv_gbs / HBM_PEAK_GBS, "traffic": None,
+                         "algorithmic_bytes_per_launch": B_spmv * share},
+            "roofline_assembly": {"kernel": "assembly (zero + quadrature + scatter)", "bound": "hbm",
+                                  "achieved": asm_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                  "frac": asm_gbs / HBM_PEAK_GBS, "algorithmic_bytes_per_launch": B_asm * share},
+            "roofline_cg_iteration": {"bound": "hbm", "achieved": cg_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                      "frac": cg_gbs / HBM_PEAK_GBS, "algorithmic_bytes_per_iteration": B_cg * share},
+            "check": check,
+            "cpu_baseline": cpu,
+        }
+        print(json.dumps(out))
+    world.cleanup()
+    ctx.close()
+
+
+if __name__ == "__main__":
+    main()

@@ -161,6 +161,7 @@ typedef struct pyn_solve_opts {
   int maxit;         /* PETSc default 10000 */
   int restart;       /* GMRES(m), PETSc default 30 */
   int fixed_iters;   /* >0: run exactly this many iterations, no convergence exit (benchmarking) */
+  int profile;       /* !=0: bracket every SpMV launch with HIP events (first 256 iterations) */
   double rtol, atol, dtol;   /* PETSc defaults 1e-5, 1e-50, 1e5 */
 } pyn_solve_opts;
 typedef struct pyn_solve_info {
@@ -170,6 +171,8 @@ typedef struct pyn_solve_info {
   double rnorm0;
   double true_resid;  /* ||b - A x||_2 / ||b||_2 recomputed at exit */
   double solve_ms;    /* device time of the iteration loop (HIP events) */
+  double spmv_ms;     /* mean device time of one SpMV launch (profile != 0), else 0 */
+  int spmv_launches;  /* launches averaged in spmv_ms */
 } pyn_solve_info;
 /* Solve A x = b (x0 = 0).  Takes over KspSolver.createSolver + KSP.__call__
  * (src/solver/ksp_solver.py:9-19, call site base_problem.py:481). */

@@ -378,12 +378,10 @@ def box_mesh(nelem, lower, upper, ngl=2, jitter=0.0, seed=12345) -> BoxMesh:
     loc = np.array(local_lattice(ngl, dim))                     # [nn, dim]
     if dim == 2:                                                # x ~ -r, y ~ -s  (A.2)
         loc = m - loc
-    cells = list(itertools.product(*[range(n) for n in reversed(nelem)]))   # x fastest
-    conn = np.zeros((len(cells), ngl ** dim), dtype=np.int32)
-    for e, rev in enumerate(cells):
-        eidx = rev[::-1]
-        base = [eidx[d] * m for d in range(dim)]
-        conn[e] = sum((base[d] + loc[:, d]) * strides[d] for d in range(dim))
+    eidx = np.indices(tuple(reversed(nelem))).reshape(dim, -1)[::-1]       # cell (ex,ey[,ez]), x fastest
+    base = sum(eidx[d].astype(np.int64) * m * strides[d] for d in range(dim))          # [n_elem]
+    off = sum(loc[:, d].astype(np.int64) * strides[d] for d in range(dim))             # [nn]
+    conn = (base[:, None] + off[None, :]).astype(np.int32)
     idx = np.indices(lat)
     on = np.zeros(lat, dtype=bool)
     for d in range(dim):

@@ -1,0 +1,212 @@
+"""Problem skeleton on the GPU path.
+
+Mirrors ``src/cases/base_problem.py``: ``BaseProblem`` (config parsing :18-44,97-115, ``setUp``
+:46-51, ``setUpDomain`` :53-78, ``setUpElement`` :80-83, ``setUpSolver`` :274-289) and ``FreeSlip``
+(``setUpEmptyMats`` :463-477, ``buildKLEMats`` :499-552, ``solveKLE`` :479-481, ``getKLEError``
+:483-497).  The per-cell Python loop of ``buildKLEMats`` is ONE fused device pass here.
+
+Out of scope for this path: the PETSc TS time integrator, the HDF5/XDMF
+viewer, the operator chain of ``evalRHS`` (row f1) and ``NoSlipFreeSlip`` (row f2).
+"""
+import logging
+
+import numpy as np
+
+from pynama_amd.common.comm import get_world
+from pynama_amd.common.options import Options
+from pynama_amd.common.timer import Timer
+from pynama_amd.domain.dmplex import DMPlexDom
+from pynama_amd.elements.spectral import Spectral
+from pynama_amd.matrices.mat_generator import Mat, Operators
+from pynama_amd.solver.ksp_solver import KspSolver
+from pynama_amd.vectors import Vec
+
+
+class BaseProblem(object):
+    def __init__(self, config, **kwargs):
+        self.comm = get_world()
+        self.timerTotal = Timer()
+        self.timerTotal.tic()
+        self.timer = Timer()
+        if 'case' in kwargs:
+            case = kwargs['case']
+        else:
+            case = Options().getString('case', 'uniform')
+        self.config = config
+        self.logger = logging.getLogger(f"[{self.comm.rank}] {self.config.get('name')}")
+        self.case = case
+        self.caseName = self.config.get("name")
+        self.readDomainData(kwargs)
+        self.readMaterialData()
+        self.opts = kwargs
+        if 'boundary-conditions' in self.config:
+            self.readBoundaryCondition(self.config.get("boundary-conditions"))
+
+    def setUp(self):
+        self.setUpGeneral()
+        self.setUpBoundaryConditions()
+        self.setUpEmptyMats()
+        self.buildKLEMats()
+        self.buildOperators()
+
+    def setUpDomain(self):
+        domain = self.config.get("domain")
+        self.dom = None
+        if "box-mesh" in domain:
+            self.logger.info("Creating dom with box Mesh")
+            meshData = domain.get('box-mesh')
+            self.meshType = "box-mesh"
+            opts = {k: v for k, v in self.opts.items() if k in ('nelem', 'lower', 'upper', 'jitter', 'jitterSeed')}
+            self.dom = DMPlexDom(boxMesh=meshData, **opts)
+        elif "gmsh-file" in domain:
+            self.meshType = 'gmsh'
+            self.dom = DMPlexDom(fileName=domain.get('gmsh-file'))
+        self.dim = self.dom.getDimension()
+        self.dim_w = 1 if self.dim == 2 else 3
+        self.dim_s = 3 if self.dim == 2 else 6
+        self.ngl = self.opts['ngl'] if "ngl" in self.opts else domain['ngl']
+        self.dom.setFemIndexing(self.ngl)
+        if not self.comm.rank:
+            self.logger.info("DMPlex dom created")
+
+    def setUpElement(self):
+        self.elemType = Spectral(self.ngl, self.dim)
+        if not self.comm.rank:
+            self.logger.info(f"{self.dim}-D ngl:{self.ngl} Spectral element created")
+
+    def setUpBoundaryConditions(self):
+        self.dom.setLabelToBorders()
+        self.dom.setBoundaryCondition()
+        if not self.comm.rank:
+            self.logger.info("Boundary Conditions setted up")
+
+    def readMaterialData(self):
+        materialData = self.config.get("material-properties")
+        self.rho = materialData['rho']
+        self.mu = materialData['mu']
+        self.nu = self.mu / self.rho
+
+    def readDomainData(self, kwargs):
+        domain = self.config.get("domain")
+        if "nelem" in kwargs:
+            self.nelem = kwargs['nelem']
+        elif "box-mesh" in domain:
+            self.nelem = domain['box-mesh']['nelem']
+            self.lower = domain['box-mesh']['lower']
+            self.upper = domain['box-mesh']['upper']
+        else:
+            raise Exception("No Gmsh Implemented")
+        self.dim = len(self.nelem)
+        self.dim_w = 1 if self.dim == 2 else 3
+        self.dim_s = 3 if self.dim == 2 else 6
+        self.ngl = kwargs['ngl'] if "ngl" in kwargs else domain['ngl']
+
+    def createMesh(self, saveMesh=True):
+        self.dom.computeFullCoordinates(self.elemType)
+        if not self.comm.rank:
+            self.logger.info("Mesh created")
+
+    def setUpGeneral(self):
+        self.setUpDomain()
+        self.setUpElement()
+        self.createMesh()
+        self.bcNodes = self.dom.getNodesFromLabel("External Boundary")
+
+    def buildOperators(self):
+        """SrT / DivSrT / Curl operators (base_problem.py:132-140): scope row f1, not built yet."""
+        return None
+
+    def solveKLE(self, time, vort):
+        pass
+
+    def buildKLEMats(self):
+        pass
+
+    def computeInitialCondition(self, startTime):
+        pass
+
+    def applyBoundaryConditions(self, time):
+        pass
+
+    def readBoundaryCondition(self, bc=None):
+        pass
+
+    def setUpSolver(self):
+        self.solver = KspSolver()
+        self.solver.createSolver(self.mat.K, self.comm)
+        self.vel = self.mat.K.createVecRight()
+        self.vel.setName("velocity")
+        self.vort = self.mat.Rw.createVecRight()
+        self.vort.setName("vorticity")
+        self.vort.set(0.0)
+        self._VtensV = Vec(self.dom.ctx, self.dim_s)
+        self._Aux1 = Vec(self.dom.ctx, self.dim_s)
+
+    def computeVtensV(self, vec=None):
+        """v (x) v in Voigt-like order (base_problem.py:234-252)."""
+        arr = (vec if vec is not None else self.vel).getArray()
+        d, ds = self.dim, self.dim_s
+        n = arr.size // d
+        out = np.empty((n, ds))
+        vx, vy = arr[0::d], arr[1::d]
+        out[:, 0], out[:, 1], out[:, 2] = vx * vx, vx * vy, vy * vy
+        if d == 3:
+            vz = arr[2::d]
+            out[:, 3], out[:, 4], out[:, 5] = vy * vz, vz * vz, vz * vx
+        self._VtensV.setArray(out.ravel())
+
+    def setUpEmptyMats(self):
+        self.mat = None
+        self.operator = None
+
+    def view(self):
+        print(f"Case: {self.case}")
+        print(f"Domain: {self.dom.view()} ")
+        print(f"NGL: {self.dom.getNGL() }")
+
+
+class NoSlipFreeSlip(BaseProblem):
+    def setUpEmptyMats(self):
+        raise NotImplementedError("no-slip/free-slip split assembly (mat_ns.py, base_problem.py:300-454) "
+                                  "is scope row f2 (SURVEY.md section 8f)")
+
+
+class FreeSlip(BaseProblem):
+    def generateExactVecs(self, time):
+        return 0, 0
+
+    def setUpEmptyMats(self):
+        self.mat = Mat(self.dim, self.comm)
+        self.operator = Operators(self.dim, self.comm)
+        rStart, rEnd, d_nnz_ind, o_nnz_ind, ind_d, ind_o = self.dom.getMatIndices()
+        globalIndicesDIR = self.dom.getGlobalIndicesDirichlet()
+        d_nnz_ind_op = d_nnz_ind.copy()
+        self.mat.createEmptyKLEMats(rStart, rEnd, d_nnz_ind, o_nnz_ind, ind_d, ind_o, globalIndicesDIR)
+        if not self.comm.rank:
+            self.logger.info("Empty KLE Matrices created")
+        self.operator.createAll(rStart, rEnd, d_nnz_ind_op, o_nnz_ind)
+
+    def solveKLE(self, time, vort):
+        self.applyBoundaryConditions(time)
+        self.solver(self.mat.Rw * vort + self.mat.Krhs * self.vel, self.vel)     # base_problem.py:481
+
+    def getKLEError(self, viscousTimes=None, startTime=0.0, endTime=1.0, steps=10):
+        if viscousTimes is None:
+            viscousTimes = np.arange(startTime, endTime, (endTime - startTime) / steps)
+        times = [(tau ** 2) / (4 * self.nu) for tau in viscousTimes]
+        errors = list()
+        for time in times:
+            exactVel, exactVort = self.generateExactVecs(time)
+            self.applyBoundaryConditions(time)
+            self.solver(self.mat.Rw * exactVort + self.mat.Krhs * self.vel, self.vel)
+            errors.append((exactVel - self.vel).norm(norm_type=2))
+        return errors
+
+    def buildKLEMats(self):
+        """base_problem.py:499-552 as one fused device pass: quadrature of every cell
+        (spectral.py:89-157), scatter with Dirichlet elimination, unit diagonal (:549)."""
+        self.mat.assembleKLE(self.elemType, alpha_d=1e3, alpha_w=1e2)
+        self.mat.setIndices2One(self.mat.globalIndicesDIR)
+        self.mat.assembleAll()
+        if not self.comm.rank:
+            self.logger.info("KLE Matrices builded")

@@ -103,6 +103,7 @@ extern "C" int pyn_ctx_destroy(pyn_ctx* c) {
   (void)hipFree(c->d_eloc);
   (void)hipHostFree(c->h_scal);
   (void)hipHostFree(c->h_flag);
+  for (auto e : c->prof_ev) (void)hipEventDestroy(e);
   (void)hipEventDestroy(c->ev0);
   (void)hipEventDestroy(c->ev1);
   (void)hipStreamDestroy(c->stream);

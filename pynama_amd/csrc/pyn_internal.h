@@ -112,6 +112,7 @@ struct pyn_ctx {
   // CG work vectors (length n_local*bs_max), reallocated on demand
   double* d_work = nullptr;
   size_t work_bytes = 0;
+  std::vector<hipEvent_t> prof_ev;  // event pool for per-kernel timing
   // element-local scratch for pyn_elem_local
   double* d_eloc = nullptr;
   size_t eloc_bytes = 0;

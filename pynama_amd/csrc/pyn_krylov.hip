@@ -380,11 +380,21 @@ static int solve_cg(pyn_ctx* c, const DMat& A, const double* b, double* x, const
   }
   int issued = 0;
   const int chunk = 32;
+  const int prof_max = o.profile ? 256 : 0;
+  while ((int)c->prof_ev.size() < 2 * prof_max) {
+    hipEvent_t e;
+    PYN_HIP(hipEventCreate(&e));
+    c->prof_ev.push_back(e);
+  }
+  int prof_n = 0;
   while (!done && issued < maxit) {
     int todo = std::min(chunk, maxit - issued);
     for (int k = 0; k < todo; ++k) {
       PYN_TRY(pyn_halo_exchange(c, p, A.bc));
+      const bool prof = prof_n < prof_max;
+      if (prof) PYN_HIP(hipEventRecord(c->prof_ev[2 * prof_n], s));
       spmv_kernel<32, true><<<gs, 256, 0, s>>>(c->d_rowptr, c->d_colidx, A.val, p, Ap, rows, A.br, A.bc, c->d_flag, c->d_part);
+      if (prof) PYN_HIP(hipEventRecord(c->prof_ev[2 * prof_n++ + 1], s));
       sum_partials_kernel<<<1, 256, 0, s>>>(c->d_part, 1, gs, c->d_scal + S_TMP0, c->d_flag);
       PYN_TRY(allreduce_tmp(c, 1));
       cg_scalar_alpha_kernel<<<1, 1, 0, s>>>(c->d_scal, c->d_flag);
@@ -406,6 +416,16 @@ static int solve_cg(pyn_ctx* c, const DMat& A, const double* b, double* x, const
   float ms = 0;
   PYN_HIP(hipEventElapsedTime(&ms, c->ev0, c->ev1));
   info->solve_ms = ms;
+  if (prof_n) {
+    double acc = 0;
+    for (int k = 0; k < prof_n; ++k) {
+      float t = 0;
+      PYN_HIP(hipEventElapsedTime(&t, c->prof_ev[2 * k], c->prof_ev[2 * k + 1]));
+      acc += t;
+    }
+    info->spmv_ms = acc / prof_n;
+    info->spmv_launches = prof_n;
+  }
   info->iters = c->h_flag[F_ITERS];
   info->reason = c->h_flag[F_REASON] ? c->h_flag[F_REASON] : PYN_DIVERGED_ITS;
   info->rnorm = c->h_scal[S_RNORM];

@@ -1,0 +1,484 @@
+"""Structured box-mesh domain with the reference's DMPlexDom interface.
+
+Mirrors ``src/domain/dmplex.py`` (``DMPlexDom(PETSc.DMPlex)``): constructor keywords (:8-23),
+``setFemIndexing`` (:42-61), ``computeFullCoordinates`` (:66-95), ``getCellCornersCoords``
+(:97-104), border / label queries (:113-195), ``getGlobalNodesFromCell`` (:197-200), DOF index
+helpers (:210-220), ``getMatIndices`` (:305-333) and the ``apply*ToVec`` helpers (:262-296).
+
+What is different by design (SURVEY.md section 7 "hard parts"):
+  * PETSc's DMPlex topology is replaced by a closed-form structured lattice: global node id =
+    lexicographic lattice index (x fastest; matches src/tests/test_domain.py:197-201), element-
+    local node order = the reference's vertex/edge/face/interior order, cell-0
+    corner order as asserted in test_domain.py:26-30,94-104.
+  * The per-cell closure lookups of the hot loop become ONE connectivity array uploaded to the
+    GPU (`pyn_mesh_set`); `getMatIndices` becomes the device symbolic phase (`pyn_csr_symbolic`).
+  * Parallel layout = contiguous node-plane slabs along the slowest axis, one process per GPU
+    (same row-block ownership shape as PETSc MPIAIJ, dmplex.py:307 / mat_generator.py:96).
+"""
+import logging
+from math import floor
+
+import numpy as np
+
+from pynama_amd import _lib
+from pynama_amd.common.comm import get_world
+from pynama_amd.domain.indices import IndicesManager
+from pynama_amd.elements.spectral import _local_lattice
+
+
+class SlabPartition:
+    """Node-plane slabs along the slowest lattice axis: rank r owns planes [a_r, b_r)."""
+
+    def __init__(self, n_planes, m, nel_slow, size):
+        if size > 1 and n_planes // size < m:
+            raise ValueError(f"{n_planes} node planes cannot be split over {size} ranks with ngl-1={m}")
+        self.size, self.m, self.nel = size, m, nel_slow
+        self.bounds = [(r * n_planes) // size for r in range(size + 1)]
+
+    def owned(self, r):
+        return self.bounds[r], self.bounds[r + 1]
+
+    def elem_layers(self, r):
+        """element layers [k0, k1) that touch an owned plane"""
+        a, b = self.owned(r)
+        m = self.m
+        k0 = max(0, -(-(a - m) // m))            # ceil((a-m)/m)
+        k1 = min(self.nel - 1, (b - 1) // m) + 1
+        return k0, k1
+
+    def local_planes(self, r):
+        k0, k1 = self.elem_layers(r)
+        return k0 * self.m, k1 * self.m + 1       # [lo, hi)
+
+    def owner_of_plane(self, p):
+        return int(np.searchsorted(self.bounds, p, side="right") - 1)
+
+
+class DeviceGraph:
+    """Lazy stand-in for the per-row index sets returned by the reference's getMatIndices
+    (dmplex.py:314-322).  Carries the device context; materialises python sets only on demand."""
+
+    def __init__(self, dom, diag):
+        self.dom, self.diag = dom, diag
+
+    @property
+    def ctx(self):
+        return self.dom.ctx
+
+    def __len__(self):
+        return self.dom.nOwned
+
+    def __getitem__(self, row):
+        rp, ci = self.dom._hostGraph()
+        cols = self.dom._local2global(ci[rp[row]:rp[row + 1]])
+        r0, r1 = self.dom.rStart, self.dom.rEnd
+        inside = (cols >= r0) & (cols < r1)
+        return set(cols[inside if self.diag else ~inside].tolist())
+
+    def __iter__(self):
+        for i in range(len(self)):
+            yield self[i]
+
+
+class DMPlexDom(object):
+    def __init__(self, **kwargs):
+        self.comm = kwargs.get('comm') or get_world()
+        if 'boxMesh' in kwargs or 'nelem' in kwargs:
+            meshData = kwargs.get('boxMesh') or {}
+            lower = kwargs['lower'] if 'lower' in kwargs else meshData.get('lower')
+            upper = kwargs['upper'] if 'upper' in kwargs else meshData.get('upper')
+            faces = kwargs['nelem'] if 'nelem' in kwargs else meshData.get('nelem')
+            if isinstance(lower[0], str):      # reference: eval() of string bounds (dmplex.py:18-20)
+                from math import pi  # noqa: F401  (names usable inside the yaml expressions)
+                lower = [eval(v) for v in lower]
+                upper = [eval(v) for v in upper]
+            self.nelem = [int(n) for n in faces]
+            self.lower = [float(v) for v in lower[:len(self.nelem)]]
+            self.upper = [float(v) for v in upper[:len(self.nelem)]]
+        elif 'fileName' in kwargs:
+            raise NotImplementedError("Gmsh import (dmplex.py:22-23) is a later scope row (SURVEY.md 8 f4)")
+        else:
+            raise ValueError("DMPlexDom needs boxMesh=... or nelem/lower/upper")
+        self.dim = len(self.nelem)
+        self.dim_w = 1 if self.dim == 2 else 3
+        self.dim_s = 3 if self.dim == 2 else 6
+        self.logger = logging.getLogger(f"[{self.comm.rank}] Class")
+        if self.dim == 2:
+            self.namingConvention = ["down", "right", "up", "left"]
+            self._border_axis = {"down": (1, 0), "right": (0, 1), "up": (1, 1), "left": (0, 0)}
+        elif self.dim == 3:
+            self.namingConvention = ["back", "front", "down", "up", "right", "left"]
+            self._border_axis = {"back": (2, 0), "front": (2, 1), "down": (1, 0), "up": (1, 1),
+                                 "right": (0, 1), "left": (0, 0)}
+        else:
+            raise ValueError("dim must be 2 or 3")
+        self._ctx = None
+        self.jitter = float(kwargs.get('jitter', 0.0))
+        self.jitterSeed = int(kwargs.get('jitterSeed', 12345))
+        self._graph = None
+        self._fullCoordVec = None
+
+    @property
+    def ctx(self):
+        """Device context of this rank: created, bound to the communicator and loaded with the local
+        mesh on first use.  Raises if no MI355X is visible (there is no CPU fallback)."""
+        if self._ctx is None:
+            if not hasattr(self, "conn"):
+                raise RuntimeError("setFemIndexing(ngl) first")
+            ctx = _lib.Context(_lib.default_device())
+            if self.comm.size > 1:
+                uid = self.comm.unique_id(_lib.Context.unique_id)
+                ctx.comm_init(self.comm.rank, self.comm.size, uid)
+                ctx.halo_set(*self._halo_plan())
+            ctx.mesh_set(self.dim, self.conn, self.xyz)
+            ctx.row_start = self.rStart
+            self._ctx = ctx
+        return self._ctx
+
+    @property
+    def fullCoordVec(self):
+        """device copy of the nodal coordinates (dmplex.py:73-92), uploaded on first use"""
+        if self._fullCoordVec is None:
+            from pynama_amd.vectors import Vec
+            self._fullCoordVec = Vec(self.ctx, self.dim, name='NodeCoordinates')
+            self._fullCoordVec.setArray(self.xyz[:self.nOwned].ravel())
+        return self._fullCoordVec
+
+    # ------------------------------------------------------------------ basic queries
+    def getDimension(self):
+        return self.dim
+
+    def getBoundingBox(self):
+        return tuple((self.lower[d], self.upper[d]) for d in range(self.dim))
+
+    def getNGL(self):
+        return self.indicesManager.getNGL()
+
+    def getHeightStratum(self, h):
+        assert h == 0
+        return self.cellStart, self.cellEnd
+
+    # ------------------------------------------------------------------ indexing / mesh build
+    def setFemIndexing(self, ngl):
+        """Build the GLL lattice, the connectivity in reference local order, the slab partition,
+        and upload the local mesh to the GPU (replaces PetscSection set-up, dmplex.py:42-61)."""
+        dim = self.dim
+        self.indicesManager = IndicesManager(dim, ngl, self.comm)
+        m = ngl - 1
+        self.ngl = ngl
+        self.lattice = tuple(m * n + 1 for n in self.nelem)
+        self.strides = [int(np.prod(self.lattice[:d])) for d in range(dim)]
+        self.nNodesGlobal = int(np.prod(self.lattice))
+        self.part = SlabPartition(self.lattice[-1], m, self.nelem[-1], self.comm.size)
+        rank = self.comm.rank
+        a, b = self.part.owned(rank)
+        lo, hi = self.part.local_planes(rank)
+        k0, k1 = self.part.elem_layers(rank)
+        plane = self.strides[-1]
+        self.rStart, self.rEnd = a * plane, b * plane
+        self.nOwned = self.rEnd - self.rStart
+        # local numbering: owned planes, then ghost planes below, then ghost planes above
+        self._ghost_lo = (lo, a)
+        self._ghost_hi = (b, hi)
+        self.nGhost = ((a - lo) + (hi - b)) * plane
+        self.nLocal = self.nOwned + self.nGhost
+        # element range of this rank (all cells of the layers that touch owned planes)
+        cells_per_layer = int(np.prod(self.nelem[:-1]))
+        self.cellStart, self.cellEnd = 0, (k1 - k0) * cells_per_layer     # local numbering (dmplex.py:99)
+        self._cell0_global = k0 * cells_per_layer
+        self._layers = (k0, k1)
+        # connectivity (vectorised): conn[e, a] = base(e) + offset(a)
+        loc = np.array(_local_lattice(ngl, dim), dtype=np.int64)
+        if dim == 2:                      # x ~ -r, y ~ -s in 2D
+            loc = m - loc
+        self._loc = loc
+        shape = tuple(reversed(self.nelem[:-1] + [k1 - k0]))
+        eidx = np.indices(shape).reshape(dim, -1)[::-1].astype(np.int64)
+        eidx[-1] += k0
+        base = sum(eidx[d] * m * self.strides[d] for d in range(dim))
+        off = sum(loc[:, d] * self.strides[d] for d in range(dim))
+        conn_global = base[:, None] + off[None, :]
+        self.conn = self._global2local(conn_global).astype(np.int32)
+        # coordinates of the local nodes (GLL spaced inside each element)
+        self.xyz = self._lattice_coordinates()
+        # ---- device: created lazily (first use of .ctx) so that the host logic runs without a GPU
+        if self._ctx is not None:
+            self._ctx.close()
+        self._ctx = None
+        self._graph = None
+        if not self.comm.rank:
+            self.logger.debug("FEM/SEM Indexing SetUp")
+
+    def _local_plane_ids(self):
+        a, b = self.part.owned(self.comm.rank)
+        return list(range(a, b)) + list(range(*self._ghost_lo)) + list(range(*self._ghost_hi))
+
+    def _global2local(self, g):
+        """global lattice node id -> local id (owned first, ghosts below, ghosts above)"""
+        g = np.asarray(g, dtype=np.int64)
+        plane = self.strides[-1]
+        a, b = self.part.owned(self.comm.rank)
+        lo, hi = self._ghost_lo[0], self._ghost_hi[1]
+        p = g // plane
+        inpl = g - p * plane
+        out = np.full(g.shape, -1, dtype=np.int64)
+        own = (p >= a) & (p < b)
+        glo = (p >= lo) & (p < a)
+        ghi = (p >= b) & (p < hi)
+        out[own] = (p[own] - a) * plane + inpl[own]
+        out[glo] = self.nOwned + (p[glo] - lo) * plane + inpl[glo]
+        out[ghi] = self.nOwned + (a - lo) * plane + (p[ghi] - b) * plane + inpl[ghi]
+        return out
+
+    def _local2global(self, l):
+        l = np.asarray(l, dtype=np.int64)
+        plane = self.strides[-1]
+        a, b = self.part.owned(self.comm.rank)
+        lo = self._ghost_lo[0]
+        n_lo = (a - lo) * plane
+        out = np.empty(l.shape, dtype=np.int64)
+        own = l < self.nOwned
+        glo = (~own) & (l < self.nOwned + n_lo)
+        ghi = (~own) & (~glo)
+        out[own] = l[own] + a * plane
+        out[glo] = l[glo] - self.nOwned + lo * plane
+        out[ghi] = l[ghi] - self.nOwned - n_lo + b * plane
+        return out
+
+    def _halo_plan(self):
+        """(n_owned, n_ghost, neigh, send_ptr, send_idx, recv_ptr) for pyn_halo_set."""
+        rank, size = self.comm.rank, self.comm.size
+        plane = self.strides[-1]
+        a, b = self.part.owned(rank)
+        neigh, send_ptr, send_idx, recv_ptr = [], [0], [], [0]
+        for nb, (g0, g1) in ((rank - 1, self._ghost_lo), (rank + 1, self._ghost_hi)):
+            if nb < 0 or nb >= size:
+                assert g1 - g0 <= 0
+                continue
+            # what we receive from nb: our ghost planes [g0, g1) (all owned by nb: slabs >= m planes)
+            assert self.part.owner_of_plane(g0) == nb and self.part.owner_of_plane(g1 - 1) == nb
+            # what nb needs from us: its ghost planes on our side
+            nlo, nhi = self.part.local_planes(nb)
+            na, nb_b = self.part.owned(nb)
+            s0, s1 = (nb_b, nhi) if nb < rank else (nlo, na)
+            assert s0 >= a and s1 <= b
+            neigh.append(nb)
+            ids = np.arange((s0 - a) * plane, (s1 - a) * plane, dtype=np.int64)
+            send_idx.append(ids)
+            send_ptr.append(send_ptr[-1] + ids.size)
+            recv_ptr.append(recv_ptr[-1] + (g1 - g0) * plane)
+        sidx = np.concatenate(send_idx).astype(np.int32) if send_idx else np.zeros(0, np.int32)
+        return (self.nOwned, self.nGhost, np.array(neigh, np.int32), np.array(send_ptr, np.int64), sidx,
+                np.array(recv_ptr, np.int64))
+
+    def _lattice_coordinates(self):
+        from pynama_amd.elements.utilities import lobattoPoints
+        dim, m = self.dim, self.ngl - 1
+        gll, _ = lobattoPoints(self.ngl)
+        axes = []
+        for d in range(dim):
+            h = (self.upper[d] - self.lower[d]) / self.nelem[d]
+            ax = np.empty(self.lattice[d])
+            for e in range(self.nelem[d]):
+                ax[e * m:e * m + self.ngl] = self.lower[d] + h * (e + 0.5 * (1.0 + gll))
+            ax[-1] = self.upper[d]
+            axes.append(ax)
+        gids = self._local2global(np.arange(self.nLocal))
+        xyz = np.empty((self.nLocal, dim))
+        rem = gids.copy()
+        idx = []
+        for d in reversed(range(dim)):
+            q = rem // self.strides[d]
+            rem = rem - q * self.strides[d]
+            idx.append(q)
+        idx = idx[::-1]
+        for d in range(dim):
+            xyz[:, d] = axes[d][idx[d]]
+        if self.jitter > 0.0:
+            if self.ngl != 2:
+                raise ValueError("jitter needs ngl == 2 (geometry is multilinear from the corners)")
+            # same stream for every rank: draw for the whole lattice, pick the local nodes
+            rng = np.random.default_rng(self.jitterSeed)
+            hmin = min((self.upper[d] - self.lower[d]) / self.nelem[d] for d in range(dim))
+            move = self.jitter * hmin * rng.uniform(-1, 1, size=(self.nNodesGlobal, dim))
+            on = np.zeros(self.nLocal, dtype=bool)
+            for d in range(dim):
+                on |= (idx[d] == 0) | (idx[d] == self.lattice[d] - 1)
+            mv = move[gids]
+            mv[on] = 0.0
+            xyz = xyz + mv
+        self._lat_idx = idx
+        return xyz
+
+    # ------------------------------------------------------------------ coordinates
+    def computeFullCoordinates(self, spElem):
+        """Nodal coordinates of every (owned) node.  The reference interpolates the corner
+        coordinates with HCooOp per cell (dmplex.py:66-95); on a box mesh that is exactly the GLL
+        lattice built in setFemIndexing."""
+        self.nodes = list(range(self.rStart, self.rEnd))
+
+    def getCellCornersCoords(self, cell):
+        if cell + self.cellStart >= self.cellEnd:
+            raise Exception('elem parameter must be in local numbering!')
+        nc = 2 ** self.dim
+        return self.xyz[self.conn[cell, :nc]].reshape(nc * self.dim).copy()
+
+    # ------------------------------------------------------------------ nodes / DOFs
+    def getGlobalNodesFromCell(self, cell, shared):
+        nodes = self._local2global(self.conn[cell])
+        if not shared:
+            nodes = nodes[(nodes >= self.rStart) & (nodes < self.rEnd)]
+        return [int(n) for n in nodes]
+
+    def getGlobalNodesFromEntities(self, entities, shared):
+        nodes = set()
+        for cell in entities:
+            nodes |= set(self.getGlobalNodesFromCell(cell, shared))
+        return nodes
+
+    def getVelocityIndex(self, nodes):
+        return self.indicesManager.mapNodesToIndices(nodes, self.dim)
+
+    def getVorticityIndex(self, nodes):
+        return self.indicesManager.mapNodesToIndices(nodes, self.dim_w)
+
+    def getSrtIndex(self, nodes):
+        return self.indicesManager.mapNodesToIndices(nodes, self.dim_s)
+
+    def getAllNodes(self):
+        return list(range(self.rStart, self.rEnd))
+
+    def getNodesCoordinates(self, nodes=None, indices=None):
+        dim = self.dim
+        if nodes is None:
+            assert indices is not None
+            nodes = [int(i // dim) for i in list(indices)[::dim]][:floor(len(indices) / dim)]
+        loc = self._global2local(np.asarray(nodes, dtype=np.int64))
+        if np.any(loc < 0):
+            raise IndexError("node not stored on this rank")
+        return self.xyz[loc].reshape((len(nodes), dim))
+
+    # ------------------------------------------------------------------ borders / labels
+    def _on_border_mask(self, name):
+        d, hi = self._border_axis[name]
+        return self._lat_idx[d] == (self.lattice[d] - 1 if hi else 0)
+
+    def _global_border_nodes(self, name):
+        """all (global) nodes of a border, computed in closed form on every rank"""
+        d, hi = self._border_axis[name]
+        others = [k for k in range(self.dim) if k != d]
+        shape = tuple(self.lattice[k] for k in reversed(others))
+        idx = np.indices(shape).reshape(len(others), -1)[::-1].astype(np.int64)     # lowest axis fastest
+        ids = (self.lattice[d] - 1 if hi else 0) * self.strides[d]
+        ids = ids + sum(idx[j] * self.strides[k] for j, k in enumerate(others))
+        return np.sort(ids)
+
+    def setLabelToBorders(self):
+        """dmplex.py:113-131 builds a bit-label per entity; here borders are closed-form masks."""
+        self._labels_set = True
+
+    def getBordersNames(self):
+        return self.namingConvention
+
+    def getBorderNodes(self, name):
+        return [int(n) for n in self._global_border_nodes(name)]
+
+    def getBordersNodes(self) -> set:
+        nodes = set()
+        for faceName in self.namingConvention:
+            nodes |= set(self.getBorderNodes(faceName))
+        return nodes
+
+    def getNodesFromLabel(self, label, shared=False) -> set:
+        if label != "External Boundary":
+            self.logger.warning(f"Label >> {label} << found")
+            return set()
+        return self.getBordersNodes()
+
+    def boundaryMaskLocal(self):
+        """uint8 [nLocal]: 1 on 'External Boundary' nodes (owned + ghost)."""
+        on = np.zeros(self.nLocal, dtype=np.uint8)
+        for name in self.namingConvention:
+            on |= self._on_border_mask(name).astype(np.uint8)
+        return on
+
+    def getGlobalIndicesDirichlet(self):
+        return self.indicesManager.getDirichletNodes()
+
+    def getGlobalIndicesNoSlip(self):
+        return self.indicesManager.getNoSlipNodes()
+
+    def setBoundaryCondition(self, freeSlipFaces=[], noSlipFaces=[]):
+        if len(freeSlipFaces) or len(noSlipFaces):
+            for fsFace in freeSlipFaces:
+                self.indicesManager.setDirichletNodes(set(self.getBorderNodes(fsFace)))
+            for nsFace in noSlipFaces:
+                self.indicesManager.setNoSlipNodes(set(self.getBorderNodes(nsFace)))
+        else:
+            self.indicesManager.setDirichletNodes(self.getBordersNodes())
+
+    def dirichletMaskLocal(self, ndof):
+        """uint8 [nLocal*ndof] from the Dirichlet node set (all DOFs of the node imposed,
+        base_problem.py:516-520)."""
+        nodes = np.fromiter(self.indicesManager.getDirichletNodes(), dtype=np.int64)
+        mask = np.zeros((self.nLocal, ndof), dtype=np.uint8)
+        if nodes.size:
+            loc = self._global2local(nodes)
+            mask[loc[loc >= 0]] = 1
+        return mask
+
+    # ------------------------------------------------------------------ matrix indices
+    def _hostGraph(self):
+        if self._graph is None:
+            self.ctx.csr_symbolic()
+            self._graph = self.ctx.csr_get()
+        return self._graph
+
+    def getMatIndices(self):
+        """Symbolic phase on the GPU (replaces the per-row Python loop of dmplex.py:305-333).
+        Returns the reference's tuple; ind_d / ind_o are lazy DeviceGraph views."""
+        rp, ci = self._hostGraph()
+        cols = self._local2global(ci)
+        inside = (cols >= self.rStart) & (cols < self.rEnd)
+        row_of = np.repeat(np.arange(self.nOwned), np.diff(rp))
+        alt_d = np.bincount(row_of[inside], minlength=self.nOwned).astype(np.int32)
+        alt_o = np.bincount(row_of[~inside], minlength=self.nOwned).astype(np.int32)
+        return self.rStart, self.rEnd, alt_d, alt_o, DeviceGraph(self, True), DeviceGraph(self, False)
+
+    # ------------------------------------------------------------------ vec helpers
+    def createGlobalVec(self, bs=None):
+        from pynama_amd.vectors import Vec
+        return Vec(self.ctx, bs or self.dim)
+
+    def _owned_local(self, nodes):
+        nodes = np.asarray(list(nodes), dtype=np.int64)
+        keep = (nodes >= self.rStart) & (nodes < self.rEnd)
+        return nodes[keep], nodes[keep] - self.rStart
+
+    def applyFunctionVecToVec(self, nodes, f_vec, vec, dof):
+        gn, ln = self._owned_local(nodes)
+        coords = self.xyz[ln]
+        values = np.array(list(map(f_vec, coords)), dtype=np.float64).reshape(len(ln), dof)
+        inds = (ln[:, None] * dof + np.arange(dof)[None, :]).ravel()
+        vec.setValuesLocal(inds, values.ravel(), addv=False)
+        return vec
+
+    def applyFunctionScalarToVec(self, nodes, f_scalar, vec):
+        gn, ln = self._owned_local(nodes)
+        values = np.array(list(map(f_scalar, self.xyz[ln])), dtype=np.float64)
+        vec.setValuesLocal(ln, values, addv=False)
+        return vec
+
+    def applyValuesToVec(self, nodes, values, vec):
+        dof = len(values)
+        assert dof <= self.dim
+        if dof == 1:
+            vec.set(values[0])
+        else:
+            gn, ln = self._owned_local(nodes)
+            inds = (ln[:, None] * dof + np.arange(dof)[None, :]).ravel()
+            vec.setValuesLocal(inds, np.tile(np.asarray(values, dtype=np.float64), len(ln)), addv=False)
+        return vec
+
+    def view(self):
+        return f"DMPlexDom(box {self.nelem}, ngl={getattr(self, 'ngl', None)}, rank {self.comm.rank}/{self.comm.size})"

@@ -1,0 +1,201 @@
+"""Sparse containers of the KLE method on the GPU.
+
+Mirrors ``src/matrices/mat_generator.py``: ``Mat`` (``createEmptyKLEMats`` :32-93, ``assembleAll``
+:14-17, ``setIndices2One`` :113-118, ``createNNZWithArray`` :106-111, ``createNonZeroIndex``
+:101-104, ``printMatsInfo`` :120-130) and ``Operators`` (:133-190).  PETSc's AIJ preallocation
+becomes: all matrices share the device node graph built by ``DMPlexDom.getMatIndices`` and store
+(br x bc) blocks per graph edge (layout in include/pynama_hip.h).  Values are filled by ONE fused
+device pass (``assembleKLE``) instead of per-cell ``setValues`` calls.
+"""
+import logging
+
+import numpy as np
+
+from pynama_amd import _lib
+from pynama_amd.common.comm import get_world
+from pynama_amd.vectors import Vec
+
+
+class DeviceMat:
+    """PETSc.Mat look-alike bound to a device matrix handle."""
+
+    def __init__(self, ctx, br, bc, name=None):
+        self.ctx, self.br, self.bc = ctx, br, bc
+        self.id = ctx.mat_create(br, bc)
+        self._name = name
+        self._assembled = False
+
+    def setName(self, name):
+        self._name = name
+
+    def getName(self):
+        return self._name
+
+    def setUp(self):
+        return self
+
+    def assemble(self):
+        self._assembled = True
+
+    assemblyBegin = assemblyEnd = assemble
+
+    def getOwnershipRange(self):
+        r0 = getattr(self.ctx, "row_start", 0) * self.br
+        return (r0, r0 + self.ctx.n_owned * self.br)
+
+    def getSizes(self):
+        return ((self.ctx.n_owned * self.br, None), (self.ctx.n_owned * self.bc, None))
+
+    def createVecRight(self):
+        return Vec(self.ctx, self.bc)
+
+    def createVecLeft(self):
+        return Vec(self.ctx, self.br)
+
+    def mult(self, x, y):
+        self.ctx.spmv(self.id, x.id, y.id)
+
+    def __mul__(self, x):
+        if isinstance(x, Vec):
+            y = Vec(self.ctx, self.br)
+            self.ctx.spmv(self.id, x.id, y.id)
+            return y
+        return NotImplemented
+
+    def __add__(self, other):
+        out = DeviceMat(self.ctx, self.br, self.bc, name=f"({self._name}+{other._name})")
+        self.ctx.mat_axpy(out.id, 1.0, self.id)
+        self.ctx.mat_axpy(out.id, 1.0, other.id)
+        return out
+
+    def diagonalScale(self, L=None, R=None):
+        if R is not None:
+            raise NotImplementedError("column scaling is not used by the reference path")
+        if L is not None:
+            self.ctx.mat_row_scale(self.id, L.id)
+
+    def getDiagonal(self, result=None):
+        v = result or Vec(self.ctx, self.br)
+        self.ctx.mat_diagonal(self.id, v.id)
+        return v
+
+    def getInfo(self):
+        nnz = self.ctx.nnzb * self.br * self.bc
+        return {"memory": nnz * 8 + self.ctx.nnzb * 4, "nz_allocated": nnz, "nz_used": nnz, "nz_unneeded": 0}
+
+    def setValues(self, rows, cols, vals, addv=True):
+        raise NotImplementedError(
+            "per-cell Mat.setValues (base_problem.py:531-547) is replaced by the fused device pass "
+            "Mat.assembleKLE(); there is no host insertion path")
+
+    def toScipy(self):
+        """host copy as scipy CSR (diagnostics / tests only)"""
+        import scipy.sparse as sp
+        rp, ci = self.ctx.csr_get()
+        val = self.ctx.mat_values(self.id, self.br, self.bc)
+        lens = np.diff(rp).astype(np.int64)
+        n = len(lens)
+        node = np.repeat(np.arange(n), lens * self.br * self.bc)
+        # storage order within a node: p, k, q
+        within = np.concatenate([np.arange(l * self.br * self.bc) for l in lens]) if n < 200000 else None
+        if within is None:
+            raise MemoryError("toScipy is a diagnostic for small problems")
+        ln = np.repeat(lens, lens * self.br * self.bc)
+        p = within // (ln * self.bc)
+        rem = within - p * ln * self.bc
+        k = rem // self.bc
+        q = rem - k * self.bc
+        rows = node * self.br + p
+        cols = ci[np.repeat(rp[:-1].astype(np.int64), lens * self.br * self.bc) + k].astype(np.int64) * self.bc + q
+        return sp.coo_matrix((val, (rows, cols)), shape=(n * self.br, self.ctx.n_node * self.bc)).tocsr()
+
+
+class Mat:
+    def __init__(self, dim, comm=None):
+        self.dim = dim
+        self.comm = comm or get_world()
+        self.logger = logging.getLogger(f"[{self.comm.rank}]:MatClass")
+        self.dim_w = 1 if self.dim == 2 else 3
+        self.dim_s = 3 if self.dim == 2 else 6
+        self.mats = list()
+        self.ctx = None
+
+    def assembleAll(self):
+        for m in self.mats:
+            m.assemble()
+            self.logger.debug(f"Mat {m.getName()} Assembled")
+
+    def isParallel(self):
+        return self.comm.size > 1
+
+    def getGlobalIndices(self, localIndices):
+        # borders are closed-form, so every rank already holds the global set (cf. :20-30)
+        return set(localIndices)
+
+    def createEmptyKLEMats(self, rStart, rEnd, d_nnz_ind, o_nnz_ind, ind_d, ind_o, indicesDIR):
+        """Allocate K, Rw, Rd, Krhs on the shared device graph (mat_generator.py:32-93).
+        `ind_d` is the DeviceGraph returned by DMPlexDom.getMatIndices and carries the context."""
+        self.ctx = ind_d.ctx
+        self.dom = ind_d.dom
+        nodesDIR = self.getGlobalIndices(indicesDIR)
+        tmp = np.array(sorted(nodesDIR), dtype=np.int64)
+        self.globalIndicesDIR = (np.repeat(tmp * self.dim, self.dim)
+                                 + np.tile(np.arange(self.dim), len(tmp))).astype(np.int64)
+        self.K = DeviceMat(self.ctx, self.dim, self.dim, "K")
+        self.Rw = DeviceMat(self.ctx, self.dim, self.dim_w, "Rw")
+        self.Rd = DeviceMat(self.ctx, self.dim, 1, "Rd")
+        self.Krhs = DeviceMat(self.ctx, self.dim, self.dim, "Krhs")
+        self.mats = [self.K, self.Rw, self.Rd, self.Krhs]
+
+    def createEmptyMat(self, rows, cols, d_nonzero, offset_nonzero):
+        raise NotImplementedError("matrices are allocated on the device graph: see createEmptyKLEMats")
+
+    def assembleKLE(self, elem, alpha_d=1e3, alpha_w=1e2, with_rd=True, variant=1):
+        """The fused device pass that replaces the cell loop of FreeSlip.buildKLEMats
+        (base_problem.py:504-547) AND setIndices2One (:549)."""
+        for t in elem.deviceTables():
+            self.ctx.tables_set(*t)
+        self.ctx.bc_set(self.dim, self.dom.dirichletMaskLocal(self.dim))
+        self.ctx.assemble_kle(alpha_d, alpha_w, self.K.id, self.Krhs.id, self.Rw.id,
+                              self.Rd.id if with_rd else -1, variant)
+
+    def createNonZeroIndex(self, d_nnz, o_nnz, dim1, dim2):
+        di_nnz = [x * dim1 for x in d_nnz for d in range(dim2)]
+        oi_nnz = [x * dim1 for x in o_nnz for d in range(dim2)]
+        return di_nnz, oi_nnz
+
+    def createNNZWithArray(self, d_nnz, o_nnz, dim1: int, dim2: int):
+        d_nnz = np.array(d_nnz, dtype=np.int32)
+        o_nnz = np.array(o_nnz, dtype=np.int32)
+        return np.repeat(d_nnz * dim1, dim2), np.repeat(o_nnz * dim1, dim2)
+
+    def setIndices2One(self, indices2one):
+        """Unit diagonal on imposed DOFs (:113-118).  Already applied on the device by
+        assembleKLE (bc_identity kernel); kept for call-site compatibility."""
+        self.Krhs.assemble()
+        self.K.assemble()
+
+    def printMatsInfo(self):
+        print(" MATS INFO ")
+        print("Mat   | Memory Used [B]  | NZ Unneeded")
+        print("--------------------------------------")
+        for m in self.mats:
+            print(self.formatMatInfo(m.getName(), m.getInfo()))
+
+    @staticmethod
+    def formatMatInfo(name, info):
+        return f"{name:{5}} | {info['memory']:{16}} | {info['nz_unneeded']:{10}}"
+
+
+class Operators(Mat):
+    """Curl / DivSrT / SrT operators (mat_generator.py:133-190) -- scope row f1:
+    allocated lazily once the device operator kernels exist."""
+
+    def createAll(self, rStart, rEnd, d_nnz_ind, o_nnz_ind):
+        self._pending = (rStart, rEnd)
+
+    def setValues(self, localOperators, nodes):
+        raise NotImplementedError("KLE operators on device: SURVEY.md section 8 row f1 (next)")
+
+    def assembleAll(self):
+        return None

@@ -1,0 +1,109 @@
+"""The reference's own end-to-end tests, run against pynama_amd through the reference's module
+layout (`from cases.uniform import UniformFlow`): /root/reference/src/tests/test_solver.py:8-86 and
+test_mat.py:22-32.  Reads like the reference tests on purpose; tolerances are the reference's."""
+import os
+
+import numpy as np
+import pytest
+import yaml
+
+import pynama_amd
+
+pytestmark = pytest.mark.gpu
+pynama_amd.install_reference_layout()
+
+CASES = os.path.join(os.path.dirname(pynama_amd.__file__), "cases")
+
+
+def setFemProblem(case, **kwargs):
+    from cases.custom_func import CustomFuncCase
+    from cases.uniform import UniformFlow
+    with open(os.path.join(CASES, f'{case}.yaml')) as f:
+        yamlData = yaml.load(f, Loader=yaml.Loader)
+    fem = UniformFlow(yamlData, case=case, **kwargs) if case == 'uniform' else CustomFuncCase(yamlData, case=case, **kwargs)
+    fem.setUp()
+    fem.setUpSolver()
+    return fem
+
+
+def test_solveKLE_uniform_2d():                    # test_solver.py:20-27
+    fem = setFemProblem('uniform')
+    exactVel, exactVort = fem.generateExactVecs()
+    fem.solveKLE(time=0.0, vort=exactVort)
+    error = exactVel - fem.vel
+    assert error.norm(norm_type=2) < 1e-12
+    assert fem.solver.info.true_resid < 1e-10
+
+
+def test_solveKLE_taylorgreen():                   # test_solver.py:29-37
+    fem = setFemProblem('taylor-green', nelem=[2, 2], ngl=11)
+    exactVel, exactVort = fem.generateExactVecs(0.0)
+    fem.solveKLE(time=0.0, vort=exactVort)
+    assert (exactVel - fem.vel).norm(norm_type=2) < 2e-8
+
+
+def test_solveKLE_uniform_3d():                    # test_solver.py:52-62
+    fem = setFemProblem('uniform', lower=[0, 0, 0], upper=[1, 1, 1], nelem=[3, 3, 3], ngl=3)
+    exactVel, exactVort = fem.generateExactVecs()
+    fem.solveKLE(time=0.0, vort=exactVort)
+    assert (exactVel - fem.vel).norm(norm_type=2) < 2e-13
+
+
+def test_solveKLE_with_cg_options():
+    """-ksp_type cg -pc_type jacobi -ksp_rtol 1e-10 (BASELINE: residual <= 1e-10)"""
+    from common.options import Options
+    o = Options(["-ksp_type", "cg", "-pc_type", "jacobi", "-ksp_rtol", "1e-11", "-ksp_norm_type", "unpreconditioned"])
+    try:
+        fem = setFemProblem('uniform', lower=[0, 0, 0], upper=[1, 1, 1], nelem=[6, 5, 4], ngl=2, jitter=0.2)
+        exactVel, exactVort = fem.generateExactVecs()
+        fem.solveKLE(time=0.0, vort=exactVort)
+        assert fem.solver.getConvergedReason() == 2
+        assert fem.solver.info.true_resid <= 1e-10
+        assert (exactVel - fem.vel).norm(norm_type=3) < 1e-8
+    finally:
+        Options([])
+
+
+def test_VtensV_eval():                            # test_solver.py:66-86
+    fem = setFemProblem('uniform', lower=[0, 0], upper=[1, 1], nelem=[2, 2], ngl=2)
+    from pynama_amd.vectors import Vec
+    v = Vec(fem.dom.ctx, 2)
+    v.setArray(np.arange(1, 19, dtype=float))
+    fem.computeVtensV(vec=v)
+    ref = np.array([[a * a, a * b, b * b] for a, b in zip(range(1, 19, 2), range(2, 19, 2))], dtype=float).ravel()
+    np.testing.assert_array_almost_equal(ref, fem._VtensV.getArray(), decimal=10)
+
+
+def test_create_nnz():                             # test_mat.py:22-32
+    from matrices.mat_generator import Mat
+    fem = setFemProblem('uniform', lower=[0, 0], upper=[1, 1], nelem=[2, 2], ngl=3)
+    mat = Mat(2)
+    rStart, rEnd, d_nnz_ind, o_nnz_ind, ind_d, ind_o = fem.dom.getMatIndices()
+    assert (rStart, rEnd) == (0, 25)
+    assert d_nnz_ind.max() == 25 and d_nnz_ind.min() == 9 and o_nnz_ind.sum() == 0
+    assert ind_d[12] == set(range(25))             # centre node of the 2x2 ngl=3 mesh sees everything
+    for i in range(1, 3):
+        for j in range(1, 3):
+            d_ref, o_ref = mat.createNonZeroIndex(d_nnz_ind, o_nnz_ind, i, j)
+            d_test, o_test = mat.createNNZWithArray(d_nnz_ind, o_nnz_ind, i, j)
+            np.testing.assert_array_equal(d_ref, d_test)
+            np.testing.assert_array_equal(o_ref, o_test)
+
+
+def test_vec_interface():
+    fem = setFemProblem('uniform', lower=[0, 0], upper=[1, 1], nelem=[3, 3], ngl=2)
+    a = fem.mat.K.createVecRight()
+    b = a.duplicate()
+    a.set(2.0)
+    b.set(3.0)
+    assert (a * b).getArray()[0] == 6.0 and (a + b).getArray()[0] == 5.0 and (-(a - b)).getArray()[0] == 1.0
+    a += b
+    a *= 2.0
+    assert a.getArray()[0] == 10.0 and abs(a.dot(b) - 30.0 * 32) < 1e-12
+    a.reciprocal()
+    assert a.getArray()[0] == 0.1
+    a.setValues([1, 3], [7.0, 8.0])
+    assert a.getValues([1, 3]).tolist() == [7.0, 8.0]
+    assert a.getOwnershipRange() == (0, 32) and a.getSize() == 32
+    y = fem.mat.K * b
+    assert abs(y.getArray() - fem.mat.K.toScipy() @ b.getArray()).max() < 1e-12
