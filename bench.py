@@ -106,6 +106,8 @@ def main():
     ctx.bc_set(1, bmask)
     n_rows, nnz = ctx.csr_symbolic()
     symbolic_ms = ctx.timers()["symbolic_ms"]
+    if args.variant == 1:
+        ctx.patch_plan_set(*dom.patchPlan((7, 7, 7)))       # plan of the tiled (atomics-free) assembly
     A = ctx.mat_create(1, 1)
     vb, vx = ctx.vec_create(1), ctx.vec_create(1)
     h = 1.0 / n

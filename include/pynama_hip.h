@@ -107,6 +107,13 @@ int pyn_csr_symbolic(pyn_ctx* ctx);
 int pyn_csr_info(pyn_ctx* ctx, int64_t* n_rows, int64_t* nnz_blocks);
 int pyn_csr_get(pyn_ctx* ctx, int32_t* rowptr, int32_t* colidx);
 
+/* Optional patch plan for the atomics-free tiled assembly (Q1 hexahedra): a partition of the owned
+ * rows into patches of <= 352 rows, patch p owning patch_rows[patch_ptr[p] .. patch_ptr[p+1]).  One
+ * workgroup per patch integrates every element touching its rows, accumulates in LDS and writes each
+ * CSR row once (no HBM atomics, no zero fill).  Built on the device from the connectivity; call after
+ * pyn_csr_symbolic.  n_patch == 0 removes the plan.  Meshes without a plan use the generic kernel. */
+int pyn_patch_plan_set(pyn_ctx* ctx, int n_patch, const int32_t* patch_ptr, const int32_t* patch_rows);
+
 /* ---- matrices and vectors (device resident) ---------------------------------------------
  * Handles are small non-negative ints.  A vector with block size b has (n_owned+n_ghost)*b
  * entries; only the owned part is meaningful to the caller. */

@@ -423,7 +423,6 @@ static int mat_ptr(pyn_ctx* c, int id, int br, int bc, const char* name, double*
   PYN_TRY(pyn_check_mat(c, id, name));
   DMat& m = c->mats[id];
   PYN_CHECK(m.br == br && m.bc == bc, "%s must have block shape %dx%d (has %dx%d)", name, br, bc, m.br, m.bc);
-  PYN_HIP(hipMemsetAsync(m.val, 0, (size_t)c->nnzb * br * bc * sizeof(double), c->stream));
   *out = m.val;
   return PYN_OK;
 }
@@ -445,8 +444,16 @@ static int run_assembly(pyn_ctx* c, int form, double alpha_d, double alpha_w, do
   PYN_HIP(hipEventRecord(c->ev0, c->stream));
   bool handled = false;
   if (variant != 0) PYN_TRY(pyn_assemble_q1_tiled(c, form, alpha_d, alpha_w, K, Krhs, Rw, Rd, &handled));
-  if (!handled) PYN_TRY(launch_generic<false>(c, A, c->n_elem));
-  if (c->d_bcmask && (K || Krhs)) {
+  if (!handled) {  // scatter-add path: values start from zero (the tiled path writes every entry itself)
+    const int dw = c->dim == 2 ? 1 : 3;
+    const size_t nb = (size_t)c->nnzb * sizeof(double);
+    if (K) PYN_HIP(hipMemsetAsync(K, 0, nb * ndof * ndof, c->stream));
+    if (Krhs) PYN_HIP(hipMemsetAsync(Krhs, 0, nb * ndof * ndof, c->stream));
+    if (Rw) PYN_HIP(hipMemsetAsync(Rw, 0, nb * ndof * dw, c->stream));
+    if (Rd) PYN_HIP(hipMemsetAsync(Rd, 0, nb * ndof, c->stream));
+    PYN_TRY(launch_generic<false>(c, A, c->n_elem));
+  }
+  if (!handled && c->d_bcmask && (K || Krhs)) {
     int64_t n = c->n_owned * ndof;
     int grid = (int)std::min<int64_t>((n + 255) / 256, 4096);
     bc_identity_kernel<<<grid, 256, 0, c->stream>>>(c->d_rowptr, c->d_colidx, c->d_bcmask, c->n_owned, ndof, K, Krhs);

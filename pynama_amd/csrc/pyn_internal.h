@@ -100,6 +100,12 @@ struct pyn_ctx {
   int32_t* d_colidx = nullptr;
   int64_t nnzb = 0;
 
+  // patch plan of the tiled assembly (pyn_assemble_tiled.hip)
+  int32_t *pl_rowptr = nullptr, *pl_rows = nullptr, *pl_eptr = nullptr, *pl_elem = nullptr;
+  void *pl_rowslot4 = nullptr, *pl_kmap4 = nullptr;
+  int pl_npatch = 0, pl_maxrows = 0, pl_maxlen = 0;
+  int64_t pl_npe = 0;
+
   std::vector<DMat> mats;
   std::vector<DVec> vecs;
 

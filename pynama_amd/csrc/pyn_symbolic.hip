@@ -97,7 +97,8 @@ extern "C" int pyn_csr_symbolic(pyn_ctx* c) {
   PYN_HIP(hipFree(k1));
   PYN_HIP(hipFree(d_nuniq));
   c->nnzb = nuniq;
-  // all matrices are tied to the graph
+  // the patch plan and all matrices are tied to the graph
+  PYN_TRY(pyn_patch_plan_set(c, 0, nullptr, nullptr));
   for (auto& m : c->mats) (void)hipFree(m.val);
   c->mats.clear();
   return PYN_OK;

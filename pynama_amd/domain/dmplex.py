@@ -427,6 +427,22 @@ class DMPlexDom(object):
             mask[loc[loc >= 0]] = 1
         return mask
 
+    def patchPlan(self, tile=(7, 7, 7)):
+        """Partition of the OWNED rows into lattice tiles for the tiled device assembly
+        (pyn_patch_plan_set): returns (patch_ptr [P+1], patch_rows [nOwned]) in local row ids."""
+        dim = self.dim
+        a, b = self.part.owned(self.comm.rank)
+        shape = list(self.lattice[:-1]) + [b - a]            # owned lattice, x fastest
+        idx = np.indices(shape[::-1]).reshape(dim, -1)[::-1]  # idx[d][row], rows in local order
+        ntile = [-(-shape[d] // tile[d]) for d in range(dim)]
+        tid = np.zeros(idx[0].shape, dtype=np.int64)
+        for d in reversed(range(dim)):
+            tid = tid * ntile[d] + idx[d] // tile[d]
+        order = np.argsort(tid, kind="stable").astype(np.int32)
+        counts = np.bincount(tid, minlength=int(np.prod(ntile)))
+        ptr = np.concatenate([[0], np.cumsum(counts)]).astype(np.int32)
+        return ptr, order
+
     # ------------------------------------------------------------------ matrix indices
     def _hostGraph(self):
         if self._graph is None:

@@ -19,6 +19,15 @@ def lib():
     return _lib
 
 
+def tile_plan(mesh, tile=(7, 7, 7)):
+    """patch plan of the product's structured domain for the same box (same node numbering)"""
+    from pynama_amd.common.comm import Comm
+    from pynama_amd.domain.dmplex import DMPlexDom
+    dom = DMPlexDom(boxMesh={'nelem': list(mesh.nelem), 'lower': [0.0] * mesh.dim, 'upper': [1.0] * mesh.dim}, comm=Comm())
+    dom.setFemIndexing(mesh.ngl)
+    return dom.patchPlan(tile)
+
+
 def make_ctx(lib, mesh, ngl, bc_ndof=None, bc_nodes=None):
     from pynama_amd.elements.spectral import Spectral
     ctx = lib.Context(0)
@@ -110,9 +119,52 @@ def test_assemble_scalar_vs_oracle(lib, nelem, form, variant):
     dim = len(nelem)
     mesh = fo.box_mesh(nelem, [0.0] * dim, [1.0] * dim, 2, jitter=0.2)
     ctx = make_ctx(lib, mesh, 2, bc_ndof=1, bc_nodes=mesh.boundary)
+    if variant == 1 and dim == 3:
+        ctx.patch_plan_set(*tile_plan(mesh))
     A, Arhs = ctx.mat_create(1, 1), ctx.mat_create(1, 1)
     ctx.assemble_scalar(lib.FORM_LAPLACE if form == "laplace" else lib.FORM_MASS_NODAL, A, Arhs, variant=variant)
     ref = fo.assemble_scalar(mesh, fo.Tables(2, dim), form, dirichlet=mesh.boundary)
+    assert sp_rel_err(mat_to_scipy(ctx, A, 1, 1), ref["A"]) < FP_TOL
+    assert sp_rel_err(mat_to_scipy(ctx, Arhs, 1, 1), ref["Arhs"]) < FP_TOL
+    ctx.close()
+
+
+@pytest.mark.parametrize("tile", [(7, 7, 7), (4, 5, 3), (16, 4, 4)])
+def test_assemble_tiled_tiles_and_no_bc(lib, tile):
+    """tiled (atomics-free) kernel == generic kernel == oracle for several tile shapes, with and
+    without Dirichlet mask, with and without the Arhs output"""
+    mesh = fo.box_mesh([11, 9, 10], [0, 0, 0], [1, 1, 1], 2, jitter=0.2)
+    ref = fo.assemble_scalar(mesh, fo.Tables(2, 3), "laplace", dirichlet=mesh.boundary)
+    ref0 = fo.assemble_scalar(mesh, fo.Tables(2, 3), "laplace")
+    ctx = make_ctx(lib, mesh, 2, bc_ndof=1, bc_nodes=mesh.boundary)
+    ctx.patch_plan_set(*tile_plan(mesh, tile))
+    A, Arhs = ctx.mat_create(1, 1), ctx.mat_create(1, 1)
+    ctx.assemble_scalar(lib.FORM_LAPLACE, A, Arhs, variant=1)
+    assert sp_rel_err(mat_to_scipy(ctx, A, 1, 1), ref["A"]) < FP_TOL
+    assert sp_rel_err(mat_to_scipy(ctx, Arhs, 1, 1), ref["Arhs"]) < FP_TOL
+    ctx.assemble_scalar(lib.FORM_LAPLACE, A, -1, variant=1)
+    assert sp_rel_err(mat_to_scipy(ctx, A, 1, 1), ref["A"]) < FP_TOL
+    ctx.bc_set(1, None)
+    ctx.assemble_scalar(lib.FORM_LAPLACE, A, -1, variant=1)
+    assert sp_rel_err(mat_to_scipy(ctx, A, 1, 1), ref0["A"]) < FP_TOL
+    ctx.close()
+
+
+def test_assemble_tiled_scattered_patches(lib):
+    """patches need not be lattice tiles: random row -> patch assignment and permuted elements
+    (irregular-indexing stress) still give the oracle's matrix"""
+    mesh = fo.box_mesh([8, 7, 6], [0, 0, 0], [1, 1, 1], 2, jitter=0.2)
+    rng = np.random.default_rng(99)
+    mesh.conn = mesh.conn[rng.permutation(mesh.n_elem)]
+    ref = fo.assemble_scalar(mesh, fo.Tables(2, 3), "laplace", dirichlet=mesh.boundary)
+    ctx = make_ctx(lib, mesh, 2, bc_ndof=1, bc_nodes=mesh.boundary)
+    rows = rng.permutation(mesh.n_node).astype(np.int32)
+    cuts = np.sort(rng.choice(np.arange(1, mesh.n_node), size=5, replace=False))
+    ptr = np.concatenate([[0], cuts, [mesh.n_node]]).astype(np.int32)
+    assert np.diff(ptr).max() <= 352
+    ctx.patch_plan_set(ptr, rows)
+    A, Arhs = ctx.mat_create(1, 1), ctx.mat_create(1, 1)
+    ctx.assemble_scalar(lib.FORM_LAPLACE, A, Arhs, variant=1)
     assert sp_rel_err(mat_to_scipy(ctx, A, 1, 1), ref["A"]) < FP_TOL
     assert sp_rel_err(mat_to_scipy(ctx, Arhs, 1, 1), ref["Arhs"]) < FP_TOL
     ctx.close()
