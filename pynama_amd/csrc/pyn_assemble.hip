@@ -423,6 +423,7 @@ static int mat_ptr(pyn_ctx* c, int id, int br, int bc, const char* name, double*
   PYN_TRY(pyn_check_mat(c, id, name));
   DMat& m = c->mats[id];
   PYN_CHECK(m.br == br && m.bc == bc, "%s must have block shape %dx%d (has %dx%d)", name, br, bc, m.br, m.bc);
+  m.sell_valid = false;  // values are about to change
   *out = m.val;
   return PYN_OK;
 }

@@ -126,6 +126,7 @@ struct TileArgs {
   const int32_t* rowptr;
   const int32_t* colidx;
   const uint8_t* bcmask;  // per node (scalar forms), may be null
+  const uint8_t* colbc;   // per CSR entry: column node imposed (null iff bcmask null)
   const int32_t* p_rowptr;
   const int32_t* p_rows;
   const int32_t* p_eptr;
@@ -135,6 +136,7 @@ struct TileArgs {
   int64_t npe;
   int n_patch;
   int maxlen;           // max CSR row length (27)
+  int maxrows;          // max rows per patch (LDS layout)
   const double* w;      // full rule [8]
   const double* hrs;    // [8][3][8]  reference gradients of the nodal basis at the Gauss points
   const double* hcoo;   // [8][3][8]  reference gradients of the geometry (corner) basis
@@ -203,14 +205,23 @@ __device__ inline int tri(int a, int b) {  // index of (min,max) in the packed u
 }
 
 __global__ void __launch_bounds__(TILE_THREADS, 2) assemble_q1_hex_tiled_kernel(TileArgs T) {
-  extern __shared__ __align__(16) double acc[];  // [nrows][maxlen]
+  extern __shared__ __align__(16) double acc[];  // [nrows][maxlen] then per-row meta
   const int p = blockIdx.x;
   const int r_lo = T.p_rowptr[p];
   const int nrows = T.p_rowptr[p + 1] - r_lo;
   const int e_lo = T.p_eptr[p];
   const int ne = T.p_eptr[p + 1] - e_lo;
   const int ml = T.maxlen;
+  int* rmeta = reinterpret_cast<int*>(acc + (size_t)T.maxrows * ml);  // [maxrows][2]: csr offset, len | bc<<16
   for (int i = threadIdx.x; i < nrows * ml; i += TILE_THREADS) acc[i] = 0.0;
+  for (int sl = threadIdx.x; sl < nrows; sl += TILE_THREADS) {
+    const int row = T.p_rows[r_lo + sl];
+    const int lo = T.rowptr[row];
+    const int len = T.rowptr[row + 1] - lo;
+    const int mr = (T.bcmask && T.bcmask[row]) ? 1 : 0;
+    rmeta[2 * sl] = lo;
+    rmeta[2 * sl + 1] = len | (mr << 16) | ((find_slot_t(T.colidx, lo, len, row) & 0xFF) << 20);
+  }
   __syncthreads();
 
   for (int base = 0; base < ne; base += TILE_THREADS) {
@@ -260,20 +271,20 @@ __global__ void __launch_bounds__(TILE_THREADS, 2) assemble_q1_hex_tiled_kernel(
   __syncthreads();
 
   // ---- write every owned row once: A gets the free columns, Arhs the imposed ones (negated);
-  //      imposed rows become identity rows (mat_generator.py:113-118)
+  //      imposed rows become identity rows (mat_generator.py:113-118).  All indices come from LDS
+  //      row meta + one coalesced byte per entry: no dependent gathers in this phase.
   for (int i = threadIdx.x; i < nrows * ml; i += TILE_THREADS) {
     const int slot = i / ml, k = i - slot * ml;
-    const int row = T.p_rows[r_lo + slot];
-    const int lo = T.rowptr[row];
-    const int len = T.rowptr[row + 1] - lo;
+    const int lo = rmeta[2 * slot];
+    const int m1 = rmeta[2 * slot + 1];
+    const int len = m1 & 0xFFFF;
     if (k >= len) continue;
-    const int col = T.colidx[lo + k];
     const double v = acc[i];
-    const bool mr = T.bcmask && T.bcmask[row];
-    const bool mc = T.bcmask && T.bcmask[col];
+    const bool mr = (m1 >> 16) & 1;
+    const bool mc = T.colbc && T.colbc[lo + k];
     double va, vr;
     if (mr) {
-      va = vr = (col == row) ? 1.0 : 0.0;
+      va = vr = (k == ((m1 >> 20) & 0xFF)) ? 1.0 : 0.0;
     } else if (mc) {
       va = 0.0;
       vr = -v;
@@ -284,6 +295,12 @@ __global__ void __launch_bounds__(TILE_THREADS, 2) assemble_q1_hex_tiled_kernel(
     T.A[lo + k] = va;
     if (T.Arhs) T.Arhs[lo + k] = vr;
   }
+}
+
+__global__ void colbc_kernel(const int32_t* __restrict__ colidx, const uint8_t* __restrict__ bcmask, int64_t nnz,
+                             uint8_t* __restrict__ colbc) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < nnz; i += (int64_t)gridDim.x * blockDim.x)
+    colbc[i] = bcmask[colidx[i]];
 }
 
 }  // namespace
@@ -299,6 +316,9 @@ extern "C" int pyn_patch_plan_set(pyn_ctx* c, int n_patch, const int32_t* patch_
   (void)hipFree(c->pl_elem);
   (void)hipFree(c->pl_rowslot4);
   (void)hipFree(c->pl_kmap4);
+  (void)hipFree(c->pl_colbc);
+  c->pl_colbc = nullptr;
+  c->pl_colbc_stamp = -1;
   c->pl_rowptr = c->pl_rows = c->pl_eptr = c->pl_elem = nullptr;
   c->pl_rowslot4 = c->pl_kmap4 = nullptr;
   c->pl_npatch = 0;
@@ -381,7 +401,7 @@ extern "C" int pyn_patch_plan_set(pyn_ctx* c, int n_patch, const int32_t* patch_
   c->pl_npe = npe;
   c->pl_maxrows = max_rows;
   c->pl_maxlen = maxlen;
-  size_t lds = (size_t)max_rows * maxlen * sizeof(double);
+  size_t lds = (size_t)max_rows * maxlen * sizeof(double) + (size_t)max_rows * 2 * sizeof(int);
   PYN_CHECK(lds <= 160 * 1024, "patch accumulators need %zu B of LDS", lds);
   PYN_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(assemble_q1_hex_tiled_kernel),
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
@@ -398,6 +418,16 @@ int pyn_assemble_q1_tiled(pyn_ctx* c, int form, double, double, double* K, doubl
   T.rowptr = c->d_rowptr;
   T.colidx = c->d_colidx;
   T.bcmask = c->d_bcmask;
+  T.colbc = nullptr;
+  if (c->d_bcmask) {  // per-entry "column imposed" bytes, refreshed when the mask changed
+    if (!c->pl_colbc) PYN_HIP(hipMalloc((void**)&c->pl_colbc, (size_t)c->nnzb));
+    if (c->pl_colbc_stamp != c->bc_stamp) {
+      int g = (int)std::min<int64_t>((c->nnzb + 255) / 256, 65536);
+      colbc_kernel<<<g, 256, 0, c->stream>>>(c->d_colidx, c->d_bcmask, c->nnzb, c->pl_colbc);
+      c->pl_colbc_stamp = c->bc_stamp;
+    }
+    T.colbc = c->pl_colbc;
+  }
   T.p_rowptr = c->pl_rowptr;
   T.p_rows = c->pl_rows;
   T.p_eptr = c->pl_eptr;
@@ -407,12 +437,13 @@ int pyn_assemble_q1_tiled(pyn_ctx* c, int form, double, double, double* K, doubl
   T.npe = c->pl_npe;
   T.n_patch = c->pl_npatch;
   T.maxlen = c->pl_maxlen;
+  T.maxrows = c->pl_maxrows;
   T.w = c->quad[0].w;
   T.hrs = c->quad[0].Hrs;
   T.hcoo = c->quad[0].HrsCoo;
   T.A = K;
   T.Arhs = Krhs;
-  size_t lds = (size_t)c->pl_maxrows * c->pl_maxlen * sizeof(double);
+  size_t lds = (size_t)c->pl_maxrows * c->pl_maxlen * sizeof(double) + (size_t)c->pl_maxrows * 2 * sizeof(int);
   assemble_q1_hex_tiled_kernel<<<c->pl_npatch, TILE_THREADS, lds, c->stream>>>(T);
   PYN_HIP(hipGetLastError());
   *handled = true;

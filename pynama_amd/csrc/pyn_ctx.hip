@@ -86,7 +86,11 @@ extern "C" int pyn_ctx_destroy(pyn_ctx* c) {
   (void)hipSetDevice(c->device);
   (void)hipStreamSynchronize(c->stream);
   if (c->comm) ncclCommDestroy(c->comm);
-  for (auto& m : c->mats) (void)hipFree(m.val);
+  for (auto& m : c->mats) {
+    (void)hipFree(m.val);
+    (void)hipFree(m.sell_val);
+  }
+  pyn_sell_drop_structure(c);
   for (auto& v : c->vecs) (void)hipFree(v.d);
   for (auto& q : c->quad) free_quad(q);
   (void)hipFree(c->d_conn);
@@ -100,6 +104,7 @@ extern "C" int pyn_ctx_destroy(pyn_ctx* c) {
   (void)hipFree(c->pl_elem);
   (void)hipFree(c->pl_rowslot4);
   (void)hipFree(c->pl_kmap4);
+  (void)hipFree(c->pl_colbc);
   (void)hipFree(c->d_send_idx);
   (void)hipFree(c->d_send_buf);
   (void)hipFree(c->d_part);
@@ -286,6 +291,7 @@ extern "C" int pyn_elem_tables_set(pyn_ctx* c, int which, int ngp, const double*
 
 extern "C" int pyn_bc_set(pyn_ctx* c, int ndof, const uint8_t* mask) {
   PYN_CHECK(c, "ctx is NULL");
+  c->bc_stamp++;
   PYN_CHECK(c->n_node > 0, "pyn_mesh_set first");
   if (!mask) {
     (void)hipFree(c->d_bcmask);
@@ -333,6 +339,7 @@ extern "C" int pyn_mat_zero(pyn_ctx* c, int id) {
   PYN_TRY(pyn_check_mat(c, id, "pyn_mat_zero"));
   DMat& m = c->mats[id];
   PYN_HIP(hipMemsetAsync(m.val, 0, (size_t)c->nnzb * m.br * m.bc * sizeof(double), c->stream));
+  m.sell_valid = false;
   return PYN_OK;
 }
 

@@ -55,6 +55,8 @@ struct QuadTab {
 struct DMat {
   int br = 0, bc = 0;
   double* val = nullptr;  // [nnzb*br*bc], layout in pynama_hip.h
+  double* sell_val = nullptr;  // SELL-64 image of `val` (scalar matrices, solver side)
+  bool sell_valid = false;
   bool live = false;
 };
 
@@ -93,6 +95,7 @@ struct pyn_ctx {
 
   // boundary condition
   int bc_ndof = 0;
+  int64_t bc_stamp = 0;  // bumped by every pyn_bc_set
   uint8_t* d_bcmask = nullptr;
 
   // node graph
@@ -103,8 +106,17 @@ struct pyn_ctx {
   // patch plan of the tiled assembly (pyn_assemble_tiled.hip)
   int32_t *pl_rowptr = nullptr, *pl_rows = nullptr, *pl_eptr = nullptr, *pl_elem = nullptr;
   void *pl_rowslot4 = nullptr, *pl_kmap4 = nullptr;
+  uint8_t* pl_colbc = nullptr;   // per CSR entry: column imposed (follows bc_stamp)
+  int64_t pl_colbc_stamp = -1;
   int pl_npatch = 0, pl_maxrows = 0, pl_maxlen = 0;
   int64_t pl_npe = 0;
+
+  // SELL-64 structure shared by the scalar matrices of the graph (pyn_sell.hip)
+  int64_t* sell_ptr = nullptr;
+  int* sell_w = nullptr;
+  int32_t* sell_col = nullptr;
+  int64_t sell_total = 0, sell_ns = 0;
+  int sell_maxw = 0;
 
   std::vector<DMat> mats;
   std::vector<DVec> vecs;
@@ -134,3 +146,6 @@ int pyn_check_vec(pyn_ctx* c, int id, const char* what);
 int pyn_reduce_host(pyn_ctx* c, int nslots, int nblocks, int op, double* out);  // partials -> host, allreduced
 int pyn_spmv_raw(pyn_ctx* c, const DMat& A, const double* x, double* y);        // no halo exchange
 int pyn_extract_diag_inv(pyn_ctx* c, const DMat& A, double* dinv, bool invert);
+int pyn_sell_ensure(pyn_ctx* c, DMat& A);
+int pyn_sell_spmv(pyn_ctx* c, const DMat& A, const double* x, double* y, bool dot, int* grid_out);
+void pyn_sell_drop_structure(pyn_ctx* c);

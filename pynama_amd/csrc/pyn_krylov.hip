@@ -288,6 +288,7 @@ extern "C" int pyn_mat_axpy(pyn_ctx* c, int ym, double a, int xm) {
   DMat &Y = c->mats[ym], &X = c->mats[xm];
   PYN_CHECK(Y.br == X.br && Y.bc == X.bc, "block shape mismatch");
   int64_t n = c->nnzb * Y.br * Y.bc;
+  Y.sell_valid = false;
   mat_axpy_kernel<<<vgrid(n), 256, 0, c->stream>>>(Y.val, a, X.val, n);
   return PYN_OK;
 }
@@ -314,6 +315,7 @@ extern "C" int pyn_mat_row_scale(pyn_ctx* c, int mat_id, int vec_id) {
   DMat& A = c->mats[mat_id];
   PYN_CHECK(c->vecs[vec_id].bs == A.br, "block size mismatch");
   int64_t rows = c->n_owned * A.br;
+  A.sell_valid = false;
   int grid = (int)std::max<int64_t>(1, std::min<int64_t>((rows * 64 + 255) / 256, 8192));
   row_scale_kernel<<<grid, 256, 0, c->stream>>>(c->d_rowptr, A.val, c->vecs[vec_id].d, c->n_owned, A.br, A.bc);
   return PYN_OK;
@@ -345,7 +347,9 @@ static int allreduce_tmp(pyn_ctx* c, int n) {
   return PYN_OK;
 }
 
-static int solve_cg(pyn_ctx* c, const DMat& A, const double* b, double* x, const pyn_solve_opts& o, pyn_solve_info* info) {
+static int solve_cg(pyn_ctx* c, DMat& A, const double* b, double* x, const pyn_solve_opts& o, pyn_solve_info* info) {
+  const bool sell = A.br == 1 && A.bc == 1;
+  if (sell) PYN_TRY(pyn_sell_ensure(c, A));
   const int64_t n = c->n_owned * A.br;
   const int64_t nl = n_local(c) * A.br;
   // work: r[n] p[nl] Ap[n] dinv[n] hist
@@ -393,9 +397,13 @@ static int solve_cg(pyn_ctx* c, const DMat& A, const double* b, double* x, const
       PYN_TRY(pyn_halo_exchange(c, p, A.bc));
       const bool prof = prof_n < prof_max;
       if (prof) PYN_HIP(hipEventRecord(c->prof_ev[2 * prof_n], s));
-      spmv_kernel<32, true><<<gs, 256, 0, s>>>(c->d_rowptr, c->d_colidx, A.val, p, Ap, rows, A.br, A.bc, c->d_flag, c->d_part);
+      int gsp = gs;
+      if (sell)
+        PYN_TRY(pyn_sell_spmv(c, A, p, Ap, true, &gsp));
+      else
+        spmv_kernel<32, true><<<gs, 256, 0, s>>>(c->d_rowptr, c->d_colidx, A.val, p, Ap, rows, A.br, A.bc, c->d_flag, c->d_part);
       if (prof) PYN_HIP(hipEventRecord(c->prof_ev[2 * prof_n++ + 1], s));
-      sum_partials_kernel<<<1, 256, 0, s>>>(c->d_part, 1, gs, c->d_scal + S_TMP0, c->d_flag);
+      sum_partials_kernel<<<1, 256, 0, s>>>(c->d_part, 1, gsp, c->d_scal + S_TMP0, c->d_flag);
       PYN_TRY(allreduce_tmp(c, 1));
       cg_scalar_alpha_kernel<<<1, 1, 0, s>>>(c->d_scal, c->d_flag);
       cg_update_kernel<<<g, 256, 0, s>>>(c->d_scal, c->d_flag, dv, p, Ap, x, r, n, o.norm_type, c->d_part);

@@ -99,8 +99,12 @@ extern "C" int pyn_csr_symbolic(pyn_ctx* c) {
   c->nnzb = nuniq;
   // the patch plan and all matrices are tied to the graph
   PYN_TRY(pyn_patch_plan_set(c, 0, nullptr, nullptr));
-  for (auto& m : c->mats) (void)hipFree(m.val);
+  for (auto& m : c->mats) {
+    (void)hipFree(m.val);
+    (void)hipFree(m.sell_val);
+  }
   c->mats.clear();
+  pyn_sell_drop_structure(c);
   return PYN_OK;
 }
 
