@@ -68,6 +68,9 @@ int pyn_sync(pyn_ctx* ctx);                       /* hipStreamSynchronize on the
  * src/matrices/mat_generator.py:95-99) and the implicit collectives inside MatAssembly /
  * KSPSolve. */
 int pyn_comm_unique_id(void* out, int nbytes);    /* rank 0: nbytes >= 128 */
+/* unique_id == NULL with nranks > 1 declares the ranks WITHOUT a transport ("detached"): the rank's
+ * slab can be assembled and multiplied in isolation, ghost entries being supplied by the caller
+ * through pyn_vec_set_local_host; collectives and pyn_solve are refused. */
 int pyn_comm_init(pyn_ctx* ctx, int rank, int nranks, const void* unique_id, int nbytes);
 int pyn_comm_barrier(pyn_ctx* ctx);               /* device + host barrier over all ranks */
 int pyn_comm_allreduce_f64(pyn_ctx* ctx, double* inout, int n, int op /*0 sum, 1 max*/);
@@ -126,6 +129,7 @@ int pyn_mat_row_scale(pyn_ctx* ctx, int mat_id, int vec_id);        /* diagonalS
 int pyn_vec_create(pyn_ctx* ctx, int bs, int* vec_id);
 int pyn_vec_destroy(pyn_ctx* ctx, int vec_id);
 int pyn_vec_set_host(pyn_ctx* ctx, int vec_id, const double* src);  /* owned part, n_owned*bs */
+int pyn_vec_set_local_host(pyn_ctx* ctx, int vec_id, const double* src); /* owned + ghost, (n_owned+n_ghost)*bs */
 int pyn_vec_get_host(pyn_ctx* ctx, int vec_id, double* dst);
 int pyn_vec_fill(pyn_ctx* ctx, int vec_id, double value);
 int pyn_vec_scatter_host(pyn_ctx* ctx, int vec_id, int64_t n, const int32_t* idx, const double* vals,

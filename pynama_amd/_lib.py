@@ -75,6 +75,7 @@ SIGNATURES = {
     "pyn_vec_create": [_P, _I, C.POINTER(_I)],
     "pyn_vec_destroy": [_P, _I],
     "pyn_vec_set_host": [_P, _I, _pf64],
+    "pyn_vec_set_local_host": [_P, _I, _pf64],
     "pyn_vec_get_host": [_P, _I, _pf64],
     "pyn_vec_fill": [_P, _I, _D],
     "pyn_vec_scatter_host": [_P, _I, _L, _pi32, _pf64, _I],
@@ -200,6 +201,7 @@ class Context:
                                      _i32(send_idx) if len(send_idx) else np.zeros(1, np.int32),
                                      np.ascontiguousarray(recv_ptr, np.int64)))
         self._halo = True
+        self.n_owned, self.n_ghost = int(n_owned), int(n_ghost)
 
     def sync(self):
         _check(self.lib.pyn_sync(self.h))
@@ -282,6 +284,11 @@ class Context:
 
     def vec_set(self, vid, arr):
         _check(self.lib.pyn_vec_set_host(self.h, vid, _f64(arr)))
+
+    def vec_set_local(self, vid, arr):
+        a = _f64(arr)
+        assert a.size % (self.n_owned + self.n_ghost) == 0
+        _check(self.lib.pyn_vec_set_local_host(self.h, vid, a))
 
     def vec_get(self, vid, bs):
         out = np.empty(self.n_owned * bs, np.float64)

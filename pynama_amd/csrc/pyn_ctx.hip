@@ -153,7 +153,11 @@ extern "C" int pyn_comm_init(pyn_ctx* c, int rank, int nranks, const void* uid, 
   c->rank = rank;
   c->nranks = nranks;
   if (nranks == 1) return PYN_OK;
-  PYN_CHECK(uid && nbytes >= (int)sizeof(ncclUniqueId), "unique id missing");
+  if (!uid) {  // detached: this rank's slab is processed in isolation (tests, staged pipelines)
+    c->detached = true;
+    return PYN_OK;
+  }
+  PYN_CHECK(nbytes >= (int)sizeof(ncclUniqueId), "unique id too short");
   ncclUniqueId id;
   memcpy(&id, uid, sizeof(id));
   PYN_HIP(hipSetDevice(c->device));
@@ -164,6 +168,7 @@ extern "C" int pyn_comm_init(pyn_ctx* c, int rank, int nranks, const void* uid, 
 extern "C" int pyn_comm_allreduce_f64(pyn_ctx* c, double* inout, int n, int op) {
   PYN_CHECK(c && inout && n > 0 && n <= 32, "bad arguments");
   if (c->nranks == 1) return PYN_OK;
+  PYN_CHECK(!c->detached, "detached communicator: no collectives");
   PYN_HIP(hipMemcpyAsync(c->d_scal + 32, inout, n * sizeof(double), hipMemcpyHostToDevice, c->stream));
   PYN_NCCL(ncclAllReduce(c->d_scal + 32, c->d_scal + 32, n, ncclDouble, op == 1 ? ncclMax : ncclSum, c->comm,
                          c->stream));
@@ -215,6 +220,7 @@ __global__ void pack_send_kernel(const double* __restrict__ x, const int32_t* __
 
 int pyn_halo_exchange(pyn_ctx* c, double* x, int bs) {
   if (c->nranks == 1 || c->neigh.empty()) return PYN_OK;
+  if (c->detached) return PYN_OK;  // ghost entries were written by the caller (pyn_vec_set_local_host)
   PYN_CHECK(bs <= 6, "block size too large for the halo buffer");
   if (c->n_send) {
     int64_t tot = c->n_send * bs;
@@ -390,6 +396,15 @@ extern "C" int pyn_vec_set_host(pyn_ctx* c, int id, const double* src) {
   return PYN_OK;
 }
 
+extern "C" int pyn_vec_set_local_host(pyn_ctx* c, int id, const double* src) {
+  PYN_TRY(pyn_check_vec(c, id, "pyn_vec_set_local_host"));
+  PYN_CHECK(src, "src is NULL");
+  DVec& v = c->vecs[id];
+  PYN_HIP(hipMemcpyAsync(v.d, src, (size_t)n_local(c) * v.bs * sizeof(double), hipMemcpyHostToDevice, c->stream));
+  PYN_HIP(hipStreamSynchronize(c->stream));
+  return PYN_OK;
+}
+
 extern "C" int pyn_vec_get_host(pyn_ctx* c, int id, double* dst) {
   PYN_TRY(pyn_check_vec(c, id, "pyn_vec_get_host"));
   PYN_CHECK(dst, "dst is NULL");
@@ -543,7 +558,7 @@ __global__ void __launch_bounds__(256) finish_kernel(const double* __restrict__ 
 
 int pyn_reduce_host(pyn_ctx* c, int nslots, int nblocks, int op, double* out) {
   finish_kernel<<<1, 256, 0, c->stream>>>(c->d_part, nslots, nblocks, op, c->d_scal + 40);
-  if (c->nranks > 1)
+  if (c->nranks > 1 && !c->detached)
     PYN_NCCL(ncclAllReduce(c->d_scal + 40, c->d_scal + 40, nslots, ncclDouble, op == 1 ? ncclMax : ncclSum, c->comm, c->stream));
   PYN_HIP(hipMemcpyAsync(c->h_scal, c->d_scal + 40, nslots * sizeof(double), hipMemcpyDeviceToHost, c->stream));
   PYN_HIP(hipStreamSynchronize(c->stream));

