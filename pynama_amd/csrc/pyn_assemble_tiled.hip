@@ -21,7 +21,7 @@
 namespace {
 
 constexpr int PATCH_MAX_ROWS = 352;   // 7*7*7 = 343 rows -> 74 KB of LDS accumulators at 27 cols
-constexpr int TILE_THREADS = 512;
+constexpr int TILE_THREADS = 256;
 
 __device__ inline int find_slot_t(const int32_t* __restrict__ colidx, int lo, int len, int col) {
   int l = 0, h = len;
@@ -204,8 +204,9 @@ __device__ inline int tri(int a, int b) {  // index of (min,max) in the packed u
   return i * 8 - (i * (i - 1)) / 2 + (j - i);
 }
 
+template <int ABLATE>
 __global__ void __launch_bounds__(TILE_THREADS, 2) assemble_q1_hex_tiled_kernel(TileArgs T) {
-  extern __shared__ __align__(16) double acc[];  // [nrows][maxlen] then per-row meta
+  extern __shared__ __align__(16) double acc[];  // [maxrows][maxlen] accumulators, then per-row meta
   const int p = blockIdx.x;
   const int r_lo = T.p_rowptr[p];
   const int nrows = T.p_rowptr[p + 1] - r_lo;
@@ -213,24 +214,39 @@ __global__ void __launch_bounds__(TILE_THREADS, 2) assemble_q1_hex_tiled_kernel(
   const int ne = T.p_eptr[p + 1] - e_lo;
   const int ml = T.maxlen;
   int* rmeta = reinterpret_cast<int*>(acc + (size_t)T.maxrows * ml);  // [maxrows][2]: csr offset, len | bc<<16
-  for (int i = threadIdx.x; i < nrows * ml; i += TILE_THREADS) acc[i] = 0.0;
-  for (int sl = threadIdx.x; sl < nrows; sl += TILE_THREADS) {
-    const int row = T.p_rows[r_lo + sl];
-    const int lo = T.rowptr[row];
-    const int len = T.rowptr[row + 1] - lo;
-    const int mr = (T.bcmask && T.bcmask[row]) ? 1 : 0;
-    rmeta[2 * sl] = lo;
-    rmeta[2 * sl + 1] = len | (mr << 16) | ((find_slot_t(T.colidx, lo, len, row) & 0xFF) << 20);
+  unsigned* cflag = reinterpret_cast<unsigned*>(rmeta + 2 * T.maxrows);  // [maxrows]: bit k = column k imposed
+  const int tid = threadIdx.x;
+
+  // ---- issue the first dependent loads of every chain before touching LDS (latency overlap)
+  int e_cur = (tid < ne) ? T.p_elem[e_lo + tid] : -1;
+  int row_a = (tid < nrows) ? T.p_rows[r_lo + tid] : -1;
+  int row_b = (tid + TILE_THREADS < nrows) ? T.p_rows[r_lo + tid + TILE_THREADS] : -1;
+  for (int i = tid; i < nrows * ml; i += TILE_THREADS) acc[i] = 0.0;
+  for (int i = tid; i < nrows; i += TILE_THREADS) cflag[i] = 0u;
+  int4 c0 = make_int4(0, 0, 0, 0), c1 = c0;
+  if (e_cur >= 0) {
+    c0 = reinterpret_cast<const int4*>(T.conn)[(int64_t)e_cur * 2];
+    c1 = reinterpret_cast<const int4*>(T.conn)[(int64_t)e_cur * 2 + 1];
+  }
+  if (row_a >= 0) {
+    const int lo = T.rowptr[row_a], hi = T.rowptr[row_a + 1];
+    rmeta[2 * tid] = lo;
+    rmeta[2 * tid + 1] = (hi - lo) | ((T.bcmask && T.bcmask[row_a]) ? (1 << 16) : 0);
+  }
+  if (row_b >= 0) {
+    const int lo = T.rowptr[row_b], hi = T.rowptr[row_b + 1];
+    rmeta[2 * (tid + TILE_THREADS)] = lo;
+    rmeta[2 * (tid + TILE_THREADS) + 1] = (hi - lo) | ((T.bcmask && T.bcmask[row_b]) ? (1 << 16) : 0);
   }
   __syncthreads();
 
   for (int base = 0; base < ne; base += TILE_THREADS) {
-    const int t = base + threadIdx.x;
-    if (t < ne) {
+    const int t = base + tid;
+    // prefetch the next round's element id + connectivity while this round computes
+    const int tn = t + TILE_THREADS;
+    const int e_nxt = (tn < ne) ? T.p_elem[e_lo + tn] : -1;
+    if (e_cur >= 0) {
       const int64_t pe = (int64_t)e_lo + t;
-      const int64_t e = T.p_elem[pe];
-      const int4 c0 = reinterpret_cast<const int4*>(T.conn)[e * 2];
-      const int4 c1 = reinterpret_cast<const int4*>(T.conn)[e * 2 + 1];
       const int nd[8] = {c0.x, c0.y, c0.z, c0.w, c1.x, c1.y, c1.z, c1.w};
       double X[8][3];
 #pragma unroll
@@ -240,60 +256,107 @@ __global__ void __launch_bounds__(TILE_THREADS, 2) assemble_q1_hex_tiled_kernel(
         X[a][1] = q[1];
         X[a][2] = q[2];
       }
+      unsigned bcn = 0;  // bit b = node b imposed
+      if (T.bcmask) {
+#pragma unroll
+        for (int b = 0; b < 8; ++b) bcn |= (T.bcmask[nd[b]] ? 1u : 0u) << b;
+      }
+      const uint4 rs4 = T.rowslot4[pe];
+      uint4 km4[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) km4[j] = T.kmap4[(int64_t)j * T.npe + pe];
+      if (e_nxt >= 0) {
+        c0 = reinterpret_cast<const int4*>(T.conn)[(int64_t)e_nxt * 2];
+        c1 = reinterpret_cast<const int4*>(T.conn)[(int64_t)e_nxt * 2 + 1];
+      }
       double L[36];
 #pragma unroll
       for (int i = 0; i < 36; ++i) L[i] = 0.0;
+      if (ABLATE == 2) {  // no quadrature: keep the loads live
+#pragma unroll
+        for (int i = 0; i < 36; ++i) L[i] = X[i % 8][i % 3];
+      } else {
 #pragma nounroll
-      for (int g = 0; g < 8; ++g) gauss_point(T, g, X, L);
-
-      const uint4 rs4 = T.rowslot4[pe];
+        for (int g = 0; g < 8; ++g) gauss_point(T, g, X, L);
+      }
       const unsigned rsw[4] = {rs4.x, rs4.y, rs4.z, rs4.w};
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
-        const uint4 km4 = T.kmap4[(int64_t)j * T.npe + pe];
-        const unsigned kw[4] = {km4.x, km4.y, km4.z, km4.w};
+        const unsigned kw[4] = {km4[j].x, km4[j].y, km4[j].z, km4[j].w};
 #pragma unroll
         for (int h = 0; h < 2; ++h) {  // rows a = 2j + h
           const int a = 2 * j + h;
           const unsigned slot = (rsw[j] >> (16 * h)) & 0xFFFFu;
           if (slot != 0xFFFFu) {
             double* row = acc + slot * ml;
+            if (bcn) {  // rare (boundary elements): remember which columns of this row are imposed
+              unsigned m = 0;
+#pragma unroll
+              for (int b = 0; b < 8; ++b)
+                if ((bcn >> b) & 1u) m |= 1u << ((kw[2 * h + (b >> 2)] >> (8 * (b & 3))) & 0xFFu);
+              atomicOr(&cflag[slot], m);
+            }
 #pragma unroll
             for (int b = 0; b < 8; ++b) {
               const unsigned k = (kw[2 * h + (b >> 2)] >> (8 * (b & 3))) & 0xFFu;
-              atomicAdd(&row[k], L[tri(a, b)]);
+              if (ABLATE == 1)
+                asm volatile("" ::"v"(L[tri(a, b)]), "v"(k));
+              else
+                atomicAdd(&row[k], L[tri(a, b)]);
             }
           }
         }
       }
+    } else if (e_nxt >= 0) {
+      c0 = reinterpret_cast<const int4*>(T.conn)[(int64_t)e_nxt * 2];
+      c1 = reinterpret_cast<const int4*>(T.conn)[(int64_t)e_nxt * 2 + 1];
     }
+    e_cur = e_nxt;
   }
   __syncthreads();
 
   // ---- write every owned row once: A gets the free columns, Arhs the imposed ones (negated);
-  //      imposed rows become identity rows (mat_generator.py:113-118).  All indices come from LDS
-  //      row meta + one coalesced byte per entry: no dependent gathers in this phase.
-  for (int i = threadIdx.x; i < nrows * ml; i += TILE_THREADS) {
-    const int slot = i / ml, k = i - slot * ml;
-    const int lo = rmeta[2 * slot];
-    const int m1 = rmeta[2 * slot + 1];
-    const int len = m1 & 0xFFFF;
-    if (k >= len) continue;
-    const double v = acc[i];
-    const bool mr = (m1 >> 16) & 1;
-    const bool mc = T.colbc && T.colbc[lo + k];
-    double va, vr;
-    if (mr) {
-      va = vr = (k == ((m1 >> 20) & 0xFF)) ? 1.0 : 0.0;
-    } else if (mc) {
-      va = 0.0;
-      vr = -v;
-    } else {
-      va = v;
-      vr = 0.0;
+  //      imposed rows become identity rows (mat_generator.py:113-118).  Half a wave per row
+  //      (27 of 32 lanes active), rows and per-entry bytes are fetched UNROLL at a time so that
+  //      no store waits on a load it does not need.
+  {
+    double* __restrict__ outA = T.A;
+    double* __restrict__ outR = T.Arhs;
+    const int32_t* __restrict__ colidx = T.colidx;
+    const int half = tid >> 5, k = tid & 31;                  // TILE_THREADS/32 half-waves
+    constexpr int NH = TILE_THREADS / 32, UNROLL = 4;
+    for (int s0 = half; s0 < nrows; s0 += NH * UNROLL) {
+      int lo[UNROLL], m1[UNROLL];
+      unsigned char cb[UNROLL];
+      double v[UNROLL];
+#pragma unroll
+      for (int u = 0; u < UNROLL; ++u) {
+        const int slot = s0 + u * NH;
+        const bool ok = slot < nrows;
+        lo[u] = ok ? rmeta[2 * slot] : 0;
+        m1[u] = ok ? rmeta[2 * slot + 1] : 0;
+        const bool act = k < (m1[u] & 0xFFFF);
+        v[u] = act ? acc[slot * ml + k] : 0.0;
+        cb[u] = act ? ((cflag[slot] >> k) & 1u) : 0;
+        if (act && (m1[u] >> 16)) cb[u] = (colidx[lo[u] + k] == T.p_rows[r_lo + slot]) ? 2 : 3;  // imposed row: diag?
+      }
+#pragma unroll
+      for (int u = 0; u < UNROLL; ++u) {
+        if (k >= (m1[u] & 0xFFFF)) continue;
+        double va, vr;
+        if (m1[u] >> 16) {
+          va = vr = (cb[u] == 2) ? 1.0 : 0.0;
+        } else if (cb[u]) {
+          va = 0.0;
+          vr = -v[u];
+        } else {
+          va = v[u];
+          vr = 0.0;
+        }
+        outA[lo[u] + k] = va;
+        if (outR) outR[lo[u] + k] = vr;
+      }
     }
-    T.A[lo + k] = va;
-    if (T.Arhs) T.Arhs[lo + k] = vr;
   }
 }
 
@@ -401,9 +464,14 @@ extern "C" int pyn_patch_plan_set(pyn_ctx* c, int n_patch, const int32_t* patch_
   c->pl_npe = npe;
   c->pl_maxrows = max_rows;
   c->pl_maxlen = maxlen;
-  size_t lds = (size_t)max_rows * maxlen * sizeof(double) + (size_t)max_rows * 2 * sizeof(int);
+  size_t lds = (size_t)max_rows * maxlen * sizeof(double) + (size_t)max_rows * 3 * sizeof(int);
   PYN_CHECK(lds <= 160 * 1024, "patch accumulators need %zu B of LDS", lds);
-  PYN_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(assemble_q1_hex_tiled_kernel),
+  PYN_CHECK(maxlen <= 32, "rows of %d entries: the tiled kernel handles <= 32 (Q1 hex has 27)", maxlen);
+  PYN_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(assemble_q1_hex_tiled_kernel<0>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  PYN_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(assemble_q1_hex_tiled_kernel<1>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  PYN_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(assemble_q1_hex_tiled_kernel<2>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   return PYN_OK;
 }
@@ -419,15 +487,6 @@ int pyn_assemble_q1_tiled(pyn_ctx* c, int form, double, double, double* K, doubl
   T.colidx = c->d_colidx;
   T.bcmask = c->d_bcmask;
   T.colbc = nullptr;
-  if (c->d_bcmask) {  // per-entry "column imposed" bytes, refreshed when the mask changed
-    if (!c->pl_colbc) PYN_HIP(hipMalloc((void**)&c->pl_colbc, (size_t)c->nnzb));
-    if (c->pl_colbc_stamp != c->bc_stamp) {
-      int g = (int)std::min<int64_t>((c->nnzb + 255) / 256, 65536);
-      colbc_kernel<<<g, 256, 0, c->stream>>>(c->d_colidx, c->d_bcmask, c->nnzb, c->pl_colbc);
-      c->pl_colbc_stamp = c->bc_stamp;
-    }
-    T.colbc = c->pl_colbc;
-  }
   T.p_rowptr = c->pl_rowptr;
   T.p_rows = c->pl_rows;
   T.p_eptr = c->pl_eptr;
@@ -443,8 +502,15 @@ int pyn_assemble_q1_tiled(pyn_ctx* c, int form, double, double, double* K, doubl
   T.hcoo = c->quad[0].HrsCoo;
   T.A = K;
   T.Arhs = Krhs;
-  size_t lds = (size_t)c->pl_maxrows * c->pl_maxlen * sizeof(double) + (size_t)c->pl_maxrows * 2 * sizeof(int);
-  assemble_q1_hex_tiled_kernel<<<c->pl_npatch, TILE_THREADS, lds, c->stream>>>(T);
+  size_t lds = (size_t)c->pl_maxrows * c->pl_maxlen * sizeof(double) + (size_t)c->pl_maxrows * 3 * sizeof(int);
+  const char* ab = getenv("PYNAMA_TILED_ABLATE");  // diagnostics only: 1 = no LDS adds, 2 = no quadrature
+  const int abl = ab ? atoi(ab) : 0;
+  if (abl == 1)
+    assemble_q1_hex_tiled_kernel<1><<<c->pl_npatch, TILE_THREADS, lds, c->stream>>>(T);
+  else if (abl == 2)
+    assemble_q1_hex_tiled_kernel<2><<<c->pl_npatch, TILE_THREADS, lds, c->stream>>>(T);
+  else
+    assemble_q1_hex_tiled_kernel<0><<<c->pl_npatch, TILE_THREADS, lds, c->stream>>>(T);
   PYN_HIP(hipGetLastError());
   *handled = true;
   return PYN_OK;

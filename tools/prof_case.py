@@ -1,0 +1,41 @@
+#!/usr/bin/env python3
+"""Small driver for rocprofv3 counter passes: the bench workload, a few launches of one phase.
+usage: prof_case.py [asm|cg] [nel] [reps]"""
+import os
+import sys
+
+import numpy as np
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from pynama_amd import _lib  # noqa: E402
+from pynama_amd.domain.dmplex import DMPlexDom  # noqa: E402
+from pynama_amd.elements.spectral import Spectral  # noqa: E402
+
+what = sys.argv[1] if len(sys.argv) > 1 else "asm"
+n = int(sys.argv[2]) if len(sys.argv) > 2 else 215
+reps = int(sys.argv[3]) if len(sys.argv) > 3 else 3
+variant = int(os.environ.get("PYNAMA_VARIANT", "1"))
+dom = DMPlexDom(boxMesh={"nelem": [n, n, n], "lower": [0, 0, 0], "upper": [1, 1, 1]},
+                jitter=float(os.environ.get("PYNAMA_JITTER", "0")))
+dom.setFemIndexing(2)
+ctx = dom.ctx
+for t in Spectral(2, 3).deviceTables():
+    ctx.tables_set(*t)
+bm = dom.boundaryMaskLocal()
+ctx.bc_set(1, bm)
+ctx.csr_symbolic()
+if variant == 1:
+    tile = tuple(int(v) for v in os.environ.get("PYNAMA_TILE", "7,7,7").split(","))
+    ctx.patch_plan_set(*dom.patchPlan(tile))
+A = ctx.mat_create(1, 1)
+for _ in range(reps if what == "asm" else 1):
+    ctx.assemble_scalar(_lib.FORM_LAPLACE, A, -1, variant=variant)
+    print("assemble_ms", ctx.timers()["assemble_ms"])
+if what == "cg":
+    vb, vx = ctx.vec_create(1), ctx.vec_create(1)
+    b = np.random.default_rng(0).standard_normal(dom.nOwned)
+    b[bm != 0] = 0
+    ctx.vec_set(vb, b)
+    info = ctx.solve(A, vb, vx, fixed_iters=reps * 10, profile=1)
+    print("cg ms/iter", info.solve_ms / info.iters, "spmv_ms", info.spmv_ms)
+ctx.close()
