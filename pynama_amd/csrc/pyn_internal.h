@@ -118,6 +118,9 @@ struct pyn_ctx {
   int32_t* sell_col = nullptr;
   int64_t sell_total = 0, sell_ns = 0;
   int sell_maxw = 0;
+  int32_t* sell_pid = nullptr;   // per-row column-pattern id (dictionary mode), else null
+  int32_t* sell_tab = nullptr;   // [npat][32] relative column offsets
+  int sell_npat = 0;
 
   std::vector<DMat> mats;
   std::vector<DVec> vecs;

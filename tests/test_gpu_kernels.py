@@ -347,3 +347,35 @@ def test_rank_slabs_assembly_and_spmv(lib, size, variant):
         with pytest.raises(lib.PynamaHipError):
             ctx.solve(A, vx, vy)
         ctx.close()
+
+
+def test_random_node_numbering_falls_back_to_explicit_columns(lib):
+    """irregular indexing: with randomly permuted node ids the column-pattern dictionary does not
+    apply (thousands of patterns) and the SpMV/CG path uses explicit column indices; results still
+    match the oracle on the permuted mesh"""
+    mesh = fo.box_mesh([9, 8, 7], [0, 0, 0], [1, 1, 1], 2, jitter=0.2)
+    rng = np.random.default_rng(4242)
+    perm = rng.permutation(mesh.n_node)                 # old id -> new id
+    inv = np.argsort(perm)
+    mesh.conn = perm[mesh.conn].astype(np.int32)
+    mesh.xyz = mesh.xyz[inv]
+    mesh.boundary = np.sort(perm[mesh.boundary])
+    ctx = make_ctx(lib, mesh, 2, bc_ndof=1, bc_nodes=mesh.boundary)
+    rp, ci = ctx.csr_get()
+    rp_o, ci_o = fo.node_graph(mesh)
+    assert np.array_equal(rp, rp_o) and np.array_equal(ci, ci_o)
+    A = ctx.mat_create(1, 1)
+    ctx.assemble_scalar(lib.FORM_LAPLACE, A)
+    ref = fo.assemble_scalar(mesh, fo.Tables(2, 3), "laplace", dirichlet=mesh.boundary)
+    S = mat_to_scipy(ctx, A, 1, 1)
+    assert sp_rel_err(S, ref["A"]) < FP_TOL
+    b = rng.standard_normal(mesh.n_node)
+    b[mesh.boundary] = 0
+    vb, vx, vy = ctx.vec_create(1), ctx.vec_create(1), ctx.vec_create(1)
+    ctx.vec_set(vb, b)
+    ctx.spmv(A, vb, vy)
+    assert rel_err(ctx.vec_get(vy, 1), ref["A"] @ b) < 1e-13
+    info = ctx.solve(A, vb, vx, rtol=1e-10, norm_type=lib.NORM_UNPRECONDITIONED)
+    x_o, it_o, _ = fo.pcg(ref["A"], b, rtol=1e-10, norm_type=fo.NORM_UNPRECONDITIONED)
+    assert info.reason == 2 and abs(info.iters - it_o) <= 1 and rel_err(ctx.vec_get(vx, 1), x_o) < 1e-8
+    ctx.close()
