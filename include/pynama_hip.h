@@ -173,6 +173,7 @@ typedef struct pyn_solve_opts {
   int restart;       /* GMRES(m), PETSc default 30 */
   int fixed_iters;   /* >0: run exactly this many iterations, no convergence exit (benchmarking) */
   int profile;       /* !=0: bracket every SpMV launch with HIP events (first 256 iterations) */
+  int cg_variant;    /* 0 auto, 1 standard PCG, 2 single-reduction PCG (Chronopoulos-Gear; default for nranks>1) */
   double rtol, atol, dtol;   /* PETSc defaults 1e-5, 1e-50, 1e5 */
 } pyn_solve_opts;
 typedef struct pyn_solve_info {

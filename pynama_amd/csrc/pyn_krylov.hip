@@ -228,6 +228,156 @@ __global__ void cg_scalar_beta_kernel(double* scal, int* flag, int norm_type, in
   }
 }
 
+
+// ---- single-reduction CG (Chronopoulos-Gear): one reduction point per iteration -----------------
+//   u = M^-1 r, w = A u, gamma = (r,u), delta = (w,u)
+//   beta = gamma/gamma_old, alpha = gamma / (delta - beta*gamma/alpha_old)
+//   p = u + beta p ; s = w + beta s ; x += alpha p ; r -= alpha s
+// Same iterates as standard PCG in exact arithmetic; 3-4 launches and ONE all-reduce (3 doubles) per
+// iteration instead of 7 launches and two all-reduces: the variant used when nranks > 1.
+enum { S_GOLD = 10, S_AOLD = 11 };
+
+__global__ void __launch_bounds__(256) cgsr_init_kernel(const double* __restrict__ b, const double* __restrict__ dinv,
+                                                        double* __restrict__ x, double* __restrict__ r, double* __restrict__ u,
+                                                        double* __restrict__ p, double* __restrict__ sv, int64_t n,
+                                                        int norm_type, double* __restrict__ part) {
+  double g = 0.0, nn = 0.0;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    double ri = b[i];
+    double ui = dinv ? dinv[i] * ri : ri;
+    x[i] = 0.0;
+    r[i] = ri;
+    u[i] = ui;
+    p[i] = 0.0;
+    sv[i] = 0.0;
+    g += ri * ui;
+    nn += norm_type == PYN_NORM_PRECONDITIONED ? ui * ui : ri * ri;
+  }
+  block_partial(g, part + PYN_MAX_PARTIALS);
+  __syncthreads();
+  block_partial(nn, part + 2 * PYN_MAX_PARTIALS);
+}
+
+__global__ void __launch_bounds__(256) cgsr_update_kernel(const double* __restrict__ scal, const int* __restrict__ flag,
+                                                          const double* __restrict__ dinv, const double* __restrict__ w,
+                                                          double* __restrict__ u, double* __restrict__ p,
+                                                          double* __restrict__ sv, double* __restrict__ x,
+                                                          double* __restrict__ r, int64_t n, int norm_type,
+                                                          double* __restrict__ part) {
+  if (flag[F_DONE]) return;
+  const double alpha = scal[S_ALPHA], beta = scal[S_BETA];
+  double g = 0.0, nn = 0.0;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    const double pi = u[i] + beta * p[i];
+    const double si = w[i] + beta * sv[i];
+    p[i] = pi;
+    sv[i] = si;
+    x[i] += alpha * pi;
+    const double ri = r[i] - alpha * si;
+    r[i] = ri;
+    const double ui = dinv ? dinv[i] * ri : ri;
+    u[i] = ui;
+    g += ri * ui;
+    nn += norm_type == PYN_NORM_PRECONDITIONED ? ui * ui : ri * ri;
+  }
+  block_partial(g, part + PYN_MAX_PARTIALS);
+  __syncthreads();
+  block_partial(nn, part + 2 * PYN_MAX_PARTIALS);
+}
+
+// one block: tmp[0] = sum part[0][0..n0) (delta), tmp[1..2] = sums of part[1..2][0..n1) (gamma, norm^2);
+// with FUSE (single rank) the scalar step follows in the same launch
+__device__ inline void cgsr_scalar_step(double* scal, int* flag, int norm_type, int maxit, int check, double* hist,
+                                        int hist_cap, int first) {
+  const double delta = scal[S_TMP0], gamma = scal[S_TMP0 + 1], nn = scal[S_TMP0 + 2];
+  const double rn = norm_type == PYN_NORM_NATURAL ? sqrt(fabs(gamma)) : sqrt(nn);
+  if (first) {
+    scal[S_RNORM0] = rn;
+    const double ttol = fmax(scal[S_TTOL] * rn, scal[S_ATOL]);  // S_TTOL holds rtol until now
+    scal[S_TTOL] = ttol;
+    scal[S_DLIM] = scal[S_DLIM] * rn;                          // held dtol
+    if (hist) hist[0] = rn;
+  } else {
+    const int it = flag[F_ITERS] + 1;
+    flag[F_ITERS] = it;
+    if (hist && it < hist_cap) hist[it] = rn;
+  }
+  scal[S_RNORM] = rn;
+  const int it = flag[F_ITERS];
+  if (!(rn == rn)) {
+    flag[F_DONE] = 1;
+    flag[F_REASON] = PYN_DIVERGED_NANORINF;
+    return;
+  }
+  if (check) {
+    if (rn <= scal[S_TTOL]) {
+      flag[F_DONE] = 1;
+      flag[F_REASON] = rn <= scal[S_ATOL] ? PYN_CONVERGED_ATOL : PYN_CONVERGED_RTOL;
+      return;
+    }
+    if (!first && rn >= scal[S_DLIM]) {
+      flag[F_DONE] = 1;
+      flag[F_REASON] = PYN_DIVERGED_DTOL;
+      return;
+    }
+  }
+  if (it >= maxit) {
+    flag[F_DONE] = 1;
+    flag[F_REASON] = check ? PYN_DIVERGED_ITS : PYN_CONVERGED_ITS;
+    return;
+  }
+  double beta = 0.0, alpha;
+  if (first) {
+    alpha = gamma / delta;
+  } else {
+    beta = gamma / scal[S_GOLD];
+    alpha = gamma / (delta - beta * gamma / scal[S_AOLD]);
+  }
+  if (!(delta > 0.0) || !(alpha == alpha)) {
+    flag[F_DONE] = 1;
+    flag[F_REASON] = PYN_DIVERGED_BREAKDOWN;
+    return;
+  }
+  scal[S_GOLD] = gamma;
+  scal[S_AOLD] = alpha;
+  scal[S_ALPHA] = alpha;
+  scal[S_BETA] = beta;
+}
+
+template <bool FUSE>
+__global__ void __launch_bounds__(256) cgsr_reduce_kernel(const double* __restrict__ part, int n0, int n1, double* scal,
+                                                          int* flag, int norm_type, int maxit, int check, double* hist,
+                                                          int hist_cap, int first) {
+  if (flag[F_DONE]) return;
+  __shared__ double sm[4];
+  for (int sl = 0; sl < 3; ++sl) {
+    const int nb = sl == 0 ? n0 : n1;
+    double acc = 0.0;
+    for (int i = threadIdx.x; i < nb; i += 256) acc += part[sl * PYN_MAX_PARTIALS + i];
+    acc = wsum(acc);
+    if ((threadIdx.x & 63) == 0) sm[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) scal[S_TMP0 + sl] = sm[0] + sm[1] + sm[2] + sm[3];
+    __syncthreads();
+  }
+  if (FUSE && threadIdx.x == 0) cgsr_scalar_step(scal, flag, norm_type, maxit, check, hist, hist_cap, first);
+}
+
+__global__ void cgsr_scalar_kernel(double* scal, int* flag, int norm_type, int maxit, int check, double* hist, int hist_cap,
+                                   int first) {
+  if (flag[F_DONE]) return;
+  cgsr_scalar_step(scal, flag, norm_type, maxit, check, hist, hist_cap, first);
+}
+
+__global__ void cgsr_setup_kernel(double* scal, int* flag, double rtol, double atol, double dtol) {
+  scal[S_TTOL] = rtol;
+  scal[S_ATOL] = atol;
+  scal[S_DLIM] = dtol;
+  flag[F_DONE] = 0;
+  flag[F_ITERS] = 0;
+  flag[F_REASON] = 0;
+}
+
 // generic helpers on raw device pointers (GMRES, residual check)
 __global__ void __launch_bounds__(256) dot2_kernel(const double* __restrict__ x, const double* __restrict__ y, int64_t n,
                                                    double* __restrict__ part) {
@@ -447,6 +597,95 @@ static int solve_cg(pyn_ctx* c, DMat& A, const double* b, double* x, const pyn_s
   return PYN_OK;
 }
 
+static int solve_cg_sr(pyn_ctx* c, DMat& A, const double* b, double* x, const pyn_solve_opts& o, pyn_solve_info* info) {
+  const bool sell = A.br == 1 && A.bc == 1;
+  if (sell) PYN_TRY(pyn_sell_ensure(c, A));
+  const int64_t n = c->n_owned * A.br;
+  const int64_t nl = n_local(c) * A.br;
+  const int hist_cap = 4096;
+  // work: r[n] u[nl] w[n] p[n] s[n] dinv[n] hist
+  PYN_TRY(pyn_ensure_work(c, (size_t)(5 * n + nl + hist_cap) * sizeof(double)));
+  double* r = c->d_work;
+  double* u = r + n;
+  double* w = u + nl;
+  double* p = w + n;
+  double* sv = p + n;
+  double* dinv = sv + n;
+  double* hist = dinv + n;
+  const bool jac = o.pc == PYN_PC_JACOBI;
+  if (jac) PYN_TRY(pyn_extract_diag_inv(c, A, dinv, true));
+  const double* dv = jac ? dinv : nullptr;
+  const int g = vgrid(n);
+  const int64_t rows = n;
+  const int gs = (int)std::max<int64_t>(1, std::min<int64_t>((rows * 32 + 255) / 256, PYN_MAX_PARTIALS));
+  hipStream_t s = c->stream;
+  const int maxit = o.fixed_iters > 0 ? o.fixed_iters : o.maxit;
+  const int check = o.fixed_iters > 0 ? 0 : 1;
+  const bool multi = c->nranks > 1;
+
+  cgsr_setup_kernel<<<1, 1, 0, s>>>(c->d_scal, c->d_flag, check ? o.rtol : 0.0, check ? o.atol : 0.0, o.dtol);
+  cgsr_init_kernel<<<g, 256, 0, s>>>(b, dv, x, r, u, p, sv, n, o.norm_type, c->d_part);
+  PYN_HIP(hipEventRecord(c->ev0, s));
+  const int prof_max = o.profile ? 256 : 0;
+  while ((int)c->prof_ev.size() < 2 * prof_max) {
+    hipEvent_t e;
+    PYN_HIP(hipEventCreate(&e));
+    c->prof_ev.push_back(e);
+  }
+  int prof_n = 0, issued = 0, done = 0;
+  const int chunk = 32;
+  // iteration k: w = A u_k ; scalars (tests ||r_k||, alpha_k, beta_k) ; update -> r_{k+1}, u_{k+1}
+  while (!done && issued <= maxit) {
+    const int todo = std::min(chunk, maxit + 1 - issued);
+    for (int k = 0; k < todo; ++k) {
+      PYN_TRY(pyn_halo_exchange(c, u, A.bc));
+      const bool prof = prof_n < prof_max;
+      if (prof) PYN_HIP(hipEventRecord(c->prof_ev[2 * prof_n], s));
+      int gsp = gs;
+      if (sell)
+        PYN_TRY(pyn_sell_spmv(c, A, u, w, true, &gsp));
+      else
+        spmv_kernel<32, true><<<gs, 256, 0, s>>>(c->d_rowptr, c->d_colidx, A.val, u, w, rows, A.br, A.bc, c->d_flag, c->d_part);
+      if (prof) PYN_HIP(hipEventRecord(c->prof_ev[2 * prof_n++ + 1], s));
+      const int first = (issued + k) == 0;
+      if (multi) {
+        cgsr_reduce_kernel<false><<<1, 256, 0, s>>>(c->d_part, gsp, g, c->d_scal, c->d_flag, o.norm_type, maxit, check, hist, hist_cap, first);
+        PYN_TRY(allreduce_tmp(c, 3));
+        cgsr_scalar_kernel<<<1, 1, 0, s>>>(c->d_scal, c->d_flag, o.norm_type, maxit, check, hist, hist_cap, first);
+      } else {
+        cgsr_reduce_kernel<true><<<1, 256, 0, s>>>(c->d_part, gsp, g, c->d_scal, c->d_flag, o.norm_type, maxit, check, hist, hist_cap, first);
+      }
+      cgsr_update_kernel<<<g, 256, 0, s>>>(c->d_scal, c->d_flag, dv, w, u, p, sv, x, r, n, o.norm_type, c->d_part);
+    }
+    issued += todo;
+    PYN_HIP(hipMemcpyAsync(c->h_flag, c->d_flag, 8 * sizeof(int), hipMemcpyDeviceToHost, s));
+    PYN_HIP(hipStreamSynchronize(s));
+    done = c->h_flag[F_DONE];
+  }
+  PYN_HIP(hipEventRecord(c->ev1, s));
+  PYN_HIP(hipMemcpyAsync(c->h_flag, c->d_flag, 8 * sizeof(int), hipMemcpyDeviceToHost, s));
+  PYN_HIP(hipMemcpyAsync(c->h_scal, c->d_scal, 16 * sizeof(double), hipMemcpyDeviceToHost, s));
+  PYN_HIP(hipStreamSynchronize(s));
+  float ms = 0;
+  PYN_HIP(hipEventElapsedTime(&ms, c->ev0, c->ev1));
+  info->solve_ms = ms;
+  if (prof_n) {
+    double acc = 0;
+    for (int k = 0; k < prof_n; ++k) {
+      float t = 0;
+      PYN_HIP(hipEventElapsedTime(&t, c->prof_ev[2 * k], c->prof_ev[2 * k + 1]));
+      acc += t;
+    }
+    info->spmv_ms = acc / prof_n;
+    info->spmv_launches = prof_n;
+  }
+  info->iters = c->h_flag[F_ITERS];
+  info->reason = c->h_flag[F_REASON] ? c->h_flag[F_REASON] : PYN_DIVERGED_ITS;
+  info->rnorm = c->h_scal[S_RNORM];
+  info->rnorm0 = c->h_scal[S_RNORM0];
+  return PYN_OK;
+}
+
 // Left-preconditioned restarted GMRES(m), modified Gram-Schmidt, Givens rotations on the host.
 static int solve_gmres(pyn_ctx* c, const DMat& A, const double* b, double* x, const pyn_solve_opts& o, pyn_solve_info* info) {
   const int64_t n = c->n_owned * A.br;
@@ -564,8 +803,15 @@ extern "C" int pyn_solve(pyn_ctx* c, int mat_id, int bv, int xv, const pyn_solve
   double* b = c->vecs[bv].d;
   double* x = c->vecs[xv].d;
   *info = pyn_solve_info();
-  if (opts->method == PYN_KSP_CG)
-    PYN_TRY(solve_cg(c, A, b, x, *opts, info));
+  if (opts->method == PYN_KSP_CG) {
+    // cg_variant: 0 auto (standard on one GPU, single-reduction across ranks), 1 standard, 2 single-reduction
+    const int v = opts->cg_variant ? opts->cg_variant : (c->nranks > 1 ? 2 : 1);
+    PYN_CHECK(v == 1 || v == 2, "cg_variant must be 0, 1 or 2");
+    if (v == 2)
+      PYN_TRY(solve_cg_sr(c, A, b, x, *opts, info));
+    else
+      PYN_TRY(solve_cg(c, A, b, x, *opts, info));
+  }
   else
     PYN_TRY(solve_gmres(c, A, b, x, *opts, info));
   c->timers[PYN_T_SOLVE] = info->solve_ms;

@@ -236,11 +236,13 @@ def _poisson(lib, nelem, jitter=0.1):
     return mesh, ctx, A, vb, vx, b
 
 
+@pytest.mark.parametrize("variant", [1, 2])
 @pytest.mark.parametrize("norm", [0, 1, 2])
-def test_cg_matches_oracle_iterates(lib, norm):
+def test_cg_matches_oracle_iterates(lib, norm, variant):
+    """variant 1 = standard PCG, 2 = single-reduction (Chronopoulos-Gear) PCG used across ranks"""
     mesh, ctx, A, vb, vx, b = _poisson(lib, [12, 10, 8])
     S = mat_to_scipy(ctx, A, 1, 1)
-    info = ctx.solve(A, vb, vx, method=lib.KSP_CG, pc=lib.PC_JACOBI, rtol=1e-10, norm_type=norm)
+    info = ctx.solve(A, vb, vx, method=lib.KSP_CG, pc=lib.PC_JACOBI, rtol=1e-10, norm_type=norm, cg_variant=variant)
     x_o, it_o, hist = fo.pcg(S, b, rtol=1e-10, norm_type=norm)
     assert info.reason == 2
     assert abs(info.iters - it_o) <= 1
@@ -262,17 +264,22 @@ def test_cg_poisson_exact_solution(lib):
     ctx.close()
 
 
-def test_cg_zero_rhs_and_maxit(lib):
+@pytest.mark.parametrize("variant", [1, 2])
+def test_cg_zero_rhs_and_maxit(lib, variant):
     mesh, ctx, A, vb, vx, b = _poisson(lib, [6, 6, 6])
     ctx.vec_fill(vb, 0.0)
-    info = ctx.solve(A, vb, vx)
+    info = ctx.solve(A, vb, vx, cg_variant=variant)
     assert info.iters == 0 and info.reason in (2, 3)
     assert np.all(ctx.vec_get(vx, 1) == 0.0)
     ctx.vec_set(vb, b)
-    info = ctx.solve(A, vb, vx, rtol=1e-14, maxit=3)
+    info = ctx.solve(A, vb, vx, rtol=1e-14, maxit=3, cg_variant=variant)
     assert info.iters == 3 and info.reason == -3
-    info = ctx.solve(A, vb, vx, fixed_iters=7)
-    assert info.iters == 7 and info.reason == 4
+    x3 = ctx.vec_get(vx, 1)
+    info = ctx.solve(A, vb, vx, fixed_iters=3, cg_variant=variant)
+    assert info.iters == 3 and info.reason == 4
+    assert rel_err(ctx.vec_get(vx, 1), x3) < 1e-12          # same 3 iterates either way
+    x_o, _, _ = fo.pcg(mat_to_scipy(ctx, A, 1, 1), b, rtol=1e-30, maxit=3)
+    assert rel_err(x3, x_o) < 1e-10
     ctx.close()
 
 

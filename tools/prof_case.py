@@ -36,6 +36,6 @@ if what == "cg":
     b = np.random.default_rng(0).standard_normal(dom.nOwned)
     b[bm != 0] = 0
     ctx.vec_set(vb, b)
-    info = ctx.solve(A, vb, vx, fixed_iters=reps * 10, profile=1)
+    info = ctx.solve(A, vb, vx, fixed_iters=reps * 10, profile=1, cg_variant=int(os.environ.get('PYNAMA_CG_VARIANT', '0')))
     print("cg ms/iter", info.solve_ms / info.iters, "spmv_ms", info.spmv_ms)
 ctx.close()
