@@ -185,7 +185,7 @@ def main():
             "config": {"workload": f"3D Poisson, {n}^3 Q1 hex elements, {n_node_global} DOFs, nnz {nnz_global}, "
                                    f"FP64 assembly + Jacobi-PCG ({args.cg_iters} its/step)",
                        "partition": f"z-slabs x{world.size}", "assembly_variant": args.variant},
-            "roofline": {"kernel": "spmv_kernel (CSR SpMV inside CG)", "bound": "hbm", "achieved": spmv_gbs,
+            "roofline": {"kernel": "sellp_spmv_kernel (SELL-64 + column-pattern dictionary SpMV inside CG)", "bound": "hbm", "achieved": spmv_gbs,
                          "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": spmv_gbs / HBM_PEAK_GBS, "traffic": None,
                          "algorithmic_bytes_per_launch": B_spmv * share},
             "roofline_assembly": {"kernel": "assembly (zero + quadrature + scatter)", "bound": "hbm",

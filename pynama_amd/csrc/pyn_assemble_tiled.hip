@@ -140,6 +140,7 @@ struct TileArgs {
   const double* w;      // full rule [8]
   const double* hrs;    // [8][3][8]  reference gradients of the nodal basis at the Gauss points
   const double* hcoo;   // [8][3][8]  reference gradients of the geometry (corner) basis
+  const double* aff;    // [6][36] affine reference matrices + [4][8] monomial signs (null: shortcut off)
   double* A;            // values for free columns
   double* Arhs;         // -values for imposed columns (may be null)
 };
@@ -196,6 +197,73 @@ __device__ __forceinline__ void gauss_point(const TileArgs& T, const int G, cons
       s = fma(g2, Gm[2][b], s);
       L[idx++] = s;
     }
+  }
+}
+
+// Affine shortcut: for a parallelepiped J is constant and the 2x2x2 rule integrates the (quadratic)
+// integrand exactly, so L_ab = detJ * sum_{r<=s} Q_rs T_rs[ab] with Q = J^-T J^-1 -- ~350 instead of
+// ~2500 FP64 operations.  `affine` is decided per element from the non-affine trilinear modes.
+__device__ __forceinline__ bool element_is_affine(const TileArgs& T, const double (&X)[8][3]) {
+  const double* __restrict__ sg = T.aff + 216;
+  double na = 0.0, h2 = 0.0;
+#pragma unroll
+  for (int m = 0; m < 4; ++m)
+#pragma unroll
+    for (int x = 0; x < 3; ++x) {
+      double c = 0.0;
+#pragma unroll
+      for (int a = 0; a < 8; ++a) c = fma(sg[m * 8 + a], X[a][x], c);
+      na = fma(c, c, na);
+    }
+#pragma unroll
+  for (int x = 0; x < 3; ++x) {  // squared edge scale: (x_6 - x_0) carries all three affine modes
+    const double d = X[6][x] - X[0][x];
+    h2 = fma(d, d, h2);
+  }
+  return na <= 1e-25 * h2;  // non-affine modes below ~3e-13 of the element size: coordinate round-off
+}
+
+__device__ __forceinline__ void affine_laplace(const TileArgs& T, const double (&X)[8][3], double (&L)[36]) {
+  const double* __restrict__ hc = T.hcoo;  // any Gauss point: J is constant
+  double J[3][3];
+#pragma unroll
+  for (int d = 0; d < 3; ++d)
+#pragma unroll
+    for (int x = 0; x < 3; ++x) {
+      double s = 0.0;
+#pragma unroll
+      for (int c = 0; c < 8; ++c) s = fma(hc[d * 8 + c], X[c][x], s);
+      J[d][x] = s;
+    }
+  const double c00 = J[1][1] * J[2][2] - J[1][2] * J[2][1];
+  const double c01 = J[1][2] * J[2][0] - J[1][0] * J[2][2];
+  const double c02 = J[1][0] * J[2][1] - J[1][1] * J[2][0];
+  const double det = J[0][0] * c00 + J[0][1] * c01 + J[0][2] * c02;
+  const double r = 1.0 / det;
+  double Ji[3][3];  // Ji[x][d]: physical axis x, reference axis d   (G = Ji . hr)
+  Ji[0][0] = c00 * r;
+  Ji[0][1] = (J[0][2] * J[2][1] - J[0][1] * J[2][2]) * r;
+  Ji[0][2] = (J[0][1] * J[1][2] - J[0][2] * J[1][1]) * r;
+  Ji[1][0] = c01 * r;
+  Ji[1][1] = (J[0][0] * J[2][2] - J[0][2] * J[2][0]) * r;
+  Ji[1][2] = (J[0][2] * J[1][0] - J[0][0] * J[1][2]) * r;
+  Ji[2][0] = c02 * r;
+  Ji[2][1] = (J[0][1] * J[2][0] - J[0][0] * J[2][1]) * r;
+  Ji[2][2] = (J[0][0] * J[1][1] - J[0][1] * J[1][0]) * r;
+  double Q[6];
+  const int RS[6][2] = {{0, 0}, {1, 1}, {2, 2}, {0, 1}, {0, 2}, {1, 2}};
+#pragma unroll
+  for (int t = 0; t < 6; ++t) {
+    const int a = RS[t][0], b = RS[t][1];
+    Q[t] = det * (Ji[0][a] * Ji[0][b] + Ji[1][a] * Ji[1][b] + Ji[2][a] * Ji[2][b]);
+  }
+  const double* __restrict__ Tm = T.aff;
+#pragma unroll
+  for (int i = 0; i < 36; ++i) {
+    double s = Q[0] * Tm[i];
+#pragma unroll
+    for (int t = 1; t < 6; ++t) s = fma(Q[t], Tm[t * 36 + i], s);
+    L[i] = s;
   }
 }
 
@@ -275,6 +343,8 @@ __global__ void __launch_bounds__(TILE_THREADS, 2) assemble_q1_hex_tiled_kernel(
       if (ABLATE == 2) {  // no quadrature: keep the loads live
 #pragma unroll
         for (int i = 0; i < 36; ++i) L[i] = X[i % 8][i % 3];
+      } else if (T.aff && __all(element_is_affine(T, X) ? 1 : 0)) {
+        affine_laplace(T, X, L);  // whole wave on parallelepipeds (uniform box meshes)
       } else {
 #pragma nounroll
         for (int g = 0; g < 8; ++g) gauss_point(T, g, X, L);
@@ -500,6 +570,7 @@ int pyn_assemble_q1_tiled(pyn_ctx* c, int form, double, double, double* K, doubl
   T.w = c->quad[0].w;
   T.hrs = c->quad[0].Hrs;
   T.hcoo = c->quad[0].HrsCoo;
+  T.aff = getenv("PYNAMA_NO_AFFINE") ? nullptr : c->d_aff;
   T.A = K;
   T.Arhs = Krhs;
   size_t lds = (size_t)c->pl_maxrows * c->pl_maxlen * sizeof(double) + (size_t)c->pl_maxrows * 3 * sizeof(int);

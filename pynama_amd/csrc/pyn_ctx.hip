@@ -95,6 +95,7 @@ extern "C" int pyn_ctx_destroy(pyn_ctx* c) {
   for (auto& q : c->quad) free_quad(q);
   (void)hipFree(c->d_conn);
   (void)hipFree(c->d_xyz);
+  (void)hipFree(c->d_aff);
   (void)hipFree(c->d_bcmask);
   (void)hipFree(c->d_rowptr);
   (void)hipFree(c->d_colidx);
@@ -291,6 +292,37 @@ extern "C" int pyn_elem_tables_set(pyn_ctx* c, int which, int ngp, const double*
   PYN_TRY(dev_upload(&q.H, H, (size_t)ngp * c->nn, c->stream));
   PYN_TRY(dev_upload(&q.Hrs, Hrs, (size_t)ngp * c->dim * c->nn, c->stream));
   PYN_TRY(dev_upload(&q.HrsCoo, HrsCoo, (size_t)ngp * c->dim * c->nc, c->stream));
+  if (which == PYN_Q_FULL && c->dim == 3 && c->nn == 8 && ngp == 8) {
+    // Tables of the affine shortcut of the tiled Q1-hex kernel (exact for parallelepipeds, where
+    // J is constant):  L_ab = detJ * sum_{r<=s} Q_rs T_rs[ab],  Q = J^-T J^-1 (reference axes),
+    // T_rr = sum_g w hr[r][a] hr[r][b],  T_rs = sum_g w (hr[r][a] hr[s][b] + hr[s][a] hr[r][b]).
+    double aff[6 * 36 + 4 * 8];
+    const int RS[6][2] = {{0, 0}, {1, 1}, {2, 2}, {0, 1}, {0, 2}, {1, 2}};
+    for (int t = 0; t < 6; ++t) {
+      const int r = RS[t][0], s2 = RS[t][1];
+      int idx = 0;
+      for (int a = 0; a < 8; ++a)
+        for (int b = a; b < 8; ++b) {
+          double acc = 0.0;
+          for (int g = 0; g < 8; ++g) {
+            const double* hr = Hrs + (size_t)g * 24;
+            acc += w[g] * (r == s2 ? hr[r * 8 + a] * hr[r * 8 + b] : hr[r * 8 + a] * hr[s2 * 8 + b] + hr[s2 * 8 + a] * hr[r * 8 + b]);
+          }
+          aff[t * 36 + idx++] = acc;
+        }
+    }
+    // signs of the non-affine trilinear monomials rs, rt, st, rst at the corners (reference
+    // coordinates of corner a = sign of dN_a/d(axis) anywhere inside the element)
+    for (int a = 0; a < 8; ++a) {
+      const double xr = HrsCoo[0 * 8 + a] > 0 ? 1.0 : -1.0, xs = HrsCoo[1 * 8 + a] > 0 ? 1.0 : -1.0,
+                   xt = HrsCoo[2 * 8 + a] > 0 ? 1.0 : -1.0;
+      aff[216 + 0 * 8 + a] = xr * xs;
+      aff[216 + 1 * 8 + a] = xr * xt;
+      aff[216 + 2 * 8 + a] = xs * xt;
+      aff[216 + 3 * 8 + a] = xr * xs * xt;
+    }
+    PYN_TRY(dev_upload(&c->d_aff, aff, (size_t)(6 * 36 + 32), c->stream));
+  }
   PYN_HIP(hipStreamSynchronize(c->stream));
   return PYN_OK;
 }

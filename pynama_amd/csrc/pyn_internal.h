@@ -93,6 +93,7 @@ struct pyn_ctx {
   int32_t* d_conn = nullptr;
   double* d_xyz = nullptr;
   QuadTab quad[3];
+  double* d_aff = nullptr;  // Q1-hex affine tables: [6][36] reference matrices + [4][8] non-affine monomial signs
 
   // boundary condition
   int bc_ndof = 0;

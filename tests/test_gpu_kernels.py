@@ -386,3 +386,28 @@ def test_random_node_numbering_falls_back_to_explicit_columns(lib):
     x_o, it_o, _ = fo.pcg(ref["A"], b, rtol=1e-10, norm_type=fo.NORM_UNPRECONDITIONED)
     assert info.reason == 2 and abs(info.iters - it_o) <= 1 and rel_err(ctx.vec_get(vx, 1), x_o) < 1e-8
     ctx.close()
+
+
+@pytest.mark.parametrize("kind", ["uniform", "sheared", "mixed"])
+def test_assemble_tiled_affine_shortcut(lib, kind):
+    """parallelepiped elements take the affine shortcut of the tiled kernel (constant Jacobian,
+    precomputed reference matrices); 'mixed' jitters only the upper half of the box so that whole-wave
+    affine and general quadrature paths coexist in one launch.  All equal the oracle's 8-point rule."""
+    mesh = fo.box_mesh([14, 9, 16], [0, 0, 0], [1.0, 0.7, 1.3], 2)
+    if kind == "sheared":
+        M = np.array([[1.0, 0.3, -0.2], [0.1, 0.9, 0.25], [-0.15, 0.2, 1.1]])
+        mesh.xyz = mesh.xyz @ M.T + np.array([0.5, -1.0, 2.0])
+    if kind == "mixed":
+        rng = np.random.default_rng(8)
+        mv = 0.15 * (1.0 / 16) * rng.uniform(-1, 1, size=mesh.xyz.shape)
+        mv[mesh.xyz[:, 2] < 0.65] = 0.0
+        mv[mesh.boundary] = 0.0
+        mesh.xyz = mesh.xyz + mv
+    ref = fo.assemble_scalar(mesh, fo.Tables(2, 3), "laplace", dirichlet=mesh.boundary)
+    ctx = make_ctx(lib, mesh, 2, bc_ndof=1, bc_nodes=mesh.boundary)
+    ctx.patch_plan_set(*tile_plan(mesh))
+    A, Arhs = ctx.mat_create(1, 1), ctx.mat_create(1, 1)
+    ctx.assemble_scalar(lib.FORM_LAPLACE, A, Arhs, variant=1)
+    assert sp_rel_err(mat_to_scipy(ctx, A, 1, 1), ref["A"]) < FP_TOL
+    assert sp_rel_err(mat_to_scipy(ctx, Arhs, 1, 1), ref["Arhs"]) < FP_TOL
+    ctx.close()
