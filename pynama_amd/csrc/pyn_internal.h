@@ -60,6 +60,14 @@ struct DMat {
   bool live = false;
 };
 
+struct SellShape {
+  int br = 0, bc = 0, maxw = 0;
+  int64_t ns = 0, total = 0;
+  int64_t* ptr = nullptr;   // [ns+1] slice offsets
+  int* w = nullptr;         // [ns] slice widths (entries per scalar row)
+  int32_t* col = nullptr;   // explicit expanded columns (only when the dictionary does not apply)
+};
+
 struct DVec {
   int bs = 0;
   double* d = nullptr;  // [(n_owned+n_ghost)*bs]
@@ -113,15 +121,12 @@ struct pyn_ctx {
   int pl_npatch = 0, pl_maxrows = 0, pl_maxlen = 0;
   int64_t pl_npe = 0;
 
-  // SELL-64 structure shared by the scalar matrices of the graph (pyn_sell.hip)
-  int64_t* sell_ptr = nullptr;
-  int* sell_w = nullptr;
-  int32_t* sell_col = nullptr;
-  int64_t sell_total = 0, sell_ns = 0;
-  int sell_maxw = 0;
-  int32_t* sell_pid = nullptr;   // per-row column-pattern id (dictionary mode), else null
-  int32_t* sell_tab = nullptr;   // [npat][32] relative column offsets
+  // SELL-64 structures, one per block shape, + the node-level column-pattern dictionary (pyn_sell.hip)
+  std::vector<SellShape> sell_shapes;
+  int32_t* sell_pid = nullptr;   // per-node column-pattern id (dictionary mode), else null
+  int32_t* sell_tab = nullptr;   // [npat][32] relative node offsets
   int sell_npat = 0;
+  bool sell_dict_built = false;
 
   std::vector<DMat> mats;
   std::vector<DVec> vecs;
@@ -152,5 +157,6 @@ int pyn_reduce_host(pyn_ctx* c, int nslots, int nblocks, int op, double* out);  
 int pyn_spmv_raw(pyn_ctx* c, const DMat& A, const double* x, double* y);        // no halo exchange
 int pyn_extract_diag_inv(pyn_ctx* c, const DMat& A, double* dinv, bool invert);
 int pyn_sell_ensure(pyn_ctx* c, DMat& A);
+bool pyn_sell_supported(const DMat& A);
 int pyn_sell_spmv(pyn_ctx* c, const DMat& A, const double* x, double* y, bool dot, int* grid_out);
 void pyn_sell_drop_structure(pyn_ctx* c);

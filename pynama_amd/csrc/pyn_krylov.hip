@@ -481,7 +481,7 @@ extern "C" int pyn_spmv(pyn_ctx* c, int mat_id, int xv, int yv) {
   PYN_HIP(hipSetDevice(c->device));
   PYN_HIP(hipEventRecord(c->ev0, c->stream));
   PYN_TRY(pyn_halo_exchange(c, c->vecs[xv].d, A.bc));
-  if (A.br == 1 && A.bc == 1) {  // scalar matrices multiply through their SELL-64 image
+  if (pyn_sell_supported(A) && !getenv("PYNAMA_NO_SELL")) {  // multiply through the SELL-64 image
     PYN_TRY(pyn_sell_ensure(c, A));
     PYN_HIP(hipEventRecord(c->ev0, c->stream));  // time the product, not the (one-off) conversion
     PYN_TRY(pyn_sell_spmv(c, A, c->vecs[xv].d, c->vecs[yv].d, false, nullptr));
@@ -504,7 +504,7 @@ static int allreduce_tmp(pyn_ctx* c, int n) {
 }
 
 static int solve_cg(pyn_ctx* c, DMat& A, const double* b, double* x, const pyn_solve_opts& o, pyn_solve_info* info) {
-  const bool sell = A.br == 1 && A.bc == 1;
+  const bool sell = pyn_sell_supported(A) && !getenv("PYNAMA_NO_SELL");
   if (sell) PYN_TRY(pyn_sell_ensure(c, A));
   const int64_t n = c->n_owned * A.br;
   const int64_t nl = n_local(c) * A.br;
@@ -598,7 +598,7 @@ static int solve_cg(pyn_ctx* c, DMat& A, const double* b, double* x, const pyn_s
 }
 
 static int solve_cg_sr(pyn_ctx* c, DMat& A, const double* b, double* x, const pyn_solve_opts& o, pyn_solve_info* info) {
-  const bool sell = A.br == 1 && A.bc == 1;
+  const bool sell = pyn_sell_supported(A) && !getenv("PYNAMA_NO_SELL");
   if (sell) PYN_TRY(pyn_sell_ensure(c, A));
   const int64_t n = c->n_owned * A.br;
   const int64_t nl = n_local(c) * A.br;

@@ -15,12 +15,48 @@ constexpr int PAT_W = 32;      // max row length in dictionary mode
 
 constexpr int SH = 64;  // slice height
 
-__global__ void sell_width_kernel(const int32_t* __restrict__ rowptr, int64_t n_rows, int64_t n_slices, int* __restrict__ w) {
+// Block matrices (br x bc per graph edge) are handled as their scalar expansion: scalar row
+// r = i*br + p has len_i*bc entries, contiguous in the canonical value array at
+// (rowptr[i]*br + p*len_i)*bc, entry k -> column colidx[rowptr[i] + k/bc]*bc + k%bc.
+__global__ void sell_width_kernel(const int32_t* __restrict__ rowptr, int64_t n_rows, int br, int bc, int64_t n_slices,
+                                  int* __restrict__ w) {
   for (int64_t s = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; s < n_slices; s += (int64_t)gridDim.x * blockDim.x) {
     int64_t r0 = s * SH, r1 = r0 + SH < n_rows ? r0 + SH : n_rows;
     int m = 0;
-    for (int64_t r = r0; r < r1; ++r) m = max(m, rowptr[r + 1] - rowptr[r]);
+    for (int64_t r = r0; r < r1; ++r) {
+      const int64_t i = r / br;
+      m = max(m, (rowptr[i + 1] - rowptr[i]) * bc);
+    }
     w[s] = m;
+  }
+}
+
+// block matrices: direct (strided) reads, one lane per scalar row -- a one-off per assembly
+template <bool WITH_COLS>
+__global__ void __launch_bounds__(256) sell_fill_block_kernel(const int32_t* __restrict__ rowptr, const int32_t* __restrict__ colidx,
+                                                              const double* __restrict__ val, int64_t n_rows, int br, int bc,
+                                                              int64_t n_slices, const int64_t* __restrict__ sptr,
+                                                              const int* __restrict__ sw, double* __restrict__ sval,
+                                                              int32_t* __restrict__ scol) {
+  const int lane = threadIdx.x & 63;
+  for (int64_t s = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6; s < n_slices; s += ((int64_t)gridDim.x * blockDim.x) >> 6) {
+    const int64_t row = s * SH + lane;
+    int64_t off = 0;
+    int len = 0, lo = 0;
+    if (row < n_rows) {
+      const int64_t i = row / br;
+      const int p = (int)(row - i * br);
+      lo = rowptr[i];
+      const int ln = rowptr[i + 1] - lo;
+      off = ((int64_t)lo * br + (int64_t)p * ln) * bc;
+      len = ln * bc;
+    }
+    const int64_t base = sptr[s];
+    const int wd = sw[s];
+    for (int k = 0; k < wd; ++k) {
+      sval[base + (int64_t)k * SH + lane] = k < len ? val[off + k] : 0.0;
+      if (WITH_COLS) scol[base + (int64_t)k * SH + lane] = k < len ? colidx[lo + k / bc] * bc + k % bc : 0;
+    }
   }
 }
 
@@ -177,7 +213,9 @@ __global__ void __launch_bounds__(256) sellp_spmv_kernel(const int64_t* __restri
   extern __shared__ int32_t ltab[];  // [npat][PAT_W]
   __shared__ double smd[4];
   if (flag && flag[0]) return;
-  for (int i = threadIdx.x; i < npat * PAT_W; i += 256) ltab[i] = tab[i];
+  // slot `npat` is an all-zero pattern for the padding lanes of the last slice (their values are
+  // zero, but the gather must stay inside x: another pattern's negative offsets would not)
+  for (int i = threadIdx.x; i < (npat + 1) * PAT_W; i += 256) ltab[i] = i < npat * PAT_W ? tab[i] : 0;
   __syncthreads();
   const int lane = threadIdx.x & 63;
   const int64_t w0 = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
@@ -187,7 +225,7 @@ __global__ void __launch_bounds__(256) sellp_spmv_kernel(const int64_t* __restri
     const int64_t row = s * SH + lane;
     const int wd = sw[s];
     const double* __restrict__ v = sval + sptr[s] + lane;
-    const int32_t* __restrict__ t = ltab + (row < n_rows ? pid[row] : 0) * PAT_W;
+    const int32_t* __restrict__ t = ltab + (row < n_rows ? pid[row] : npat) * PAT_W;
     const int64_t rb = row < n_rows ? row : 0;
     double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
     int k = 0;
@@ -201,6 +239,61 @@ __global__ void __launch_bounds__(256) sellp_spmv_kernel(const int64_t* __restri
     for (; k < wd; ++k) a0 = fma(v[k * SH], x[rb + t[k]], a0);
     const double acc = (a0 + a1) + (a2 + a3);
     if (row < n_rows) {
+      y[row] = acc;
+      if (DOT) dot += acc * x[row];
+    }
+  }
+  if (DOT) {
+    dot = wsum64(dot);
+    if (lane == 0) smd[threadIdx.x >> 6] = dot;
+    __syncthreads();
+    if (threadIdx.x == 0) part[blockIdx.x] = smd[0] + smd[1] + smd[2] + smd[3];
+  }
+}
+
+// Block matrices: lane = scalar row (i,p); columns come from the NODE-level dictionary
+// (col = (i + off[k / BC]) * BC + k % BC) or from the explicit expanded column array.
+template <int BC, bool PAT, bool DOT>
+__global__ void __launch_bounds__(256) sellb_spmv_kernel(const int64_t* __restrict__ sptr, const int* __restrict__ sw,
+                                                         const int32_t* __restrict__ pid, const int32_t* __restrict__ tab,
+                                                         int npat, const int32_t* __restrict__ scol,
+                                                         const double* __restrict__ sval, const double* __restrict__ x,
+                                                         double* __restrict__ y, int64_t n_rows, int br, int64_t n_slices,
+                                                         const int* __restrict__ flag, double* __restrict__ part) {
+  extern __shared__ int32_t ltab[];  // [npat][PAT_W]
+  __shared__ double smd[4];
+  if (flag && flag[0]) return;
+  if (PAT) {  // slot `npat` = all-zero pattern for padding lanes (see sellp_spmv_kernel)
+    for (int i = threadIdx.x; i < (npat + 1) * PAT_W; i += 256) ltab[i] = i < npat * PAT_W ? tab[i] : 0;
+    __syncthreads();
+  }
+  const int lane = threadIdx.x & 63;
+  const int64_t w0 = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  const int64_t nw = ((int64_t)gridDim.x * blockDim.x) >> 6;
+  double dot = 0.0;
+  for (int64_t s = w0; s < n_slices; s += nw) {
+    const int64_t row = s * SH + lane;
+    const bool live = row < n_rows;
+    const int64_t node = live ? row / br : 0;
+    const int nk = sw[s] / BC;  // widths are multiples of BC
+    const double* __restrict__ v = sval + sptr[s] + lane;
+    const int32_t* __restrict__ ci = scol + (PAT ? 0 : sptr[s] + lane);
+    const int32_t* __restrict__ t = ltab + (PAT ? (live ? pid[node] : npat) : 0) * PAT_W;
+    double a0 = 0.0, a1 = 0.0;
+    for (int kk = 0; kk < nk; ++kk) {
+      const int64_t cb = PAT ? (node + t[kk]) * BC : 0;
+#pragma unroll
+      for (int q = 0; q < BC; ++q) {
+        const int k = kk * BC + q;
+        const int64_t col = PAT ? cb + q : (int64_t)ci[(int64_t)k * SH];
+        if (q & 1)
+          a1 = fma(v[(int64_t)k * SH], x[col], a1);
+        else
+          a0 = fma(v[(int64_t)k * SH], x[col], a0);
+      }
+    }
+    const double acc = a0 + a1;
+    if (live) {
       y[row] = acc;
       if (DOT) dot += acc * x[row];
     }
@@ -279,90 +372,146 @@ static int build_pattern_dictionary(pyn_ctx* c, int maxw) {
   return PYN_OK;
 }
 
-// (re)build the SELL image of a scalar matrix; structure is shared by all matrices of the graph
+// (re)build the SELL image of a matrix; the structure (slice pointers, widths, explicit columns) is
+// shared by all matrices of the same block shape, the column-pattern dictionary by all of them
 int pyn_sell_ensure(pyn_ctx* c, DMat& A) {
-  PYN_CHECK(A.br == 1 && A.bc == 1, "SELL image is for scalar matrices");
+  PYN_CHECK(pyn_sell_supported(A), "no SELL kernel for block shape %dx%d", A.br, A.bc);
   hipStream_t s = c->stream;
-  const int64_t n = c->n_owned;
+  const int64_t n = c->n_owned * A.br;  // scalar rows
   const int64_t ns = (n + SH - 1) / SH;
-  bool need_cols = false;
-  if (!c->sell_ptr) {
-    int* d_w = nullptr;
-    PYN_HIP(hipMalloc((void**)&d_w, ns * sizeof(int)));
-    sell_width_kernel<<<(int)std::min<int64_t>((ns + 255) / 256, 4096), 256, 0, s>>>(c->d_rowptr, n, ns, d_w);
+  if (!c->sell_dict_built) {  // node-level dictionary, once per graph
+    std::vector<int32_t> rp((size_t)c->n_owned + 1);
+    PYN_HIP(hipMemcpyAsync(rp.data(), c->d_rowptr, (c->n_owned + 1) * sizeof(int32_t), hipMemcpyDeviceToHost, s));
+    PYN_HIP(hipStreamSynchronize(s));
+    int maxlen = 0;
+    for (int64_t i = 0; i < c->n_owned; ++i) maxlen = std::max(maxlen, rp[i + 1] - rp[i]);
+    PYN_TRY(build_pattern_dictionary(c, maxlen));
+    c->sell_dict_built = true;
+  }
+  SellShape* S = nullptr;
+  for (auto& q : c->sell_shapes)
+    if (q.br == A.br && q.bc == A.bc) S = &q;
+  bool fresh = false;
+  if (!S) {
+    SellShape q;
+    q.br = A.br;
+    q.bc = A.bc;
+    q.ns = ns;
+    PYN_HIP(hipMalloc((void**)&q.w, ns * sizeof(int)));
+    sell_width_kernel<<<(int)std::min<int64_t>((ns + 255) / 256, 4096), 256, 0, s>>>(c->d_rowptr, n, A.br, A.bc, ns, q.w);
     std::vector<int> w((size_t)ns);
-    PYN_HIP(hipMemcpyAsync(w.data(), d_w, ns * sizeof(int), hipMemcpyDeviceToHost, s));
+    PYN_HIP(hipMemcpyAsync(w.data(), q.w, ns * sizeof(int), hipMemcpyDeviceToHost, s));
     PYN_HIP(hipStreamSynchronize(s));
     std::vector<int64_t> ptr((size_t)ns + 1);
     ptr[0] = 0;
-    int maxw = 0;
     for (int64_t i = 0; i < ns; ++i) {
       ptr[i + 1] = ptr[i] + (int64_t)w[i] * SH;
-      maxw = std::max(maxw, w[i]);
+      q.maxw = std::max(q.maxw, w[i]);
     }
-    PYN_CHECK((size_t)maxw * SH * 12 * 4 <= 160 * 1024, "rows too long (%d) for the SELL converter", maxw);
-    PYN_HIP(hipMalloc((void**)&c->sell_ptr, (ns + 1) * sizeof(int64_t)));
-    PYN_HIP(hipMemcpyAsync(c->sell_ptr, ptr.data(), (ns + 1) * sizeof(int64_t), hipMemcpyHostToDevice, s));
+    q.total = ptr[ns];
+    PYN_HIP(hipMalloc((void**)&q.ptr, (ns + 1) * sizeof(int64_t)));
+    PYN_HIP(hipMemcpyAsync(q.ptr, ptr.data(), (ns + 1) * sizeof(int64_t), hipMemcpyHostToDevice, s));
     PYN_HIP(hipStreamSynchronize(s));
-    c->sell_w = d_w;
-    c->sell_total = ptr[ns];
-    c->sell_maxw = maxw;
-    c->sell_ns = ns;
-    PYN_HIP(hipMalloc((void**)&c->sell_col, c->sell_total * sizeof(int32_t)));
-    need_cols = true;
-    PYN_TRY(build_pattern_dictionary(c, maxw));
-    PYN_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(sell_fill_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-    PYN_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(sell_fill_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    if (c->sell_npat == 0) PYN_HIP(hipMalloc((void**)&q.col, q.total * sizeof(int32_t)));  // explicit columns needed
+    c->sell_shapes.push_back(q);
+    S = &c->sell_shapes.back();
+    fresh = true;
   }
-  if (!A.sell_val) PYN_HIP(hipMalloc((void**)&A.sell_val, c->sell_total * sizeof(double)));
-  if (!A.sell_valid || need_cols) {
-    const size_t lds = (size_t)4 * SH * c->sell_maxw * 12;
-    const int grid = (int)std::min<int64_t>((ns + 3) / 4, 256 * 8);
-    if (need_cols)
-      sell_fill_kernel<true><<<grid, 256, lds, s>>>(c->d_rowptr, c->d_colidx, A.val, n, ns, c->sell_ptr, c->sell_w, c->sell_maxw,
-                                                    A.sell_val, c->sell_col);
-    else
-      sell_fill_kernel<false><<<grid, 256, lds, s>>>(c->d_rowptr, c->d_colidx, A.val, n, ns, c->sell_ptr, c->sell_w, c->sell_maxw,
-                                                     A.sell_val, nullptr);
+  if (!A.sell_val) PYN_HIP(hipMalloc((void**)&A.sell_val, S->total * sizeof(double)));
+  if (!A.sell_valid || fresh) {
+    const bool cols = fresh && S->col;
+    if (A.br == 1 && A.bc == 1 && (size_t)4 * SH * S->maxw * 12 <= 160 * 1024) {
+      const size_t lds = (size_t)4 * SH * S->maxw * 12;
+      const int grid = (int)std::min<int64_t>((ns + 3) / 4, 256 * 8);
+      if (cols) {
+        PYN_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(sell_fill_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        sell_fill_kernel<true><<<grid, 256, lds, s>>>(c->d_rowptr, c->d_colidx, A.val, n, ns, S->ptr, S->w, S->maxw, A.sell_val, S->col);
+      } else {
+        PYN_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(sell_fill_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        sell_fill_kernel<false><<<grid, 256, lds, s>>>(c->d_rowptr, c->d_colidx, A.val, n, ns, S->ptr, S->w, S->maxw, A.sell_val, nullptr);
+      }
+    } else {
+      const int grid = (int)std::min<int64_t>((ns + 3) / 4, 256 * 16);
+      if (cols)
+        sell_fill_block_kernel<true><<<grid, 256, 0, s>>>(c->d_rowptr, c->d_colidx, A.val, n, A.br, A.bc, ns, S->ptr, S->w, A.sell_val, S->col);
+      else
+        sell_fill_block_kernel<false><<<grid, 256, 0, s>>>(c->d_rowptr, c->d_colidx, A.val, n, A.br, A.bc, ns, S->ptr, S->w, A.sell_val, nullptr);
+    }
     PYN_HIP(hipGetLastError());
     A.sell_valid = true;
   }
   return PYN_OK;
 }
 
-int pyn_sell_spmv(pyn_ctx* c, const DMat& A, const double* x, double* y, bool dot, int* grid_out) {
-  const int64_t ns = c->sell_ns;
-  const int grid = (int)std::max<int64_t>(1, std::min<int64_t>((ns + 3) / 4, PYN_MAX_PARTIALS));
-  if (c->sell_npat > 0) {
-    if (dot)
-      sellp_spmv_kernel<true><<<grid, 256, (size_t)c->sell_npat * PAT_W * sizeof(int32_t), c->stream>>>(c->sell_ptr, c->sell_w, c->sell_pid, c->sell_tab, c->sell_npat,
-                                                           A.sell_val, x, y, c->n_owned, ns, c->d_flag, c->d_part);
-    else
-      sellp_spmv_kernel<false><<<grid, 256, (size_t)c->sell_npat * PAT_W * sizeof(int32_t), c->stream>>>(c->sell_ptr, c->sell_w, c->sell_pid, c->sell_tab, c->sell_npat,
-                                                            A.sell_val, x, y, c->n_owned, ns, nullptr, nullptr);
-  } else if (dot)
-    sell_spmv_kernel<true><<<grid, 256, 0, c->stream>>>(c->sell_ptr, c->sell_w, c->sell_col, A.sell_val, x, y, c->n_owned, ns,
-                                                        c->d_flag, c->d_part);
+bool pyn_sell_supported(const DMat& A) { return A.bc == 1 || A.bc == 2 || A.bc == 3 || A.bc == 6; }
+
+template <int BC>
+static int launch_block(pyn_ctx* c, const SellShape& S, const DMat& A, const double* x, double* y, bool dot, int grid) {
+  const int64_t n = c->n_owned * A.br;
+  const size_t lds = (size_t)(c->sell_npat + 1) * PAT_W * sizeof(int32_t);
+  const bool pat = c->sell_npat > 0;
+  if (pat && dot)
+    sellb_spmv_kernel<BC, true, true><<<grid, 256, lds, c->stream>>>(S.ptr, S.w, c->sell_pid, c->sell_tab, c->sell_npat, nullptr,
+                                                                     A.sell_val, x, y, n, A.br, S.ns, c->d_flag, c->d_part);
+  else if (pat)
+    sellb_spmv_kernel<BC, true, false><<<grid, 256, lds, c->stream>>>(S.ptr, S.w, c->sell_pid, c->sell_tab, c->sell_npat, nullptr,
+                                                                      A.sell_val, x, y, n, A.br, S.ns, nullptr, nullptr);
+  else if (dot)
+    sellb_spmv_kernel<BC, false, true><<<grid, 256, 0, c->stream>>>(S.ptr, S.w, nullptr, nullptr, 0, S.col, A.sell_val, x, y, n,
+                                                                    A.br, S.ns, c->d_flag, c->d_part);
   else
-    sell_spmv_kernel<false><<<grid, 256, 0, c->stream>>>(c->sell_ptr, c->sell_w, c->sell_col, A.sell_val, x, y, c->n_owned, ns,
-                                                         nullptr, nullptr);
+    sellb_spmv_kernel<BC, false, false><<<grid, 256, 0, c->stream>>>(S.ptr, S.w, nullptr, nullptr, 0, S.col, A.sell_val, x, y, n,
+                                                                     A.br, S.ns, nullptr, nullptr);
+  return PYN_OK;
+}
+
+int pyn_sell_spmv(pyn_ctx* c, const DMat& A, const double* x, double* y, bool dot, int* grid_out) {
+  const SellShape* S = nullptr;
+  for (auto& q : c->sell_shapes)
+    if (q.br == A.br && q.bc == A.bc) S = &q;
+  PYN_CHECK(S && A.sell_valid, "pyn_sell_ensure first");
+  PYN_CHECK(!dot || A.br == A.bc, "fused dot needs a square block shape");
+  const int64_t ns = S->ns;
+  const int grid = (int)std::max<int64_t>(1, std::min<int64_t>((ns + 3) / 4, PYN_MAX_PARTIALS));
+  if (A.br == 1 && A.bc == 1) {  // scalar fast paths
+    if (c->sell_npat > 0) {
+      const size_t lds = (size_t)(c->sell_npat + 1) * PAT_W * sizeof(int32_t);
+      if (dot)
+        sellp_spmv_kernel<true><<<grid, 256, lds, c->stream>>>(S->ptr, S->w, c->sell_pid, c->sell_tab, c->sell_npat, A.sell_val, x, y,
+                                                               c->n_owned, ns, c->d_flag, c->d_part);
+      else
+        sellp_spmv_kernel<false><<<grid, 256, lds, c->stream>>>(S->ptr, S->w, c->sell_pid, c->sell_tab, c->sell_npat, A.sell_val, x,
+                                                                y, c->n_owned, ns, nullptr, nullptr);
+    } else if (dot) {
+      sell_spmv_kernel<true><<<grid, 256, 0, c->stream>>>(S->ptr, S->w, S->col, A.sell_val, x, y, c->n_owned, ns, c->d_flag, c->d_part);
+    } else {
+      sell_spmv_kernel<false><<<grid, 256, 0, c->stream>>>(S->ptr, S->w, S->col, A.sell_val, x, y, c->n_owned, ns, nullptr, nullptr);
+    }
+  } else if (A.bc == 1) {
+    PYN_TRY(launch_block<1>(c, *S, A, x, y, dot, grid));
+  } else if (A.bc == 2) {
+    PYN_TRY(launch_block<2>(c, *S, A, x, y, dot, grid));
+  } else if (A.bc == 3) {
+    PYN_TRY(launch_block<3>(c, *S, A, x, y, dot, grid));
+  } else {
+    PYN_TRY(launch_block<6>(c, *S, A, x, y, dot, grid));
+  }
   PYN_HIP(hipGetLastError());
   if (grid_out) *grid_out = grid;
   return PYN_OK;
 }
 
 void pyn_sell_drop_structure(pyn_ctx* c) {
-  (void)hipFree(c->sell_ptr);
-  (void)hipFree(c->sell_w);
-  (void)hipFree(c->sell_col);
+  for (auto& q : c->sell_shapes) {
+    (void)hipFree(q.ptr);
+    (void)hipFree(q.w);
+    (void)hipFree(q.col);
+  }
+  c->sell_shapes.clear();
   (void)hipFree(c->sell_pid);
   (void)hipFree(c->sell_tab);
   c->sell_pid = nullptr;
   c->sell_tab = nullptr;
   c->sell_npat = 0;
-  c->sell_ptr = nullptr;
-  c->sell_w = nullptr;
-  c->sell_col = nullptr;
-  c->sell_total = 0;
-  c->sell_ns = 0;
+  c->sell_dict_built = false;
 }

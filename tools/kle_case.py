@@ -1,0 +1,43 @@
+#!/usr/bin/env python3
+"""C3 of BASELINE.json: 3D KLE (3 DOF/node) on an n^3 Q1 hex box, uniform-flow boundary data.
+usage: kle_case.py [nel] [cg_iters]"""
+import os
+import sys
+import time
+
+import numpy as np
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from pynama_amd import _lib  # noqa: E402
+from pynama_amd.domain.dmplex import DMPlexDom  # noqa: E402
+from pynama_amd.elements.spectral import Spectral  # noqa: E402
+
+n = int(sys.argv[1]) if len(sys.argv) > 1 else 128
+iters = int(sys.argv[2]) if len(sys.argv) > 2 else 50
+dom = DMPlexDom(boxMesh={"nelem": [n, n, n], "lower": [0, 0, 0], "upper": [1, 1, 1]})
+dom.setFemIndexing(2)
+ctx = dom.ctx
+for t in Spectral(2, 3).deviceTables():
+    ctx.tables_set(*t)
+bm = dom.boundaryMaskLocal()
+ctx.bc_set(3, np.repeat(bm[:, None], 3, axis=1))
+t0 = time.time()
+ctx.csr_symbolic()
+print("symbolic ms", ctx.timers()["symbolic_ms"])
+K, Krhs, Rw = ctx.mat_create(3, 3), ctx.mat_create(3, 3), ctx.mat_create(3, 3)
+for _ in range(2):
+    ctx.assemble_kle(1e3, 1e2, K, Krhs, Rw, -1)
+    print("assemble_kle ms", ctx.timers()["assemble_ms"])
+vel = np.zeros((dom.nOwned, 3))
+vel[bm != 0] = [1.0, 0.0, 0.0]
+vv, vr, vx = ctx.vec_create(3), ctx.vec_create(3), ctx.vec_create(3)
+ctx.vec_set(vv, vel.ravel())
+ctx.spmv(Krhs, vv, vr)
+print("spmv 3x3 ms", ctx.timers()["spmv_ms"])
+info = ctx.solve(K, vr, vx, fixed_iters=iters, profile=1)
+print("cg ms/iter", info.solve_ms / info.iters, "spmv_ms", info.spmv_ms)
+info = ctx.solve(K, vr, vx, rtol=1e-10, norm_type=_lib.NORM_UNPRECONDITIONED, maxit=20000)
+x = ctx.vec_get(vx, 3).reshape(-1, 3)
+print("solve its", info.iters, "reason", info.reason, "true_resid", info.true_resid, "ms", info.solve_ms,
+      "max err vs exact", np.abs(x - [1.0, 0.0, 0.0]).max())
+ctx.close()
