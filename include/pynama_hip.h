@@ -42,7 +42,8 @@ enum {
   PYN_FORM_LAPLACE = 0,   /* L_e = sum_full w detJ G^T G          spectral.py:125,131 (one component) */
   PYN_FORM_MASS_NODAL = 1,/* M_e = sum_nodal w detJ H H^T         spectral.py:215 (elWeigMat)         */
   PYN_FORM_MASS_FULL = 2, /* same on the full rule (consistent mass)                                   */
-  PYN_FORM_KLE = 3        /* K_e, Rw_e, Rd_e                       spectral.py:89-157                  */
+  PYN_FORM_KLE = 3,       /* K_e, Rw_e, Rd_e                       spectral.py:89-157                  */
+  PYN_FORM_OPERATOR = 4   /* first-order operator blocks (internal to pyn_assemble_operator)            */
 };
 
 /* Krylov method / preconditioner / norm (PETSc option names in comments) */
@@ -160,6 +161,17 @@ int pyn_assemble_scalar(pyn_ctx* ctx, int form, int A, int Arhs, int variant);
  * scalar forms: out0 = A_e[nn, nn]. */
 int pyn_elem_local(pyn_ctx* ctx, int form, double alpha_d, double alpha_w, const double* corners,
                    double* out0, double* out1, double* out2);
+
+/* First-order operator blocks of Spectral.getElemKLEOperators (src/elements/spectral.py:159-218:
+ * SrT, DivSrT, Curl) and their global scatter (Operators.setValues, src/matrices/mat_generator.py:
+ * 157-170).  With G_g = J^-1 Hrs the physical gradients at point g of quadrature `rule`, c_g = w detJ:
+ *   M[(a,p),(b,q)] = sum_g c_g H_g[a] * sum_t [row_t == p and col_t == q] coef_t * G_g[der_t][b]
+ * terms[t] = (row component, column component, derivative axis); the block shape is the matrix's.
+ * No Dirichlet elimination (the reference applies none to the operators). */
+int pyn_assemble_operator(pyn_ctx* ctx, int rule, int nterms, const int32_t* terms, const double* coef, int mat_id);
+/* single element, dense row-major out[br*nn][bc*nn] (fixture parity) */
+int pyn_elem_operator_local(pyn_ctx* ctx, int rule, int br, int bc, int nterms, const int32_t* terms,
+                            const double* coef, const double* corners, double* out);
 
 /* ---- SpMV and Krylov solve (HOT LOOP 2) ---------------------------------------------------
  * y = A x with halo exchange of x over RCCL when nranks > 1 (PETSc MatMult,

@@ -480,6 +480,35 @@ def assemble_scalar(mesh: BoxMesh, tb: Tables, form="laplace", dirichlet=None):
     return {"A": A, "Arhs": Arhs, "is_bc": is_bc}
 
 
+def assemble_operators(mesh: BoxMesh, tb: Tables, cell0_only=False):
+    """Global SrT, DivSrT, Curl with reciprocal lumped-weight row scaling.
+    base_problem.py:132-140 (loop over cells, Operators.setValues mat_generator.py:157-170) and
+    Operators.assembleAll (mat_generator.py:172-190: weights assembled, reciprocal, diagonalScale(L=)).
+    cell0_only=True reproduces the reference literally (cell 0's blocks reused for every cell,
+    base_problem.py:133-134: valid on uniform meshes); the default integrates every cell."""
+    dim, dw, ds = tb.dim, tb.dim_w, tb.dim_s
+    X = mesh.corners()
+    if cell0_only:
+        X = np.repeat(X[:1], mesh.n_elem, axis=0)
+    SrT, Div, Curl, wei = elem_kle_operators(tb, X)
+    n = mesh.n_node
+    iv, iw, isr = dof_indices(mesh.conn, dim), dof_indices(mesh.conn, dw), dof_indices(mesh.conn, ds)
+
+    def glob(Me, rows, cols, nr, nc):
+        R = np.broadcast_to(rows[:, :, None], Me.shape)
+        C = np.broadcast_to(cols[:, None, :], Me.shape)
+        return _scatter((nr, nc), R, C, Me)
+    w = np.zeros(n)
+    np.add.at(w, mesh.conn.ravel(), wei.ravel())
+    out = {}
+    for name, Me, rows, cols, br, bc in (("SrT", SrT, isr, iv, ds, dim), ("DivSrT", Div, iv, isr, dim, ds),
+                                        ("Curl", Curl, iw, iv, dw, dim)):
+        M = glob(Me, rows, cols, n * br, n * bc)
+        out[name] = sp.diags(1.0 / np.repeat(w, br)) @ M
+    out["weights"] = w
+    return out
+
+
 def node_graph(mesh: BoxMesh):
     """Node adjacency CSR pattern (what DM.createMat yields, dmplex.py:300-333)."""
     E, nn = mesh.conn.shape

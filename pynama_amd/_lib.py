@@ -87,6 +87,8 @@ SIGNATURES = {
     "pyn_assemble_kle": [_P, _D, _D, _I, _I, _I, _I, _I],
     "pyn_assemble_scalar": [_P, _I, _I, _I, _I],
     "pyn_elem_local": [_P, _I, _D, _D, _pf64, _P, _P, _P],
+    "pyn_assemble_operator": [_P, _I, _I, _pi32, _pf64, _I],
+    "pyn_elem_operator_local": [_P, _I, _I, _I, _I, _pi32, _pf64, _pf64, _pf64],
     "pyn_spmv": [_P, _I, _I, _I],
     "pyn_solve": [_P, _I, _I, _I, C.POINTER(SolveOpts), C.POINTER(SolveInfo)],
     "pyn_timers_get": [_P, _pf64, _I],
@@ -345,6 +347,16 @@ class Context:
         o0 = np.empty((nn, nn))
         _check(self.lib.pyn_elem_local(self.h, form, 0.0, 0.0, c, o0.ctypes.data_as(_P), None, None))
         return o0
+
+    def assemble_operator(self, rule, terms, coef, mid):
+        t = _i32(terms).reshape(-1, 3)
+        _check(self.lib.pyn_assemble_operator(self.h, rule, t.shape[0], t, _f64(coef), mid))
+
+    def elem_operator_local(self, rule, br, bc, terms, coef, corners):
+        t = _i32(terms).reshape(-1, 3)
+        out = np.empty((br * self.nn, bc * self.nn))
+        _check(self.lib.pyn_elem_operator_local(self.h, rule, br, bc, t.shape[0], t, _f64(coef), _f64(corners).ravel(), out))
+        return out
 
     def spmv(self, mid, x, y):
         _check(self.lib.pyn_spmv(self.h, mid, x, y))

@@ -113,8 +113,23 @@ class BaseProblem(object):
         self.bcNodes = self.dom.getNodesFromLabel("External Boundary")
 
     def buildOperators(self):
-        """SrT / DivSrT / Curl operators (base_problem.py:132-140): scope row f1, not built yet."""
-        return None
+        """SrT / DivSrT / Curl operators (base_problem.py:132-140) in three device passes."""
+        self.operator.assembleOperators(self.elemType)
+        if not self.comm.rank:
+            self.logger.info("Operators Matrices builded")
+
+    def evalRHS(self, ts, t, Vort, f):
+        """Right-hand side of the vorticity transport (base_problem.py:212-232):
+        f = Curl( Div( 2 mu S(v) - rho v (x) v ) / rho ), v from the KLE solve."""
+        self.solveKLE(t, Vort)
+        self.computeVtensV()
+        self.operator.SrT.mult(self.vel, self._Aux1)
+        self._Aux1 *= (2.0 * self.mu)
+        self._Aux1.axpy(-1.0 * self.rho, self._VtensV)
+        rhs = self.vel.duplicate()
+        self.operator.DivSrT.mult(self._Aux1, rhs)
+        rhs.scale(1 / self.rho)
+        self.operator.Curl.mult(rhs, f)
 
     def solveKLE(self, time, vort):
         pass
@@ -184,7 +199,7 @@ class FreeSlip(BaseProblem):
         self.mat.createEmptyKLEMats(rStart, rEnd, d_nnz_ind, o_nnz_ind, ind_d, ind_o, globalIndicesDIR)
         if not self.comm.rank:
             self.logger.info("Empty KLE Matrices created")
-        self.operator.createAll(rStart, rEnd, d_nnz_ind_op, o_nnz_ind)
+        self.operator.createAll(rStart, rEnd, d_nnz_ind_op, o_nnz_ind, graph=ind_d)
 
     def solveKLE(self, time, vort):
         self.applyBoundaryConditions(time)

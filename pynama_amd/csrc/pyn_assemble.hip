@@ -40,6 +40,10 @@ struct AsmArgs {
   // dense mode
   const double* corners;  // single element
   double *out0, *out1, *out2;
+  // first-order operator form: M[(a,p),(b,q)] = sum_g c_g H_g[a] sum_t [row_t=p, col_t=q] coef_t G_g[der_t][b]
+  int op_rule, op_br, op_bc, op_nterms;
+  const int32_t* op_terms;  // [nterms][3] = (row comp, col comp, derivative axis)
+  const double* op_coef;    // [nterms]
   // scratch for high order
   double* gscratch;
   int64_t gscratch_stride;  // doubles per block
@@ -105,7 +109,8 @@ __global__ void __launch_bounds__(BLOCK) assemble_generic_kernel(AsmArgs A) {
   const int dim = A.dim, nn = A.nn, nc = A.nc;
   const int dd = dim * dim;
   // which rules this form integrates on
-  const int qa = (A.form == PYN_FORM_MASS_NODAL) ? 2 : 0;  // primary rule
+  const bool oper = A.form == PYN_FORM_OPERATOR;
+  const int qa = oper ? A.op_rule : (A.form == PYN_FORM_MASS_NODAL) ? 2 : 0;  // primary rule
   const bool kle = A.form == PYN_FORM_KLE;
   const int nga = A.ngp[qa];
   const int ngb = kle ? A.ngp[1] : 0;  // reduced rule only for KLE
@@ -185,6 +190,34 @@ __global__ void __launch_bounds__(BLOCK) assemble_generic_kernel(AsmArgs A) {
       }
     };
 
+    if (oper) {
+      const int br = A.op_br, bc = A.op_bc;
+      for (int t = tid; t < npair * br * bc; t += BLOCK) {
+        int pq = t / npair, ab = t - pq * npair;
+        int a = ab / nn, b = ab - a * nn;
+        int p = pq / bc, q = pq - p * bc;
+        double v = 0.0;
+        for (int g = 0; g < nga; ++g) {
+          const double* P = pt + (int64_t)g * pt_stride;
+          const double ha = A.H[qa][(int64_t)g * nn + a];
+          if (ha == 0.0) continue;  // nodal rules: H is the identity
+          double sterm = 0.0;
+          for (int k = 0; k < A.op_nterms; ++k)
+            if (A.op_terms[3 * k] == p && A.op_terms[3 * k + 1] == q)
+              sterm += A.op_coef[k] * P[dd + 1 + A.op_terms[3 * k + 2] * nn + b];
+          v += P[dd] * ha * sterm;
+        }
+        if (DENSE) {
+          A.out0[(int64_t)(a * br + p) * (bc * nn) + b * bc + q] = v;
+        } else {
+          locate(ab, a, b);
+          if (r_len < 0) continue;
+          int64_t off = ((int64_t)r_lo * br + (int64_t)p * r_len + slot) * bc + q;
+          if (v != 0.0) atomicAdd(&A.K[off], v);
+        }
+      }
+      continue;
+    }
     if (!kle) {
       // scalar forms: A_ab = sum c G_a.G_b (Laplace) or sum c H_a H_b (mass)
       for (int ab = tid; ab < npair; ab += BLOCK) {
@@ -381,6 +414,10 @@ int fill_args(pyn_ctx* c, AsmArgs& A, int form) {
   A.out0 = A.out1 = A.out2 = nullptr;
   A.gscratch = nullptr;
   A.gscratch_stride = 0;
+  A.op_rule = A.op_br = A.op_bc = A.op_nterms = 0;
+  A.op_terms = nullptr;
+  A.op_coef = nullptr;
+  if (form == PYN_FORM_OPERATOR) return PYN_OK;  // rule checked by the caller
   const int qa = form == PYN_FORM_MASS_NODAL ? 2 : 0;
   PYN_CHECK(c->quad[qa].ngp > 0, "element tables for rule %d not set", qa);
   if (form == PYN_FORM_KLE) PYN_CHECK(c->quad[1].ngp > 0, "reduced-rule tables not set");
@@ -389,7 +426,7 @@ int fill_args(pyn_ctx* c, AsmArgs& A, int form) {
 
 template <bool DENSE>
 int launch_generic(pyn_ctx* c, AsmArgs& A, int64_t n_work) {
-  const int qa = A.form == PYN_FORM_MASS_NODAL ? 2 : 0;
+  const int qa = A.form == PYN_FORM_OPERATOR ? A.op_rule : (A.form == PYN_FORM_MASS_NODAL ? 2 : 0);
   const int ngt = A.ngp[qa] + (A.form == PYN_FORM_KLE ? A.ngp[1] : 0);
   const size_t pt_bytes = (size_t)ngt * (c->dim * c->dim + 1 + c->dim * c->nn) * sizeof(double);
   const bool pt_lds = pt_bytes <= 40 * 1024;
@@ -525,5 +562,91 @@ extern "C" int pyn_elem_local(pyn_ctx* c, int form, double alpha_d, double alpha
   if (kle && out1) PYN_HIP(hipMemcpyAsync(out1, d1, n1 * sizeof(double), hipMemcpyDeviceToHost, c->stream));
   if (kle && out2) PYN_HIP(hipMemcpyAsync(out2, d2, n2 * sizeof(double), hipMemcpyDeviceToHost, c->stream));
   PYN_HIP(hipStreamSynchronize(c->stream));
+  return PYN_OK;
+}
+
+// ---- first-order operator blocks (SrT / DivSrT / Curl of Spectral.getElemKLEOperators, spectral.py:159-218)
+static int upload_terms(pyn_ctx* c, int nterms, const int32_t* terms, const double* coef, int32_t** dt, double** dc) {
+  PYN_HIP(hipMalloc((void**)dt, (size_t)nterms * 3 * sizeof(int32_t)));
+  PYN_HIP(hipMalloc((void**)dc, (size_t)nterms * sizeof(double)));
+  PYN_HIP(hipMemcpyAsync(*dt, terms, (size_t)nterms * 3 * sizeof(int32_t), hipMemcpyHostToDevice, c->stream));
+  PYN_HIP(hipMemcpyAsync(*dc, coef, (size_t)nterms * sizeof(double), hipMemcpyHostToDevice, c->stream));
+  return PYN_OK;
+}
+
+static int check_operator(pyn_ctx* c, int rule, int br, int bc, int nterms, const int32_t* terms, const double* coef) {
+  PYN_CHECK(c && terms && coef, "NULL argument");
+  PYN_CHECK(rule >= 0 && rule < 3 && c->quad[rule].ngp > 0, "element tables for rule %d not set", rule);
+  PYN_CHECK(br >= 1 && br <= 6 && bc >= 1 && bc <= 6 && nterms >= 1 && nterms <= 64, "bad operator shape");
+  for (int k = 0; k < nterms; ++k)
+    PYN_CHECK(terms[3 * k] >= 0 && terms[3 * k] < br && terms[3 * k + 1] >= 0 && terms[3 * k + 1] < bc && terms[3 * k + 2] >= 0 &&
+                  terms[3 * k + 2] < c->dim,
+              "operator term %d out of range", k);
+  return PYN_OK;
+}
+
+extern "C" int pyn_assemble_operator(pyn_ctx* c, int rule, int nterms, const int32_t* terms, const double* coef, int mat_id) {
+  PYN_TRY(pyn_check_mat(c, mat_id, "pyn_assemble_operator"));
+  DMat& M = c->mats[mat_id];
+  PYN_TRY(check_operator(c, rule, M.br, M.bc, nterms, terms, coef));
+  PYN_HIP(hipSetDevice(c->device));
+  int32_t* dt = nullptr;
+  double* dc = nullptr;
+  PYN_TRY(upload_terms(c, nterms, terms, coef, &dt, &dc));
+  AsmArgs A;
+  PYN_TRY(fill_args(c, A, PYN_FORM_OPERATOR));
+  A.op_rule = rule;
+  A.op_br = M.br;
+  A.op_bc = M.bc;
+  A.op_nterms = nterms;
+  A.op_terms = dt;
+  A.op_coef = dc;
+  A.K = M.val;
+  M.sell_valid = false;
+  PYN_HIP(hipEventRecord(c->ev0, c->stream));
+  PYN_HIP(hipMemsetAsync(M.val, 0, (size_t)c->nnzb * M.br * M.bc * sizeof(double), c->stream));
+  PYN_TRY(launch_generic<false>(c, A, c->n_elem));
+  PYN_HIP(hipEventRecord(c->ev1, c->stream));
+  PYN_HIP(hipStreamSynchronize(c->stream));
+  float ms = 0;
+  PYN_HIP(hipEventElapsedTime(&ms, c->ev0, c->ev1));
+  c->timers[PYN_T_ASSEMBLE] = ms;
+  PYN_HIP(hipFree(dt));
+  PYN_HIP(hipFree(dc));
+  return PYN_OK;
+}
+
+extern "C" int pyn_elem_operator_local(pyn_ctx* c, int rule, int br, int bc, int nterms, const int32_t* terms,
+                                       const double* coef, const double* corners, double* out) {
+  PYN_CHECK(corners && out, "NULL argument");
+  PYN_TRY(check_operator(c, rule, br, bc, nterms, terms, coef));
+  PYN_HIP(hipSetDevice(c->device));
+  const size_t n0 = (size_t)br * c->nn * bc * c->nn, ncor = (size_t)c->nc * c->dim;
+  const size_t need = (n0 + ncor) * sizeof(double);
+  if (need > c->eloc_bytes) {
+    if (c->d_eloc) PYN_HIP(hipFree(c->d_eloc));
+    c->d_eloc = nullptr;
+    PYN_HIP(hipMalloc((void**)&c->d_eloc, need));
+    c->eloc_bytes = need;
+  }
+  int32_t* dt = nullptr;
+  double* dc = nullptr;
+  PYN_TRY(upload_terms(c, nterms, terms, coef, &dt, &dc));
+  PYN_HIP(hipMemcpyAsync(c->d_eloc, corners, ncor * sizeof(double), hipMemcpyHostToDevice, c->stream));
+  AsmArgs A;
+  PYN_TRY(fill_args(c, A, PYN_FORM_OPERATOR));
+  A.op_rule = rule;
+  A.op_br = br;
+  A.op_bc = bc;
+  A.op_nterms = nterms;
+  A.op_terms = dt;
+  A.op_coef = dc;
+  A.corners = c->d_eloc;
+  A.out0 = c->d_eloc + ncor;
+  PYN_TRY(launch_generic<true>(c, A, 1));
+  PYN_HIP(hipMemcpyAsync(out, A.out0, n0 * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+  PYN_HIP(hipStreamSynchronize(c->stream));
+  PYN_HIP(hipFree(dt));
+  PYN_HIP(hipFree(dc));
   return PYN_OK;
 }

@@ -173,7 +173,47 @@ class Spectral(Element):
         form = _lib.FORM_MASS_NODAL if nodal else _lib.FORM_MASS_FULL
         return self._device().elem_local(form, np.asarray(coords, dtype=np.float64))
 
+    # ------------------------------------------------------------------ operators (GPU)
+    def operatorTerms(self):
+        """Term tables (row comp, col comp, derivative axis) + coefficients of the three first-order
+        operators, as pyn_assemble_operator consumes them.  Restates the B-matrix fill of the reference
+        (spectral.py:189-207): strain-rate rows through indBdiv plus the sign overrides, the
+        divergence of the (Voigt-ordered) tensor, and the curl through indCurl."""
+        dim, ds = self.dim, self.dim_s
+        srt = {}
+        for x in range(dim):
+            for i in range(dim):
+                srt[(self.indBdiv[x][i], i)] = (x, 1.0)
+        srt[(0, 1)] = (1, -1.0)
+        srt[(2, 0)] = (0, -1.0)
+        for i in range(ds - 4):
+            srt[(4, i)] = (i, -1.0)
+            srt[(2 * i, 2)] = (2, -1.0)
+        div = {}
+        for x in range(dim):
+            for i in range(dim):
+                div[(i, self.indBdiv[x][i])] = (x, 1.0)
+        curl = {}
+        for n, (row, comp, der) in enumerate(self.indCurl):
+            curl[(row, comp)] = (der, -1.0 if n % 2 else 1.0)
+
+        def pack(d, scale):
+            keys = sorted(d)
+            return (np.array([[r, c, d[(r, c)][0]] for r, c in keys], dtype=np.int32),
+                    np.array([scale * d[k][1] for k in keys], dtype=np.float64))
+        return {"SrT": (ds, dim) + pack(srt, 0.5), "DivSrT": (dim, ds) + pack(div, 1.0),
+                "Curl": (self.dim_w, dim) + pack(curl, 1.0)}
+
     def getElemKLEOperators(self, coords):
-        raise NotImplementedError(
-            "getElemKLEOperators (spectral.py:159-218) is scheduled after the assembly+solve path "
-            "(SURVEY.md section 8 row f1); there is deliberately no CPU fallback")
+        """SrT_e, DivSrT_e, Curl_e and the lumped nodal weights (spectral.py:159-218) on the GPU, at
+        the nodal GLL rule.  Returns (elSTensorMat, elDivSTMat, elCurlMat, elWeigVec)."""
+        coords.shape = (int(len(coords) / self.dim), self.dim)
+        from pynama_amd import _lib
+        dev = self._device()
+        out = []
+        ops = self.operatorTerms()
+        for name in ("SrT", "DivSrT", "Curl"):
+            br, bc, terms, coef = ops[name]
+            out.append(dev.elem_operator_local(_lib.Q_NODAL, br, bc, terms, coef, coords))
+        wei = dev.elem_local(_lib.FORM_MASS_NODAL, coords).sum(axis=1)
+        return (out[0], out[1], out[2], wei)

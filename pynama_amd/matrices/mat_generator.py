@@ -188,14 +188,48 @@ class Mat:
 
 
 class Operators(Mat):
-    """Curl / DivSrT / SrT operators (mat_generator.py:133-190) -- scope row f1:
-    allocated lazily once the device operator kernels exist."""
+    """Curl / DivSrT / SrT operators with lumped-weight row scaling (mat_generator.py:133-190).
+    The per-cell ``setValues`` loop of the reference (base_problem.py:132-140) is one device pass per
+    operator (``pyn_assemble_operator``); unlike the reference, which integrates cell 0 once and reuses
+    its blocks for every cell (valid on uniform meshes only), every cell is integrated."""
 
-    def createAll(self, rStart, rEnd, d_nnz_ind, o_nnz_ind):
-        self._pending = (rStart, rEnd)
+    def createAll(self, rStart, rEnd, d_nnz_ind, o_nnz_ind, graph=None):
+        if graph is not None:
+            self.ctx, self.dom = graph.ctx, graph.dom
+        self.Curl = self.SrT = self.DivSrT = None
+
+    def bind(self, graph):
+        self.ctx, self.dom = graph.ctx, graph.dom
+
+    def assembleOperators(self, elem):
+        from pynama_amd import _lib
+        ctx = self.ctx
+        for t in elem.deviceTables():
+            ctx.tables_set(*t)
+        ops = elem.operatorTerms()
+        mats = {}
+        for name in ("Curl", "DivSrT", "SrT"):
+            br, bc, terms, coef = ops[name]
+            m = DeviceMat(ctx, br, bc, name)
+            ctx.assemble_operator(_lib.Q_NODAL, terms, coef, m.id)
+            mats[name] = m
+        self.Curl, self.DivSrT, self.SrT = mats["Curl"], mats["DivSrT"], mats["SrT"]
+        # lumped nodal weights = diagonal of the nodal-rule mass matrix (spectral.py:215-217)
+        ctx.bc_set(1, None)
+        mass = DeviceMat(ctx, 1, 1, "nodal-mass")
+        ctx.assemble_scalar(_lib.FORM_MASS_NODAL, mass.id, -1, 0)
+        w = mass.getDiagonal().getArray()
+        self.weights = w
+        for m in (self.SrT, self.DivSrT, self.Curl):      # mat_generator.py:172-186
+            wv = Vec(ctx, m.br)
+            wv.setArray(np.repeat(w, m.br))
+            wv.reciprocal()
+            m.diagonalScale(L=wv)
+            m.assemble()
+        self.mats = [self.Curl, self.DivSrT, self.SrT]
 
     def setValues(self, localOperators, nodes):
-        raise NotImplementedError("KLE operators on device: SURVEY.md section 8 row f1 (next)")
+        raise NotImplementedError("per-cell Operators.setValues is replaced by Operators.assembleOperators(elem)")
 
     def assembleAll(self):
         return None

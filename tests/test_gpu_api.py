@@ -107,3 +107,19 @@ def test_vec_interface():
     assert a.getOwnershipRange() == (0, 32) and a.getSize() == 32
     y = fem.mat.K * b
     assert abs(y.getArray() - fem.mat.K.toScipy() @ b.getArray()).max() < 1e-12
+
+
+def test_evalRHS_uniform_flow_is_zero():           # base_problem.py:212-232 on the device operators
+    fem = setFemProblem('uniform', lower=[0, 0, 0], upper=[1, 1, 1], nelem=[4, 3, 3], ngl=2)
+    f = fem.vort.duplicate()
+    fem.evalRHS(None, 0.0, fem.vort, f)
+    assert f.norm(norm_type=3) < 1e-8              # constant velocity: no strain, no transport
+    assert abs((fem.operator.Curl * fem.vel).norm(norm_type=3)) < 1e-8
+
+
+def test_curl_operator_exact_on_rotation():
+    fem = setFemProblem('uniform', lower=[0, 0], upper=[1, 1], nelem=[5, 4], ngl=3)
+    v = fem.mat.K.createVecRight()
+    fem.dom.applyFunctionVecToVec(fem.dom.getAllNodes(), lambda c: (-c[1], c[0]), v, 2)
+    w = fem.operator.Curl * v
+    assert np.abs(w.getArray() - 2.0).max() < 1e-11

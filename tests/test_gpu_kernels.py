@@ -411,3 +411,49 @@ def test_assemble_tiled_affine_shortcut(lib, kind):
     assert sp_rel_err(mat_to_scipy(ctx, A, 1, 1), ref["A"]) < FP_TOL
     assert sp_rel_err(mat_to_scipy(ctx, Arhs, 1, 1), ref["Arhs"]) < FP_TOL
     ctx.close()
+
+
+# ---- first-order operators (scope row f1) ------------------------------------------------------
+@pytest.mark.parametrize("dim,ngl", [(2, 2), (2, 3), (2, 5), (3, 2), (3, 3)])
+def test_elem_operators_vs_reference_golden(lib, golden, dim, ngl):
+    """getElemKLEOperators on the GPU == the reference's own outputs (spectral.py:159-218)"""
+    from pynama_amd.elements.spectral import Spectral
+    g = golden["g3_elem"]
+    sp = Spectral(ngl, dim)
+    for case in ("unit", "reftest", "brick128", "stretched", "jitter"):
+        key = f"d{dim}_n{ngl}_{case}"
+        SrT, Div, Curl, wei = sp.getElemKLEOperators(g[key + "_coords"].copy())
+        for name, got in (("SrT", SrT), ("DivSrT", Div), ("Curl", Curl), ("wei", wei)):
+            assert rel_err(got, g[f"{key}_{name}"]) < FP_TOL, (case, name)
+
+
+@pytest.mark.parametrize("nelem,ngl", [([6, 5], 2), ([5, 4, 3], 2), ([3, 2], 3)])
+def test_operators_global_vs_oracle(lib, nelem, ngl):
+    from pynama_amd.elements.spectral import Spectral
+    dim = len(nelem)
+    mesh = fo.box_mesh(nelem, [0.0] * dim, [1.0, 0.8, 1.2][:dim], ngl, jitter=0.15 if ngl == 2 else 0.0)
+    ref = fo.assemble_operators(mesh, fo.Tables(ngl, dim))
+    ctx = make_ctx(lib, mesh, ngl)
+    sp = Spectral(ngl, dim)
+    ops = sp.operatorTerms()
+    mass = ctx.mat_create(1, 1)
+    ctx.assemble_scalar(lib.FORM_MASS_NODAL, mass, -1, 0)
+    vw = ctx.vec_create(1)
+    ctx.mat_diagonal(mass, vw)
+    w = ctx.vec_get(vw, 1)
+    assert rel_err(w, ref["weights"]) < FP_TOL
+    for name in ("SrT", "DivSrT", "Curl"):
+        br, bc, terms, coef = ops[name]
+        m = ctx.mat_create(br, bc)
+        ctx.assemble_operator(lib.Q_NODAL, terms, coef, m)
+        vs = ctx.vec_create(br)
+        ctx.vec_set(vs, np.repeat(1.0 / w, br))
+        ctx.mat_row_scale(m, vs)
+        assert sp_rel_err(mat_to_scipy(ctx, m, br, bc), ref[name]) < FP_TOL, name
+        # SpMV through the block SELL image of the rectangular operator
+        x = np.random.default_rng(2).standard_normal(mesh.n_node * bc)
+        vx, vy = ctx.vec_create(bc), ctx.vec_create(br)
+        ctx.vec_set(vx, x)
+        ctx.spmv(m, vx, vy)
+        assert rel_err(ctx.vec_get(vy, br), ref[name] @ x) < 1e-12, name
+    ctx.close()

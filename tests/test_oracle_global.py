@@ -126,3 +126,29 @@ def test_node_graph_matches_assembled_pattern():
     lens = np.diff(rp)
     assert lens.max() == 27 and lens.min() == 8
     assert rp[-1] == (3 * 3 + 1) ** 3              # nnz = (3n+1)^3 (385^3 at n=128)
+
+
+@pytest.mark.parametrize("dim", [2, 3])
+def test_operators_exact_on_linear_fields(dim):
+    """Curl / SrT operators (base_problem.py:132-140, mat_generator.py:157-190) reproduce the
+    derivatives of a linear velocity field exactly at every node (lumped projection of a constant)."""
+    nelem = [4, 3, 3][:dim]
+    mesh = fo.box_mesh(nelem, [0.0] * dim, [1.0, 0.8, 1.2][:dim], 2, jitter=0.15)
+    tb = fo.Tables(2, dim)
+    ops = fo.assemble_operators(mesh, tb)
+    Agrad = np.array([[0.3, -1.0, 0.2], [1.5, 0.1, -0.4], [0.7, 0.6, -0.4]])[:dim, :dim]
+    v = (mesh.xyz @ Agrad.T).ravel()
+    curl = (ops["Curl"] @ v).reshape(mesh.n_node, -1)
+    if dim == 2:
+        np.testing.assert_allclose(curl[:, 0], Agrad[1, 0] - Agrad[0, 1], atol=1e-12)
+    else:
+        w = [Agrad[2, 1] - Agrad[1, 2], Agrad[0, 2] - Agrad[2, 0], Agrad[1, 0] - Agrad[0, 1]]
+        np.testing.assert_allclose(curl, np.tile(w, (mesh.n_node, 1)), atol=1e-12)
+    # constant tensor field has zero divergence only in the interior (boundary rows see one-sided sums)
+    srt = (ops["SrT"] @ v).reshape(mesh.n_node, -1)
+    assert np.abs(srt - srt[0]).max() < 1e-12
+    # the reference's shortcut (cell-0 blocks for every cell) agrees on a uniform mesh
+    um = fo.box_mesh(nelem, [0.0] * dim, [1.0] * dim, 2)
+    a, b = fo.assemble_operators(um, tb), fo.assemble_operators(um, tb, cell0_only=True)
+    for k in ("SrT", "DivSrT", "Curl"):
+        assert abs(a[k] - b[k]).max() < 1e-12
