@@ -140,6 +140,7 @@ int pyn_vec_scatter_host(pyn_ctx* ctx, int vec_id, int64_t n, const int32_t* idx
 int pyn_vec_axpby(pyn_ctx* ctx, int w, double a, int x, double b, int y);
 int pyn_vec_pointwise_mult(pyn_ctx* ctx, int w, int x, int y);
 int pyn_vec_reciprocal(pyn_ctx* ctx, int x);
+int pyn_vec_vtensv(pyn_ctx* ctx, int v, int out);   /* v (x) v, BaseProblem.computeVtensV (base_problem.py:234-252) */
 int pyn_vec_dot(pyn_ctx* ctx, int x, int y, double* out);
 int pyn_vec_norm(pyn_ctx* ctx, int x, int type /*1, 2, 3=inf (PETSc NormType)*/, double* out);
 

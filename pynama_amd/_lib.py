@@ -82,6 +82,7 @@ SIGNATURES = {
     "pyn_vec_axpby": [_P, _I, _D, _I, _D, _I],
     "pyn_vec_pointwise_mult": [_P, _I, _I, _I],
     "pyn_vec_reciprocal": [_P, _I],
+    "pyn_vec_vtensv": [_P, _I, _I],
     "pyn_vec_dot": [_P, _I, _I, C.POINTER(_D)],
     "pyn_vec_norm": [_P, _I, _I, C.POINTER(_D)],
     "pyn_assemble_kle": [_P, _D, _D, _I, _I, _I, _I, _I],
@@ -314,6 +315,9 @@ class Context:
 
     def vec_reciprocal(self, x):
         _check(self.lib.pyn_vec_reciprocal(self.h, x))
+
+    def vec_vtensv(self, v, out):
+        _check(self.lib.pyn_vec_vtensv(self.h, v, out))
 
     def vec_dot(self, x, y) -> float:
         d = _D(0)

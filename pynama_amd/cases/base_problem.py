@@ -158,17 +158,9 @@ class BaseProblem(object):
         self._Aux1 = Vec(self.dom.ctx, self.dim_s)
 
     def computeVtensV(self, vec=None):
-        """v (x) v in Voigt-like order (base_problem.py:234-252)."""
-        arr = (vec if vec is not None else self.vel).getArray()
-        d, ds = self.dim, self.dim_s
-        n = arr.size // d
-        out = np.empty((n, ds))
-        vx, vy = arr[0::d], arr[1::d]
-        out[:, 0], out[:, 1], out[:, 2] = vx * vx, vx * vy, vy * vy
-        if d == 3:
-            vz = arr[2::d]
-            out[:, 3], out[:, 4], out[:, 5] = vy * vz, vz * vz, vz * vx
-        self._VtensV.setArray(out.ravel())
+        """v (x) v in Voigt-like order (base_problem.py:234-252), on the device."""
+        src = vec if vec is not None else self.vel
+        self.dom.ctx.vec_vtensv(src.id, self._VtensV.id)
 
     def setUpEmptyMats(self):
         self.mat = None

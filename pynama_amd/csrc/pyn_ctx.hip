@@ -531,6 +531,36 @@ extern "C" int pyn_vec_reciprocal(pyn_ctx* c, int x) {
   return PYN_OK;
 }
 
+// v (x) v in the reference's component order (base_problem.py:234-252):
+// 2D [vx vx, vx vy, vy vy] ; 3D [vx vx, vx vy, vy vy, vy vz, vz vz, vz vx]
+__global__ void vtensv_kernel(const double* __restrict__ v, double* __restrict__ out, int64_t n_nodes, int dim) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n_nodes; i += (int64_t)gridDim.x * blockDim.x) {
+    const double vx = v[i * dim], vy = v[i * dim + 1];
+    if (dim == 2) {
+      out[i * 3] = vx * vx;
+      out[i * 3 + 1] = vx * vy;
+      out[i * 3 + 2] = vy * vy;
+    } else {
+      const double vz = v[i * 3 + 2];
+      out[i * 6] = vx * vx;
+      out[i * 6 + 1] = vx * vy;
+      out[i * 6 + 2] = vy * vy;
+      out[i * 6 + 3] = vy * vz;
+      out[i * 6 + 4] = vz * vz;
+      out[i * 6 + 5] = vz * vx;
+    }
+  }
+}
+
+extern "C" int pyn_vec_vtensv(pyn_ctx* c, int v, int out) {
+  PYN_TRY(pyn_check_vec(c, v, "vtensv v"));
+  PYN_TRY(pyn_check_vec(c, out, "vtensv out"));
+  const int dim = c->vecs[v].bs;
+  PYN_CHECK((dim == 2 && c->vecs[out].bs == 3) || (dim == 3 && c->vecs[out].bs == 6), "block sizes must be (2,3) or (3,6)");
+  vtensv_kernel<<<ew_grid(c->n_owned), 256, 0, c->stream>>>(c->vecs[v].d, c->vecs[out].d, c->n_owned, dim);
+  return PYN_OK;
+}
+
 // ---- reductions ------------------------------------------------------------------------------
 __device__ inline double wave_sum(double v) {
   for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
