@@ -60,17 +60,18 @@ __global__ void __launch_bounds__(256) sell_fill_block_kernel(const int32_t* __r
   }
 }
 
-// one wave per slice; the slice's CSR chunk is contiguous -> staged through LDS with coalesced loads
+// one single-wave workgroup per slice (many small workgroups keep every CU busy); the slice's CSR
+// chunk is contiguous -> staged through LDS with coalesced loads, written back as 512-B k-columns
 template <bool WITH_COLS>
-__global__ void __launch_bounds__(256) sell_fill_kernel(const int32_t* __restrict__ rowptr, const int32_t* __restrict__ colidx,
-                                                        const double* __restrict__ val, int64_t n_rows, int64_t n_slices,
-                                                        const int64_t* __restrict__ sptr, const int* __restrict__ sw,
-                                                        int maxw, double* __restrict__ sval, int32_t* __restrict__ scol) {
+__global__ void __launch_bounds__(64) sell_fill_kernel(const int32_t* __restrict__ rowptr, const int32_t* __restrict__ colidx,
+                                                       const double* __restrict__ val, int64_t n_rows, int64_t n_slices,
+                                                       const int64_t* __restrict__ sptr, const int* __restrict__ sw,
+                                                       int maxw, double* __restrict__ sval, int32_t* __restrict__ scol) {
   extern __shared__ __align__(16) unsigned char sm[];
-  const int wid = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  double* lv = reinterpret_cast<double*>(sm) + (size_t)wid * SH * maxw;
-  int32_t* lc = reinterpret_cast<int32_t*>(reinterpret_cast<double*>(sm) + (size_t)4 * SH * maxw) + (size_t)wid * SH * maxw;
-  for (int64_t s = (int64_t)blockIdx.x * 4 + wid; s < n_slices; s += (int64_t)gridDim.x * 4) {
+  const int lane = threadIdx.x;
+  double* lv = reinterpret_cast<double*>(sm);
+  int32_t* lc = reinterpret_cast<int32_t*>(lv + (size_t)SH * maxw);
+  for (int64_t s = blockIdx.x; s < n_slices; s += gridDim.x) {
     const int64_t r0 = s * SH, r1 = r0 + SH < n_rows ? r0 + SH : n_rows;
     const int lo0 = rowptr[r0];
     const int cnt = rowptr[r1] - lo0;
@@ -78,8 +79,7 @@ __global__ void __launch_bounds__(256) sell_fill_kernel(const int32_t* __restric
       lv[i] = val[lo0 + i];
       if (WITH_COLS) lc[i] = colidx[lo0 + i];
     }
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_s_waitcnt(0);
+    __syncthreads();
     const int64_t row = r0 + lane;
     int lo = 0, len = 0;
     if (row < n_rows) {
@@ -92,7 +92,7 @@ __global__ void __launch_bounds__(256) sell_fill_kernel(const int32_t* __restric
       sval[base + (int64_t)k * SH + lane] = k < len ? lv[lo + k] : 0.0;
       if (WITH_COLS) scol[base + (int64_t)k * SH + lane] = k < len ? lc[lo + k] : (row < n_rows ? (int32_t)row : 0);
     }
-    __builtin_amdgcn_wave_barrier();
+    __syncthreads();
   }
 }
 
@@ -420,16 +420,13 @@ int pyn_sell_ensure(pyn_ctx* c, DMat& A) {
   if (!A.sell_val) PYN_HIP(hipMalloc((void**)&A.sell_val, S->total * sizeof(double)));
   if (!A.sell_valid || fresh) {
     const bool cols = fresh && S->col;
-    if (A.br == 1 && A.bc == 1 && (size_t)4 * SH * S->maxw * 12 <= 160 * 1024) {
-      const size_t lds = (size_t)4 * SH * S->maxw * 12;
-      const int grid = (int)std::min<int64_t>((ns + 3) / 4, 256 * 8);
-      if (cols) {
-        PYN_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(sell_fill_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        sell_fill_kernel<true><<<grid, 256, lds, s>>>(c->d_rowptr, c->d_colidx, A.val, n, ns, S->ptr, S->w, S->maxw, A.sell_val, S->col);
-      } else {
-        PYN_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(sell_fill_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        sell_fill_kernel<false><<<grid, 256, lds, s>>>(c->d_rowptr, c->d_colidx, A.val, n, ns, S->ptr, S->w, S->maxw, A.sell_val, nullptr);
-      }
+    if (A.br == 1 && A.bc == 1 && (size_t)SH * S->maxw * 12 <= 64 * 1024) {
+      const size_t lds = (size_t)SH * S->maxw * (cols ? 12 : 8);
+      const int grid = (int)std::min<int64_t>(ns, 256 * 32);
+      if (cols)
+        sell_fill_kernel<true><<<grid, 64, lds, s>>>(c->d_rowptr, c->d_colidx, A.val, n, ns, S->ptr, S->w, S->maxw, A.sell_val, S->col);
+      else
+        sell_fill_kernel<false><<<grid, 64, lds, s>>>(c->d_rowptr, c->d_colidx, A.val, n, ns, S->ptr, S->w, S->maxw, A.sell_val, nullptr);
     } else {
       const int grid = (int)std::min<int64_t>((ns + 3) / 4, 256 * 16);
       if (cols)
