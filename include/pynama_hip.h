@@ -117,6 +117,9 @@ int pyn_csr_get(pyn_ctx* ctx, int32_t* rowptr, int32_t* colidx);
  * CSR row once (no HBM atomics, no zero fill).  Built on the device from the connectivity; call after
  * pyn_csr_symbolic.  n_patch == 0 removes the plan.  Meshes without a plan use the generic kernel. */
 int pyn_patch_plan_set(pyn_ctx* ctx, int n_patch, const int32_t* patch_ptr, const int32_t* patch_rows);
+/* kind 0: the plan of the scalar forms (<= 352 rows per patch); kind 1: the plan of the tiled KLE
+ * assembly (3x3 blocks: <= 36 rows per patch, e.g. 4x3x3 node tiles).  Both may coexist. */
+int pyn_patch_plan_set_kind(pyn_ctx* ctx, int kind, int n_patch, const int32_t* patch_ptr, const int32_t* patch_rows);
 
 /* ---- matrices and vectors (device resident) ---------------------------------------------
  * Handles are small non-negative ints.  A vector with block size b has (n_owned+n_ghost)*b

@@ -66,6 +66,7 @@ SIGNATURES = {
     "pyn_csr_info": [_P, C.POINTER(_L), C.POINTER(_L)],
     "pyn_csr_get": [_P, _pi32, _pi32],
     "pyn_patch_plan_set": [_P, _I, _P, _P],
+    "pyn_patch_plan_set_kind": [_P, _I, _I, _P, _P],
     "pyn_mat_create": [_P, _I, _I, C.POINTER(_I)],
     "pyn_mat_zero": [_P, _I],
     "pyn_mat_get_values": [_P, _I, _pf64],
@@ -247,13 +248,14 @@ class Context:
         _check(self.lib.pyn_csr_get(self.h, rp, ci))
         return rp, ci
 
-    def patch_plan_set(self, patch_ptr, patch_rows):
+    def patch_plan_set(self, patch_ptr, patch_rows, kind=0):
+        """kind 0: scalar forms (tiles of <= 352 rows), kind 1: tiled KLE assembly (<= 36 rows)"""
         if patch_ptr is None:
-            _check(self.lib.pyn_patch_plan_set(self.h, 0, None, None))
+            _check(self.lib.pyn_patch_plan_set_kind(self.h, kind, 0, None, None))
             return
         pp = _i32(patch_ptr)
         pr = _i32(patch_rows)
-        _check(self.lib.pyn_patch_plan_set(self.h, len(pp) - 1, pp.ctypes.data_as(_P), pr.ctypes.data_as(_P)))
+        _check(self.lib.pyn_patch_plan_set_kind(self.h, kind, len(pp) - 1, pp.ctypes.data_as(_P), pr.ctypes.data_as(_P)))
 
     # -- matrices
     def mat_create(self, br, bc) -> int:

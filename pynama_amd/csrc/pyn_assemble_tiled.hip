@@ -20,6 +20,7 @@
 
 namespace {
 
+constexpr int KLE_MAX_ROWS = 36;      // 4*3*3 node tiles: 36 rows * 27 cols * 9 * 8 B = 70 KB of LDS
 constexpr int PATCH_MAX_ROWS = 352;   // 7*7*7 = 343 rows -> 74 KB of LDS accumulators at 27 cols
 constexpr int TILE_THREADS = 256;
 
@@ -430,32 +431,314 @@ __global__ void __launch_bounds__(TILE_THREADS, 2) assemble_q1_hex_tiled_kernel(
   }
 }
 
+
+// =================================================================================================
+// Tiled KLE assembly (3 DOF per node): K, Krhs (WHICH = 0) and Rw (WHICH = 1) of
+// FreeSlip.buildKLEMats (src/cases/base_problem.py:499-552) without HBM atomics.
+//
+// Same scheme as the scalar kernel with 3x3 blocks: a patch owns <= KLE_MAX_ROWS nodes, its LDS holds
+// acc[slot][p][k][q] (row component p, in-row column slot k, column component q) -- exactly the layout of
+// the node row in the block-CSR value array, so the store phase streams 3*len contiguous doubles per
+// scalar row.  Per element (one lane each):
+//   K : B_ab[p][q] = d_pq (L_ab + c aw G_a.G_b) + c (ad G_pa G_qb - aw G_qa G_pb)      (spectral.py:131,152-153)
+//       L = 8-point (or affine) Laplacian block, G = reduced-point gradients, c = w_r detJ_r
+//   Rw: R_ab[p][k] = eps_pmk T_m[a][b] + aw c eps_kmp G_ma H_b,  T_m = sum_g c_g H_g[a] G_g[m][b]
+//       (spectral.py:132,155), done as three passes over m so that only one 8x8 T_m is live
+// Dirichlet routing per DOF (base_problem.py:512-547): imposed row -> identity (K, Krhs) / zero (Rw);
+// imposed column -> -value into Krhs.
+struct KleArgs {
+  const int32_t* conn;
+  const double* xyz;
+  const int32_t* rowptr;
+  const int32_t* colidx;
+  const uint8_t* bcmask;  // per DOF (node*3 + comp), may be null
+  const int32_t* p_rowptr;
+  const int32_t* p_rows;
+  const int32_t* p_eptr;
+  const int32_t* p_elem;
+  const uint4* rowslot4;
+  const uint4* kmap4;
+  int64_t npe;
+  int maxlen, maxrows;
+  const double *w, *H, *hrs, *hcoo;          // full rule
+  const double *wr, *Hr, *hrsr, *hcoor;      // reduced rule (one point)
+  const double* aff;
+  double alpha_d, alpha_w;
+  double* K;     // WHICH 0: K     | WHICH 1: Rw
+  double* Krhs;  // WHICH 0: Krhs (may be null)
+};
+
+constexpr int KLE_THREADS = 128;
+
+// geometry at one point of a rule: Ji = (hc . X)^-1, returns detJ; G[d][a] = sum_r Ji[d][r] hr[r][a]
+__device__ __forceinline__ double point_gradients(const double* __restrict__ hc, const double* __restrict__ hr,
+                                                  const double (&X)[8][3], double (&G)[3][8]) {
+  double J[3][3];
+#pragma unroll
+  for (int d = 0; d < 3; ++d)
+#pragma unroll
+    for (int x = 0; x < 3; ++x) {
+      double s = 0.0;
+#pragma unroll
+      for (int c = 0; c < 8; ++c) s = fma(hc[d * 8 + c], X[c][x], s);
+      J[d][x] = s;
+    }
+  const double c00 = J[1][1] * J[2][2] - J[1][2] * J[2][1];
+  const double c01 = J[1][2] * J[2][0] - J[1][0] * J[2][2];
+  const double c02 = J[1][0] * J[2][1] - J[1][1] * J[2][0];
+  const double det = J[0][0] * c00 + J[0][1] * c01 + J[0][2] * c02;
+  const double r = 1.0 / det;
+  double Ji[3][3];
+  Ji[0][0] = c00 * r;
+  Ji[0][1] = (J[0][2] * J[2][1] - J[0][1] * J[2][2]) * r;
+  Ji[0][2] = (J[0][1] * J[1][2] - J[0][2] * J[1][1]) * r;
+  Ji[1][0] = c01 * r;
+  Ji[1][1] = (J[0][0] * J[2][2] - J[0][2] * J[2][0]) * r;
+  Ji[1][2] = (J[0][2] * J[1][0] - J[0][0] * J[1][2]) * r;
+  Ji[2][0] = c02 * r;
+  Ji[2][1] = (J[0][1] * J[2][0] - J[0][0] * J[2][1]) * r;
+  Ji[2][2] = (J[0][0] * J[1][1] - J[0][1] * J[1][0]) * r;
+#pragma unroll
+  for (int d = 0; d < 3; ++d)
+#pragma unroll
+    for (int a = 0; a < 8; ++a) {
+      double s = Ji[d][0] * hr[a];
+      s = fma(Ji[d][1], hr[8 + a], s);
+      s = fma(Ji[d][2], hr[16 + a], s);
+      G[d][a] = s;
+    }
+  return det;
+}
+
+// one (m, half) pass of the Rw element block: T_m[a][b] = sum_g c_g H_g[a] G_g[m][b] for the four row
+// nodes a = 4*AH .. 4*AH+3, plus the reduced-point term, scattered into the LDS rows of the patch
+template <int M, int AH>
+__device__ __forceinline__ void rw_pass(const KleArgs& T, const double (&X)[8][3], const unsigned (&rsw)[4],
+                                        const unsigned (&kmw)[16], double* acc, int rowsz, int ml) {
+  double Tm[32];
+#pragma unroll
+  for (int i = 0; i < 32; ++i) Tm[i] = 0.0;
+#pragma nounroll
+  for (int g = 0; g < 8; ++g) {
+    double G[3][8];
+    const double cg = T.w[g] * point_gradients(T.hcoo + g * 24, T.hrs + g * 24, X, G);
+    const double* __restrict__ Hg = T.H + g * 8;
+#pragma unroll
+    for (int a = 0; a < 4; ++a) {
+      const double ha = cg * Hg[4 * AH + a];
+#pragma unroll
+      for (int b = 0; b < 8; ++b) Tm[a * 8 + b] = fma(ha, G[M][b], Tm[a * 8 + b]);
+    }
+  }
+  double Gr[3][8];
+  const double caw = T.wr[0] * point_gradients(T.hcoor, T.hrsr, X, Gr) * T.alpha_w;
+  constexpr int P1 = (M + 1) % 3, P2 = (M + 2) % 3;
+  // (curl w)_p = eps_{p m k} d_m w_k, cyclic triples (0,1,2),(1,2,0),(2,0,1): (p, m, k) = (P2, M, P1) is
+  // cyclic -> +T_m at (row comp P2, col comp P1), -T_m at (P1, P2); the reduced term carries eps_{k m p}
+#pragma unroll
+  for (int a = 0; a < 4; ++a) {
+    const int an = 4 * AH + a;
+    const unsigned slot = (rsw[an >> 1] >> (16 * (an & 1))) & 0xFFFFu;
+    if (slot == 0xFFFFu) continue;
+    double* rowp = acc + (size_t)slot * rowsz;
+#pragma unroll
+    for (int b = 0; b < 8; ++b) {
+      const unsigned k = (kmw[2 * an + (b >> 2)] >> (8 * (b & 3))) & 0xFFu;
+      const double tv = Tm[a * 8 + b];
+      const double red = caw * Gr[M][an] * T.Hr[b];
+      atomicAdd(&rowp[(P2 * ml + k) * 3 + P1], tv - red);
+      atomicAdd(&rowp[(P1 * ml + k) * 3 + P2], red - tv);
+    }
+  }
+}
+
+template <int WHICH>
+__global__ void __launch_bounds__(KLE_THREADS, 2) assemble_q1_hex_kle_tiled_kernel(KleArgs T) {
+  extern __shared__ __align__(16) double acc[];  // [maxrows][3][maxlen][3]
+  const int p = blockIdx.x;
+  const int r_lo = T.p_rowptr[p];
+  const int nrows = T.p_rowptr[p + 1] - r_lo;
+  const int e_lo = T.p_eptr[p];
+  const int ne = T.p_eptr[p + 1] - e_lo;
+  const int ml = T.maxlen;
+  const int rowsz = 9 * ml;                                                   // doubles per node row
+  int* rmeta = reinterpret_cast<int*>(acc + (size_t)T.maxrows * rowsz);      // [maxrows][2]: csr offset, len | rowbc<<16
+  unsigned* cflag = reinterpret_cast<unsigned*>(rmeta + 2 * T.maxrows);      // [maxrows][3]: per q, bit k = (col k, comp q) imposed
+  const int tid = threadIdx.x;
+
+  for (int i = tid; i < nrows * rowsz; i += KLE_THREADS) acc[i] = 0.0;
+  for (int i = tid; i < nrows * 3; i += KLE_THREADS) cflag[i] = 0u;
+  for (int sl = tid; sl < nrows; sl += KLE_THREADS) {
+    const int row = T.p_rows[r_lo + sl];
+    const int lo = T.rowptr[row];
+    const int len = T.rowptr[row + 1] - lo;
+    int rb = 0;
+    if (T.bcmask) rb = (T.bcmask[row * 3] ? 1 : 0) | (T.bcmask[row * 3 + 1] ? 2 : 0) | (T.bcmask[row * 3 + 2] ? 4 : 0);
+    rmeta[2 * sl] = lo;
+    rmeta[2 * sl + 1] = len | (rb << 16);
+  }
+  __syncthreads();
+
+  for (int base = 0; base < ne; base += KLE_THREADS) {
+    const int t = base + tid;
+    if (t >= ne) continue;
+    const int64_t pe = (int64_t)e_lo + t;
+    const int64_t e = T.p_elem[pe];
+    const int4 c0 = reinterpret_cast<const int4*>(T.conn)[e * 2];
+    const int4 c1 = reinterpret_cast<const int4*>(T.conn)[e * 2 + 1];
+    const int nd[8] = {c0.x, c0.y, c0.z, c0.w, c1.x, c1.y, c1.z, c1.w};
+    double X[8][3];
+#pragma unroll
+    for (int a = 0; a < 8; ++a) {
+      const double* q = T.xyz + (int64_t)nd[a] * 3;
+      X[a][0] = q[0];
+      X[a][1] = q[1];
+      X[a][2] = q[2];
+    }
+    unsigned bcn = 0;  // bit 3*b + q = DOF (node b, comp q) imposed
+    if (WHICH == 0 && T.bcmask) {
+#pragma unroll
+      for (int b = 0; b < 8; ++b)
+#pragma unroll
+        for (int q = 0; q < 3; ++q) bcn |= (T.bcmask[(int64_t)nd[b] * 3 + q] ? 1u : 0u) << (3 * b + q);
+    }
+    const uint4 rs4 = T.rowslot4[pe];
+    const unsigned rsw[4] = {rs4.x, rs4.y, rs4.z, rs4.w};
+    uint4 km4[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) km4[j] = T.kmap4[(int64_t)j * T.npe + pe];
+    const unsigned kmw[16] = {km4[0].x, km4[0].y, km4[0].z, km4[0].w, km4[1].x, km4[1].y, km4[1].z, km4[1].w,
+                              km4[2].x, km4[2].y, km4[2].z, km4[2].w, km4[3].x, km4[3].y, km4[3].z, km4[3].w};
+    // reduced (centroid) point
+    if (WHICH == 0) {
+      double Gr[3][8];
+      const double cr = T.wr[0] * point_gradients(T.hcoor, T.hrsr, X, Gr);
+      double L[36];
+#pragma unroll
+      for (int i = 0; i < 36; ++i) L[i] = 0.0;
+      {
+        TileArgs S;
+        S.w = T.w;
+        S.hrs = T.hrs;
+        S.hcoo = T.hcoo;
+        S.aff = T.aff;
+        if (T.aff && __all(element_is_affine(S, X) ? 1 : 0)) {
+          affine_laplace(S, X, L);
+        } else {
+#pragma nounroll
+          for (int g = 0; g < 8; ++g) gauss_point(S, g, X, L);
+        }
+      }
+      const double caw = cr * T.alpha_w, cad = cr * T.alpha_d;
+#pragma unroll
+      for (int a = 0; a < 8; ++a) {
+        const unsigned slot = (rsw[a >> 1] >> (16 * (a & 1))) & 0xFFFFu;
+        if (slot == 0xFFFFu) continue;
+        double* rowp = acc + (size_t)slot * rowsz;
+#pragma unroll
+        for (int b = 0; b < 8; ++b) {
+          const unsigned k = (kmw[2 * a + (b >> 2)] >> (8 * (b & 3))) & 0xFFu;
+          const double s_ab = Gr[0][a] * Gr[0][b] + Gr[1][a] * Gr[1][b] + Gr[2][a] * Gr[2][b];
+          const double diag = L[tri(a, b)] + caw * s_ab;
+          if (bcn) {
+#pragma unroll
+            for (int q = 0; q < 3; ++q)
+              if ((bcn >> (3 * b + q)) & 1u) atomicOr(&cflag[slot * 3 + q], 1u << k);
+          }
+#pragma unroll
+          for (int pp = 0; pp < 3; ++pp)
+#pragma unroll
+            for (int q = 0; q < 3; ++q) {
+              double v = cad * Gr[pp][a] * Gr[q][b] - caw * Gr[q][a] * Gr[pp][b];
+              if (pp == q) v += diag;
+              atomicAdd(&rowp[(pp * ml + k) * 3 + q], v);
+            }
+        }
+      }
+    } else {
+      // Rw: passes over the derivative axis m (x the two halves of the row nodes, to keep one 4x8
+      // block of T_m live): (p, kc) = the two other axes in both orders
+#pragma nounroll
+      for (int it = 0; it < 6; ++it) {  // a rolled loop keeps the passes from being interleaved (registers)
+        switch (it) {
+          case 0: rw_pass<0, 0>(T, X, rsw, kmw, acc, rowsz, ml); break;
+          case 1: rw_pass<0, 1>(T, X, rsw, kmw, acc, rowsz, ml); break;
+          case 2: rw_pass<1, 0>(T, X, rsw, kmw, acc, rowsz, ml); break;
+          case 3: rw_pass<1, 1>(T, X, rsw, kmw, acc, rowsz, ml); break;
+          case 4: rw_pass<2, 0>(T, X, rsw, kmw, acc, rowsz, ml); break;
+          default: rw_pass<2, 1>(T, X, rsw, kmw, acc, rowsz, ml); break;
+        }
+      }
+    }
+  }
+  __syncthreads();
+
+  // ---- store: every scalar row (slot, p) = 3*len contiguous doubles, written once
+  {
+    double* __restrict__ outA = T.K;
+    double* __restrict__ outR = T.Krhs;
+    const int lane = tid & 63, wv = tid >> 6;
+    constexpr int NW = KLE_THREADS / 64;
+    for (int sr = wv; sr < nrows * 3; sr += NW) {
+      const int slot = sr / 3, pp = sr - slot * 3;
+      const int lo = rmeta[2 * slot];
+      const int m1 = rmeta[2 * slot + 1];
+      const int len = m1 & 0xFFFF;
+      const bool rowbc = (m1 >> (16 + pp)) & 1;
+      const int64_t gbase = ((int64_t)lo * 3 + (int64_t)pp * len) * 3;
+      const double* src = acc + (size_t)slot * rowsz + (size_t)pp * ml * 3;
+      for (int idx = lane; idx < len * 3; idx += 64) {
+        const int k = idx / 3, q = idx - k * 3;
+        const double v = src[idx];
+        double va, vr;
+        if (rowbc) {
+          const bool dg = (WHICH == 0) && q == pp && T.colidx[lo + k] == T.p_rows[r_lo + slot];
+          va = vr = dg ? 1.0 : 0.0;
+        } else if (WHICH == 0 && ((cflag[slot * 3 + q] >> k) & 1u)) {
+          va = 0.0;
+          vr = -v;
+        } else {
+          va = v;
+          vr = 0.0;
+        }
+        outA[gbase + idx] = va;
+        if (WHICH == 0 && outR) outR[gbase + idx] = vr;
+      }
+    }
+  }
+}
+
 __global__ void colbc_kernel(const int32_t* __restrict__ colidx, const uint8_t* __restrict__ bcmask, int64_t nnz,
                              uint8_t* __restrict__ colbc) {
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < nnz; i += (int64_t)gridDim.x * blockDim.x)
     colbc[i] = bcmask[colidx[i]];
 }
 
+static size_t kle_lds_bytes(int max_rows, int maxlen) {
+  return (size_t)max_rows * 9 * maxlen * sizeof(double) + (size_t)max_rows * 2 * sizeof(int) + (size_t)max_rows * 3 * sizeof(unsigned);
+}
+
 }  // namespace
 
 // -------------------------------------------------------------------------------------------------
 extern "C" int pyn_patch_plan_set(pyn_ctx* c, int n_patch, const int32_t* patch_ptr, const int32_t* patch_rows) {
+  return pyn_patch_plan_set_kind(c, 0, n_patch, patch_ptr, patch_rows);
+}
+
+extern "C" int pyn_patch_plan_set_kind(pyn_ctx* c, int kind, int n_patch, const int32_t* patch_ptr, const int32_t* patch_rows) {
   PYN_CHECK(c, "ctx is NULL");
+  PYN_CHECK(kind == 0 || kind == 1, "plan kind must be 0 (scalar) or 1 (KLE)");
+  PatchPlan& P = c->plan[kind];
+  const int max_rows_allowed = kind == 0 ? PATCH_MAX_ROWS : KLE_MAX_ROWS;
   PYN_HIP(hipSetDevice(c->device));
   // drop an existing plan
-  (void)hipFree(c->pl_rowptr);
-  (void)hipFree(c->pl_rows);
-  (void)hipFree(c->pl_eptr);
-  (void)hipFree(c->pl_elem);
-  (void)hipFree(c->pl_rowslot4);
-  (void)hipFree(c->pl_kmap4);
-  (void)hipFree(c->pl_colbc);
-  c->pl_colbc = nullptr;
-  c->pl_colbc_stamp = -1;
-  c->pl_rowptr = c->pl_rows = c->pl_eptr = c->pl_elem = nullptr;
-  c->pl_rowslot4 = c->pl_kmap4 = nullptr;
-  c->pl_npatch = 0;
-  c->pl_npe = 0;
+  (void)hipFree(P.rowptr);
+  (void)hipFree(P.rows);
+  (void)hipFree(P.eptr);
+  (void)hipFree(P.elem);
+  (void)hipFree(P.rowslot4);
+  (void)hipFree(P.kmap4);
+  P = PatchPlan();
   if (n_patch == 0) return PYN_OK;
   PYN_CHECK(patch_ptr && patch_rows, "NULL argument");
   PYN_CHECK(c->d_rowptr, "pyn_csr_symbolic first");
@@ -466,7 +749,7 @@ extern "C" int pyn_patch_plan_set(pyn_ctx* c, int n_patch, const int32_t* patch_
     PYN_CHECK(patch_ptr[p + 1] >= patch_ptr[p], "patch_ptr not monotone");
     max_rows = std::max(max_rows, patch_ptr[p + 1] - patch_ptr[p]);
   }
-  PYN_CHECK(max_rows <= PATCH_MAX_ROWS, "a patch has %d rows (max %d)", max_rows, PATCH_MAX_ROWS);
+  PYN_CHECK(max_rows <= max_rows_allowed, "a patch has %d rows (max %d for this kind)", max_rows, max_rows_allowed);
   {
     std::vector<uint8_t> seen((size_t)c->n_owned, 0);
     for (int64_t i = 0; i < c->n_owned; ++i) {
@@ -475,14 +758,14 @@ extern "C" int pyn_patch_plan_set(pyn_ctx* c, int n_patch, const int32_t* patch_
     }
   }
   hipStream_t s = c->stream;
-  PYN_HIP(hipMalloc((void**)&c->pl_rowptr, (n_patch + 1) * sizeof(int32_t)));
-  PYN_HIP(hipMalloc((void**)&c->pl_rows, c->n_owned * sizeof(int32_t)));
-  PYN_HIP(hipMemcpyAsync(c->pl_rowptr, patch_ptr, (n_patch + 1) * sizeof(int32_t), hipMemcpyHostToDevice, s));
-  PYN_HIP(hipMemcpyAsync(c->pl_rows, patch_rows, c->n_owned * sizeof(int32_t), hipMemcpyHostToDevice, s));
+  PYN_HIP(hipMalloc((void**)&P.rowptr, (n_patch + 1) * sizeof(int32_t)));
+  PYN_HIP(hipMalloc((void**)&P.rows, c->n_owned * sizeof(int32_t)));
+  PYN_HIP(hipMemcpyAsync(P.rowptr, patch_ptr, (n_patch + 1) * sizeof(int32_t), hipMemcpyHostToDevice, s));
+  PYN_HIP(hipMemcpyAsync(P.rows, patch_rows, c->n_owned * sizeof(int32_t), hipMemcpyHostToDevice, s));
   int32_t *node2patch = nullptr, *node2slot = nullptr;
   PYN_HIP(hipMalloc((void**)&node2patch, c->n_owned * sizeof(int32_t)));
   PYN_HIP(hipMalloc((void**)&node2slot, c->n_owned * sizeof(int32_t)));
-  plan_node_maps_kernel<<<std::min(n_patch, 65536), 256, 0, s>>>(c->pl_rowptr, c->pl_rows, n_patch, node2patch, node2slot);
+  plan_node_maps_kernel<<<std::min(n_patch, 65536), 256, 0, s>>>(P.rowptr, P.rows, n_patch, node2patch, node2slot);
   const int64_t nk = c->n_elem * c->nn;
   unsigned long long *k0 = nullptr, *k1 = nullptr;
   int64_t* d_npe = nullptr;
@@ -506,17 +789,17 @@ extern "C" int pyn_patch_plan_set(pyn_ctx* c, int n_patch, const int32_t* patch_
   int32_t* ecount = nullptr;
   PYN_HIP(hipMalloc((void**)&ecount, (n_patch + 1) * sizeof(int32_t)));
   PYN_HIP(hipMemsetAsync(ecount, 0, (n_patch + 1) * sizeof(int32_t), s));
-  PYN_HIP(hipMalloc((void**)&c->pl_eptr, (n_patch + 1) * sizeof(int32_t)));
-  PYN_HIP(hipMalloc((void**)&c->pl_elem, npe * sizeof(int32_t)));
-  PYN_HIP(hipMalloc((void**)&c->pl_rowslot4, npe * sizeof(uint4)));
-  PYN_HIP(hipMalloc((void**)&c->pl_kmap4, 4 * npe * sizeof(uint4)));
+  PYN_HIP(hipMalloc((void**)&P.eptr, (n_patch + 1) * sizeof(int32_t)));
+  PYN_HIP(hipMalloc((void**)&P.elem, npe * sizeof(int32_t)));
+  PYN_HIP(hipMalloc((void**)&P.rowslot4, npe * sizeof(uint4)));
+  PYN_HIP(hipMalloc((void**)&P.kmap4, 4 * npe * sizeof(uint4)));
   grid = (int)std::min<int64_t>((npe + 255) / 256, 65536);
   plan_fill_kernel<<<grid, 256, 0, s>>>(k1, npe, c->d_conn, c->nn, c->n_owned, node2patch, node2slot, c->d_rowptr, c->d_colidx,
-                                        c->pl_elem, ecount, (uint4*)c->pl_rowslot4, (uint4*)c->pl_kmap4);
+                                        P.elem, ecount, (uint4*)P.rowslot4, (uint4*)P.kmap4);
   tb = 0;
-  PYN_HIP(hipcub::DeviceScan::ExclusiveSum(nullptr, tb, ecount, c->pl_eptr, n_patch + 1, s));
+  PYN_HIP(hipcub::DeviceScan::ExclusiveSum(nullptr, tb, ecount, P.eptr, n_patch + 1, s));
   PYN_HIP(hipMalloc(&tmp, tb));
-  PYN_HIP(hipcub::DeviceScan::ExclusiveSum(tmp, tb, ecount, c->pl_eptr, n_patch + 1, s));
+  PYN_HIP(hipcub::DeviceScan::ExclusiveSum(tmp, tb, ecount, P.eptr, n_patch + 1, s));
   // max row length of the graph (LDS row stride)
   std::vector<int32_t> rp((size_t)c->n_owned + 1);
   PYN_HIP(hipMemcpyAsync(rp.data(), c->d_rowptr, (c->n_owned + 1) * sizeof(int32_t), hipMemcpyDeviceToHost, s));
@@ -530,25 +813,81 @@ extern "C" int pyn_patch_plan_set(pyn_ctx* c, int n_patch, const int32_t* patch_
   PYN_HIP(hipFree(d_npe));
   PYN_HIP(hipFree(node2patch));
   PYN_HIP(hipFree(node2slot));
-  c->pl_npatch = n_patch;
-  c->pl_npe = npe;
-  c->pl_maxrows = max_rows;
-  c->pl_maxlen = maxlen;
-  size_t lds = (size_t)max_rows * maxlen * sizeof(double) + (size_t)max_rows * 3 * sizeof(int);
-  PYN_CHECK(lds <= 160 * 1024, "patch accumulators need %zu B of LDS", lds);
-  PYN_CHECK(maxlen <= 32, "rows of %d entries: the tiled kernel handles <= 32 (Q1 hex has 27)", maxlen);
-  PYN_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(assemble_q1_hex_tiled_kernel<0>),
-                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-  PYN_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(assemble_q1_hex_tiled_kernel<1>),
-                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-  PYN_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(assemble_q1_hex_tiled_kernel<2>),
-                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  P.npatch = n_patch;
+  P.npe = npe;
+  P.maxrows = max_rows;
+  P.maxlen = maxlen;
+  PYN_CHECK(maxlen <= 32, "rows of %d entries: the tiled kernels handle <= 32 (Q1 hex has 27)", maxlen);
+  if (kind == 0) {
+    size_t lds = (size_t)max_rows * maxlen * sizeof(double) + (size_t)max_rows * 3 * sizeof(int);
+    PYN_CHECK(lds <= 160 * 1024, "patch accumulators need %zu B of LDS", lds);
+    PYN_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(assemble_q1_hex_tiled_kernel<0>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    PYN_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(assemble_q1_hex_tiled_kernel<1>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    PYN_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(assemble_q1_hex_tiled_kernel<2>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  } else {
+    size_t lds = kle_lds_bytes(max_rows, maxlen);
+    PYN_CHECK(lds <= 160 * 1024, "KLE patch accumulators need %zu B of LDS", lds);
+    PYN_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(assemble_q1_hex_kle_tiled_kernel<0>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    PYN_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(assemble_q1_hex_kle_tiled_kernel<1>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  }
   return PYN_OK;
 }
 
-int pyn_assemble_q1_tiled(pyn_ctx* c, int form, double, double, double* K, double* Krhs, double* Rw, double* Rd, bool* handled) {
+static int assemble_kle_tiled(pyn_ctx* c, double alpha_d, double alpha_w, double* K, double* Krhs, double* Rw, bool* handled) {
+  PatchPlan& P = c->plan[1];
+  if (!P.npatch || c->dim != 3 || c->nn != 8 || c->quad[0].ngp != 8 || c->quad[1].ngp != 1) return PYN_OK;
+  KleArgs T;
+  T.conn = c->d_conn;
+  T.xyz = c->d_xyz;
+  T.rowptr = c->d_rowptr;
+  T.colidx = c->d_colidx;
+  T.bcmask = c->d_bcmask;
+  T.p_rowptr = P.rowptr;
+  T.p_rows = P.rows;
+  T.p_eptr = P.eptr;
+  T.p_elem = P.elem;
+  T.rowslot4 = (const uint4*)P.rowslot4;
+  T.kmap4 = (const uint4*)P.kmap4;
+  T.npe = P.npe;
+  T.maxlen = P.maxlen;
+  T.maxrows = P.maxrows;
+  T.w = c->quad[0].w;
+  T.H = c->quad[0].H;
+  T.hrs = c->quad[0].Hrs;
+  T.hcoo = c->quad[0].HrsCoo;
+  T.wr = c->quad[1].w;
+  T.Hr = c->quad[1].H;
+  T.hrsr = c->quad[1].Hrs;
+  T.hcoor = c->quad[1].HrsCoo;
+  T.aff = getenv("PYNAMA_NO_AFFINE") ? nullptr : c->d_aff;
+  T.alpha_d = alpha_d;
+  T.alpha_w = alpha_w;
+  const size_t lds = kle_lds_bytes(P.maxrows, P.maxlen);
+  if (K) {
+    T.K = K;
+    T.Krhs = Krhs;
+    assemble_q1_hex_kle_tiled_kernel<0><<<P.npatch, KLE_THREADS, lds, c->stream>>>(T);
+  }
+  if (Rw) {
+    T.K = Rw;
+    T.Krhs = nullptr;
+    assemble_q1_hex_kle_tiled_kernel<1><<<P.npatch, KLE_THREADS, lds, c->stream>>>(T);
+  }
+  PYN_HIP(hipGetLastError());
+  *handled = true;
+  return PYN_OK;
+}
+
+int pyn_assemble_q1_tiled(pyn_ctx* c, int form, double alpha_d, double alpha_w, double* K, double* Krhs, double* Rw, double* Rd, bool* handled) {
   *handled = false;
-  if (!c->pl_npatch || form != PYN_FORM_LAPLACE || !K || Rw || Rd) return PYN_OK;
+  if (form == PYN_FORM_KLE && K && !Rd) return assemble_kle_tiled(c, alpha_d, alpha_w, K, Krhs, Rw, handled);
+  PatchPlan& P = c->plan[0];
+  if (!P.npatch || form != PYN_FORM_LAPLACE || !K || Rw || Rd) return PYN_OK;
   if (c->dim != 3 || c->nn != 8 || c->quad[0].ngp != 8) return PYN_OK;
   TileArgs T;
   T.conn = c->d_conn;
@@ -557,31 +896,31 @@ int pyn_assemble_q1_tiled(pyn_ctx* c, int form, double, double, double* K, doubl
   T.colidx = c->d_colidx;
   T.bcmask = c->d_bcmask;
   T.colbc = nullptr;
-  T.p_rowptr = c->pl_rowptr;
-  T.p_rows = c->pl_rows;
-  T.p_eptr = c->pl_eptr;
-  T.p_elem = c->pl_elem;
-  T.rowslot4 = (const uint4*)c->pl_rowslot4;
-  T.kmap4 = (const uint4*)c->pl_kmap4;
-  T.npe = c->pl_npe;
-  T.n_patch = c->pl_npatch;
-  T.maxlen = c->pl_maxlen;
-  T.maxrows = c->pl_maxrows;
+  T.p_rowptr = P.rowptr;
+  T.p_rows = P.rows;
+  T.p_eptr = P.eptr;
+  T.p_elem = P.elem;
+  T.rowslot4 = (const uint4*)P.rowslot4;
+  T.kmap4 = (const uint4*)P.kmap4;
+  T.npe = P.npe;
+  T.n_patch = P.npatch;
+  T.maxlen = P.maxlen;
+  T.maxrows = P.maxrows;
   T.w = c->quad[0].w;
   T.hrs = c->quad[0].Hrs;
   T.hcoo = c->quad[0].HrsCoo;
   T.aff = getenv("PYNAMA_NO_AFFINE") ? nullptr : c->d_aff;
   T.A = K;
   T.Arhs = Krhs;
-  size_t lds = (size_t)c->pl_maxrows * c->pl_maxlen * sizeof(double) + (size_t)c->pl_maxrows * 3 * sizeof(int);
+  size_t lds = (size_t)P.maxrows * P.maxlen * sizeof(double) + (size_t)P.maxrows * 3 * sizeof(int);
   const char* ab = getenv("PYNAMA_TILED_ABLATE");  // diagnostics only: 1 = no LDS adds, 2 = no quadrature
   const int abl = ab ? atoi(ab) : 0;
   if (abl == 1)
-    assemble_q1_hex_tiled_kernel<1><<<c->pl_npatch, TILE_THREADS, lds, c->stream>>>(T);
+    assemble_q1_hex_tiled_kernel<1><<<P.npatch, TILE_THREADS, lds, c->stream>>>(T);
   else if (abl == 2)
-    assemble_q1_hex_tiled_kernel<2><<<c->pl_npatch, TILE_THREADS, lds, c->stream>>>(T);
+    assemble_q1_hex_tiled_kernel<2><<<P.npatch, TILE_THREADS, lds, c->stream>>>(T);
   else
-    assemble_q1_hex_tiled_kernel<0><<<c->pl_npatch, TILE_THREADS, lds, c->stream>>>(T);
+    assemble_q1_hex_tiled_kernel<0><<<P.npatch, TILE_THREADS, lds, c->stream>>>(T);
   PYN_HIP(hipGetLastError());
   *handled = true;
   return PYN_OK;

@@ -99,13 +99,8 @@ extern "C" int pyn_ctx_destroy(pyn_ctx* c) {
   (void)hipFree(c->d_bcmask);
   (void)hipFree(c->d_rowptr);
   (void)hipFree(c->d_colidx);
-  (void)hipFree(c->pl_rowptr);
-  (void)hipFree(c->pl_rows);
-  (void)hipFree(c->pl_eptr);
-  (void)hipFree(c->pl_elem);
-  (void)hipFree(c->pl_rowslot4);
-  (void)hipFree(c->pl_kmap4);
-  (void)hipFree(c->pl_colbc);
+  (void)pyn_patch_plan_set_kind(c, 0, 0, nullptr, nullptr);
+  (void)pyn_patch_plan_set_kind(c, 1, 0, nullptr, nullptr);
   (void)hipFree(c->d_send_idx);
   (void)hipFree(c->d_send_buf);
   (void)hipFree(c->d_part);

@@ -60,6 +60,13 @@ struct DMat {
   bool live = false;
 };
 
+struct PatchPlan {
+  int32_t *rowptr = nullptr, *rows = nullptr, *eptr = nullptr, *elem = nullptr;
+  void *rowslot4 = nullptr, *kmap4 = nullptr;
+  int npatch = 0, maxrows = 0, maxlen = 0;
+  int64_t npe = 0;
+};
+
 struct SellShape {
   int br = 0, bc = 0, maxw = 0;
   int64_t ns = 0, total = 0;
@@ -113,13 +120,8 @@ struct pyn_ctx {
   int32_t* d_colidx = nullptr;
   int64_t nnzb = 0;
 
-  // patch plan of the tiled assembly (pyn_assemble_tiled.hip)
-  int32_t *pl_rowptr = nullptr, *pl_rows = nullptr, *pl_eptr = nullptr, *pl_elem = nullptr;
-  void *pl_rowslot4 = nullptr, *pl_kmap4 = nullptr;
-  uint8_t* pl_colbc = nullptr;   // per CSR entry: column imposed (follows bc_stamp)
-  int64_t pl_colbc_stamp = -1;
-  int pl_npatch = 0, pl_maxrows = 0, pl_maxlen = 0;
-  int64_t pl_npe = 0;
+  // patch plans of the tiled assemblies (pyn_assemble_tiled.hip): [0] scalar forms, [1] KLE (3x3 blocks)
+  PatchPlan plan[2];
 
   // SELL-64 structures, one per block shape, + the node-level column-pattern dictionary (pyn_sell.hip)
   std::vector<SellShape> sell_shapes;

@@ -98,7 +98,8 @@ extern "C" int pyn_csr_symbolic(pyn_ctx* c) {
   PYN_HIP(hipFree(d_nuniq));
   c->nnzb = nuniq;
   // the patch plan and all matrices are tied to the graph
-  PYN_TRY(pyn_patch_plan_set(c, 0, nullptr, nullptr));
+  PYN_TRY(pyn_patch_plan_set_kind(c, 0, 0, nullptr, nullptr));
+  PYN_TRY(pyn_patch_plan_set_kind(c, 1, 0, nullptr, nullptr));
   for (auto& m : c->mats) {
     (void)hipFree(m.val);
     (void)hipFree(m.sell_val);

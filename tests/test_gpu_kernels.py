@@ -103,7 +103,13 @@ def test_assemble_kle_vs_oracle(lib, nelem, ngl, jitter, variant):
     ctx = make_ctx(lib, mesh, ngl, bc_ndof=dim, bc_nodes=mesh.boundary)
     K, Krhs, Rw, Rd = (ctx.mat_create(dim, dim), ctx.mat_create(dim, dim), ctx.mat_create(dim, dw),
                        ctx.mat_create(dim, 1))
-    ctx.assemble_kle(1e3, 1e2, K, Krhs, Rw, Rd, variant=variant)
+    if variant == 1 and dim == 3 and ngl == 2:
+        # tiled KLE kernels (K, Krhs, Rw without HBM atomics); Rd goes through the generic kernel
+        ctx.patch_plan_set(*tile_plan(mesh, (4, 3, 3)), kind=1)
+        ctx.assemble_kle(1e3, 1e2, K, Krhs, Rw, -1, variant=1)
+        ctx.assemble_kle(1e3, 1e2, -1, -1, -1, Rd, variant=0)
+    else:
+        ctx.assemble_kle(1e3, 1e2, K, Krhs, Rw, Rd, variant=variant)
     ref = fo.assemble_kle_freeslip(mesh, fo.Tables(ngl, dim), with_rd=True)
     assert sp_rel_err(mat_to_scipy(ctx, K, dim, dim), ref["K"]) < FP_TOL
     assert sp_rel_err(mat_to_scipy(ctx, Krhs, dim, dim), ref["Krhs"]) < FP_TOL
@@ -167,6 +173,62 @@ def test_assemble_tiled_scattered_patches(lib):
     ctx.assemble_scalar(lib.FORM_LAPLACE, A, Arhs, variant=1)
     assert sp_rel_err(mat_to_scipy(ctx, A, 1, 1), ref["A"]) < FP_TOL
     assert sp_rel_err(mat_to_scipy(ctx, Arhs, 1, 1), ref["Arhs"]) < FP_TOL
+    ctx.close()
+
+
+@pytest.mark.parametrize("kind", ["jitter", "uniform", "nobc", "partial_bc"])
+def test_assemble_kle_tiled_variants(lib, kind):
+    """tiled KLE kernels: general + affine geometry, no mask, per-component masks (normal DOFs only),
+    K without Krhs; scattered patches"""
+    mesh = fo.box_mesh([7, 6, 5], [0, 0, 0], [1.0, 0.9, 1.1], 2, jitter=0.0 if kind == "uniform" else 0.2)
+    from pynama_amd.elements.spectral import Spectral
+    ctx = lib.Context(0)
+    ctx.mesh_set(3, mesh.conn, mesh.xyz)
+    for t in Spectral(2, 3).deviceTables():
+        ctx.tables_set(*t)
+    mask = np.zeros((mesh.n_node, 3), np.uint8)
+    if kind in ("jitter", "uniform"):
+        mask[mesh.boundary] = 1
+    elif kind == "partial_bc":                       # only the normal component on each border
+        for name, (d, _) in {"back": (2, 0), "front": (2, 1), "down": (1, 0), "up": (1, 1), "right": (0, 1), "left": (0, 0)}.items():
+            mask[mesh.borders[name], d] = 1
+    if kind != "nobc":
+        ctx.bc_set(3, mask)
+    ctx.csr_symbolic()
+    rng = np.random.default_rng(1)
+    rows = rng.permutation(mesh.n_node).astype(np.int32)
+    ptr = np.arange(0, mesh.n_node + 30, 30).astype(np.int32)
+    ptr[-1] = mesh.n_node
+    ctx.patch_plan_set(ptr, rows, kind=1)
+    K, Krhs, Rw = ctx.mat_create(3, 3), ctx.mat_create(3, 3), ctx.mat_create(3, 3)
+    ctx.assemble_kle(1e3, 1e2, K, Krhs, Rw, -1, variant=1)
+    # oracle with the same per-DOF mask
+    tb = fo.Tables(2, 3)
+    Ke, Rwe, _ = fo.elem_kle_matrices(tb, mesh.corners())
+    import scipy.sparse as sps
+    vdof = fo.dof_indices(mesh.conn, 3)
+    is_bc = mask.ravel().astype(bool)
+    rfree, cbc = ~is_bc[vdof], is_bc[vdof]
+    R = np.broadcast_to(vdof[:, :, None], Ke.shape)
+    Cc = np.broadcast_to(vdof[:, None, :], Ke.shape)
+    mff = rfree[:, :, None] & rfree[:, None, :]
+    mfb = rfree[:, :, None] & cbc[:, None, :]
+    n3 = mesh.n_node * 3
+    ident = sps.coo_matrix((np.ones(is_bc.sum()), (np.nonzero(is_bc)[0],) * 2), shape=(n3, n3)).tocsr()
+    Kref = sps.coo_matrix((Ke[mff], (R[mff], Cc[mff])), shape=(n3, n3)).tocsr() + ident
+    Krref = sps.coo_matrix((-Ke[mfb], (R[mfb], Cc[mfb])), shape=(n3, n3)).tocsr() + ident
+    mr = np.broadcast_to(rfree[:, :, None], Rwe.shape)
+    Rwref = sps.coo_matrix((Rwe[mr], (np.broadcast_to(vdof[:, :, None], Rwe.shape)[mr],
+                                      np.broadcast_to(vdof[:, None, :], Rwe.shape)[mr])), shape=(n3, n3)).tocsr()
+    assert sp_rel_err(mat_to_scipy(ctx, K, 3, 3), Kref) < FP_TOL
+    assert sp_rel_err(mat_to_scipy(ctx, Krhs, 3, 3), Krref) < FP_TOL
+    assert sp_rel_err(mat_to_scipy(ctx, Rw, 3, 3), Rwref) < FP_TOL
+    # generic kernel agrees too (same per-DOF routing), and K alone (no Krhs / Rw) works
+    K2 = ctx.mat_create(3, 3)
+    ctx.assemble_kle(1e3, 1e2, K2, -1, -1, -1, variant=1)
+    assert sp_rel_err(mat_to_scipy(ctx, K2, 3, 3), Kref) < FP_TOL
+    ctx.assemble_kle(1e3, 1e2, K2, -1, -1, -1, variant=0)
+    assert sp_rel_err(mat_to_scipy(ctx, K2, 3, 3), Kref) < FP_TOL
     ctx.close()
 
 
