@@ -762,32 +762,30 @@ extern "C" int pyn_patch_plan_set_kind(pyn_ctx* c, int kind, int n_patch, const 
   PYN_HIP(hipMalloc((void**)&P.rows, c->n_owned * sizeof(int32_t)));
   PYN_HIP(hipMemcpyAsync(P.rowptr, patch_ptr, (n_patch + 1) * sizeof(int32_t), hipMemcpyHostToDevice, s));
   PYN_HIP(hipMemcpyAsync(P.rows, patch_rows, c->n_owned * sizeof(int32_t), hipMemcpyHostToDevice, s));
-  int32_t *node2patch = nullptr, *node2slot = nullptr;
-  PYN_HIP(hipMalloc((void**)&node2patch, c->n_owned * sizeof(int32_t)));
-  PYN_HIP(hipMalloc((void**)&node2slot, c->n_owned * sizeof(int32_t)));
+  DevTmp t_n2p, t_n2s, t_k0, t_k1, t_npe, t_tmp, t_cnt;  // scratch, released on every exit path
+  PYN_HIP(t_n2p.alloc(c->n_owned * sizeof(int32_t)));
+  PYN_HIP(t_n2s.alloc(c->n_owned * sizeof(int32_t)));
+  int32_t *node2patch = t_n2p.as<int32_t>(), *node2slot = t_n2s.as<int32_t>();
   plan_node_maps_kernel<<<std::min(n_patch, 65536), 256, 0, s>>>(P.rowptr, P.rows, n_patch, node2patch, node2slot);
   const int64_t nk = c->n_elem * c->nn;
-  unsigned long long *k0 = nullptr, *k1 = nullptr;
-  int64_t* d_npe = nullptr;
-  PYN_HIP(hipMalloc((void**)&k0, nk * sizeof(unsigned long long)));
-  PYN_HIP(hipMalloc((void**)&k1, nk * sizeof(unsigned long long)));
-  PYN_HIP(hipMalloc((void**)&d_npe, sizeof(int64_t)));
+  PYN_HIP(t_k0.alloc(nk * sizeof(unsigned long long)));
+  PYN_HIP(t_k1.alloc(nk * sizeof(unsigned long long)));
+  PYN_HIP(t_npe.alloc(sizeof(int64_t)));
+  unsigned long long *k0 = t_k0.as<unsigned long long>(), *k1 = t_k1.as<unsigned long long>();
+  int64_t* d_npe = t_npe.as<int64_t>();
   int grid = (int)std::min<int64_t>((c->n_elem + 255) / 256, 65536);
   plan_emit_kernel<<<grid, 256, 0, s>>>(c->d_conn, c->n_elem, c->nn, c->n_owned, node2patch, k0);
   size_t tb = 0;
-  void* tmp = nullptr;
   PYN_HIP(hipcub::DeviceRadixSort::SortKeys(nullptr, tb, k0, k1, nk, 0, 64, s));
-  PYN_HIP(hipMalloc(&tmp, tb));
-  PYN_HIP(hipcub::DeviceRadixSort::SortKeys(tmp, tb, k0, k1, nk, 0, 64, s));
+  PYN_HIP(t_tmp.alloc(tb));
+  PYN_HIP(hipcub::DeviceRadixSort::SortKeys(t_tmp.p, tb, k0, k1, nk, 0, 64, s));
   plan_count_valid_kernel<<<1, 1, 0, s>>>(k1, nk, d_npe);
   int64_t npe = 0;
   PYN_HIP(hipMemcpyAsync(&npe, d_npe, sizeof(int64_t), hipMemcpyDeviceToHost, s));
   PYN_HIP(hipStreamSynchronize(s));
-  PYN_HIP(hipFree(tmp));
-  tmp = nullptr;
   PYN_CHECK(npe > 0 && npe < (int64_t)INT32_MAX, "bad patch-element count %lld", (long long)npe);
-  int32_t* ecount = nullptr;
-  PYN_HIP(hipMalloc((void**)&ecount, (n_patch + 1) * sizeof(int32_t)));
+  PYN_HIP(t_cnt.alloc((n_patch + 1) * sizeof(int32_t)));
+  int32_t* ecount = t_cnt.as<int32_t>();
   PYN_HIP(hipMemsetAsync(ecount, 0, (n_patch + 1) * sizeof(int32_t), s));
   PYN_HIP(hipMalloc((void**)&P.eptr, (n_patch + 1) * sizeof(int32_t)));
   PYN_HIP(hipMalloc((void**)&P.elem, npe * sizeof(int32_t)));
@@ -798,21 +796,15 @@ extern "C" int pyn_patch_plan_set_kind(pyn_ctx* c, int kind, int n_patch, const 
                                         P.elem, ecount, (uint4*)P.rowslot4, (uint4*)P.kmap4);
   tb = 0;
   PYN_HIP(hipcub::DeviceScan::ExclusiveSum(nullptr, tb, ecount, P.eptr, n_patch + 1, s));
-  PYN_HIP(hipMalloc(&tmp, tb));
-  PYN_HIP(hipcub::DeviceScan::ExclusiveSum(tmp, tb, ecount, P.eptr, n_patch + 1, s));
+  PYN_HIP(hipStreamSynchronize(s));
+  PYN_HIP(t_tmp.alloc(tb));
+  PYN_HIP(hipcub::DeviceScan::ExclusiveSum(t_tmp.p, tb, ecount, P.eptr, n_patch + 1, s));
   // max row length of the graph (LDS row stride)
   std::vector<int32_t> rp((size_t)c->n_owned + 1);
   PYN_HIP(hipMemcpyAsync(rp.data(), c->d_rowptr, (c->n_owned + 1) * sizeof(int32_t), hipMemcpyDeviceToHost, s));
   PYN_HIP(hipStreamSynchronize(s));
   int maxlen = 0;
   for (int64_t i = 0; i < c->n_owned; ++i) maxlen = std::max(maxlen, rp[i + 1] - rp[i]);
-  PYN_HIP(hipFree(tmp));
-  PYN_HIP(hipFree(ecount));
-  PYN_HIP(hipFree(k0));
-  PYN_HIP(hipFree(k1));
-  PYN_HIP(hipFree(d_npe));
-  PYN_HIP(hipFree(node2patch));
-  PYN_HIP(hipFree(node2slot));
   P.npatch = n_patch;
   P.npe = npe;
   P.maxrows = max_rows;

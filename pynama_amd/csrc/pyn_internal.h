@@ -44,6 +44,26 @@ void pyn_set_error(const char* fmt, ...);
     if (rc_ != PYN_OK) return rc_;                                                            \
   } while (0)
 
+// scratch device allocation released on every exit path of a set-up routine
+struct DevTmp {
+  void* p = nullptr;
+  DevTmp() = default;
+  DevTmp(const DevTmp&) = delete;
+  DevTmp& operator=(const DevTmp&) = delete;
+  ~DevTmp() {
+    if (p) (void)hipFree(p);
+  }
+  hipError_t alloc(size_t bytes) {
+    if (p) (void)hipFree(p);
+    p = nullptr;
+    return bytes ? hipMalloc(&p, bytes) : hipSuccess;
+  }
+  template <typename T>
+  T* as() const {
+    return static_cast<T*>(p);
+  }
+};
+
 struct QuadTab {
   int ngp = 0;
   double* w = nullptr;       // [ngp]

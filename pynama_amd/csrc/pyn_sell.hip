@@ -313,62 +313,49 @@ static int build_pattern_dictionary(pyn_ctx* c, int maxw) {
   if (maxw > PAT_W || getenv("PYNAMA_NO_PATTERNS")) return PYN_OK;
   hipStream_t s = c->stream;
   const int64_t n = c->n_owned;
-  unsigned long long *h = nullptr, *hs = nullptr, *hu = nullptr;
-  int64_t* d_nu = nullptr;
-  void* tmp = nullptr;
-  PYN_HIP(hipMalloc((void**)&h, n * sizeof(unsigned long long)));
-  PYN_HIP(hipMalloc((void**)&hs, n * sizeof(unsigned long long)));
-  PYN_HIP(hipMalloc((void**)&hu, n * sizeof(unsigned long long)));
-  PYN_HIP(hipMalloc((void**)&d_nu, sizeof(int64_t)));
+  DevTmp t_h, t_hs, t_hu, t_nu, t_tmp, t_rep, t_len, t_bad;  // scratch, released on every exit path
+  PYN_HIP(t_h.alloc(n * sizeof(unsigned long long)));
+  PYN_HIP(t_hs.alloc(n * sizeof(unsigned long long)));
+  PYN_HIP(t_hu.alloc(n * sizeof(unsigned long long)));
+  PYN_HIP(t_nu.alloc(sizeof(int64_t)));
+  unsigned long long *h = t_h.as<unsigned long long>(), *hs = t_hs.as<unsigned long long>(), *hu = t_hu.as<unsigned long long>();
+  int64_t* d_nu = t_nu.as<int64_t>();
   const int grid = (int)std::min<int64_t>((n + 255) / 256, 16384);
   pat_hash_kernel<<<grid, 256, 0, s>>>(c->d_rowptr, c->d_colidx, n, h);
   size_t tb = 0;
   PYN_HIP(hipcub::DeviceRadixSort::SortKeys(nullptr, tb, h, hs, n, 0, 64, s));
-  PYN_HIP(hipMalloc(&tmp, tb));
-  PYN_HIP(hipcub::DeviceRadixSort::SortKeys(tmp, tb, h, hs, n, 0, 64, s));
-  PYN_HIP(hipFree(tmp));
-  tmp = nullptr;
+  PYN_HIP(t_tmp.alloc(tb));
+  PYN_HIP(hipcub::DeviceRadixSort::SortKeys(t_tmp.p, tb, h, hs, n, 0, 64, s));
   tb = 0;
   PYN_HIP(hipcub::DeviceSelect::Unique(nullptr, tb, hs, hu, d_nu, n, s));
-  PYN_HIP(hipMalloc(&tmp, tb));
-  PYN_HIP(hipcub::DeviceSelect::Unique(tmp, tb, hs, hu, d_nu, n, s));
+  PYN_HIP(hipStreamSynchronize(s));
+  PYN_HIP(t_tmp.alloc(tb));
+  PYN_HIP(hipcub::DeviceSelect::Unique(t_tmp.p, tb, hs, hu, d_nu, n, s));
   int64_t nu = 0;
   PYN_HIP(hipMemcpyAsync(&nu, d_nu, sizeof(int64_t), hipMemcpyDeviceToHost, s));
   PYN_HIP(hipStreamSynchronize(s));
-  PYN_HIP(hipFree(tmp));
-  bool ok = nu >= 1 && nu <= PAT_MAX;
-  if (ok) {
-    int32_t *rep = nullptr, *tlen = nullptr;
-    int* bad = nullptr;
-    PYN_HIP(hipMalloc((void**)&c->sell_pid, n * sizeof(int32_t)));
-    PYN_HIP(hipMalloc((void**)&c->sell_tab, (size_t)PAT_MAX * PAT_W * sizeof(int32_t)));
-    PYN_HIP(hipMalloc((void**)&rep, PAT_MAX * sizeof(int32_t)));
-    PYN_HIP(hipMalloc((void**)&tlen, PAT_MAX * sizeof(int32_t)));
-    PYN_HIP(hipMalloc((void**)&bad, sizeof(int)));
-    PYN_HIP(hipMemsetAsync(bad, 0, sizeof(int), s));
-    PYN_HIP(hipMemsetAsync(c->sell_tab, 0, (size_t)PAT_MAX * PAT_W * sizeof(int32_t), s));
-    pat_assign_kernel<<<grid, 256, 0, s>>>(h, n, hu, (int)nu, c->sell_pid, rep);
-    pat_table_kernel<<<(int)nu, 64, 0, s>>>(c->d_rowptr, c->d_colidx, rep, (int)nu, c->sell_tab, tlen);
-    pat_verify_kernel<<<grid, 256, 0, s>>>(c->d_rowptr, c->d_colidx, n, c->sell_pid, c->sell_tab, tlen, bad);
-    int hbad = 0;
-    PYN_HIP(hipMemcpyAsync(&hbad, bad, sizeof(int), hipMemcpyDeviceToHost, s));
-    PYN_HIP(hipStreamSynchronize(s));
-    PYN_HIP(hipFree(rep));
-    PYN_HIP(hipFree(tlen));
-    PYN_HIP(hipFree(bad));
-    ok = hbad == 0;  // a hash collision would show up here: fall back to explicit columns
-    if (!ok) {
-      PYN_HIP(hipFree(c->sell_pid));
-      PYN_HIP(hipFree(c->sell_tab));
-      c->sell_pid = nullptr;
-      c->sell_tab = nullptr;
-    }
+  if (nu < 1 || nu > PAT_MAX) return PYN_OK;  // irregular numbering: explicit columns
+  PYN_HIP(hipMalloc((void**)&c->sell_pid, n * sizeof(int32_t)));
+  PYN_HIP(hipMalloc((void**)&c->sell_tab, (size_t)PAT_MAX * PAT_W * sizeof(int32_t)));
+  PYN_HIP(t_rep.alloc(PAT_MAX * sizeof(int32_t)));
+  PYN_HIP(t_len.alloc(PAT_MAX * sizeof(int32_t)));
+  PYN_HIP(t_bad.alloc(sizeof(int)));
+  PYN_HIP(hipMemsetAsync(t_bad.p, 0, sizeof(int), s));
+  PYN_HIP(hipMemsetAsync(c->sell_tab, 0, (size_t)PAT_MAX * PAT_W * sizeof(int32_t), s));
+  pat_assign_kernel<<<grid, 256, 0, s>>>(h, n, hu, (int)nu, c->sell_pid, t_rep.as<int32_t>());
+  pat_table_kernel<<<(int)nu, 64, 0, s>>>(c->d_rowptr, c->d_colidx, t_rep.as<int32_t>(), (int)nu, c->sell_tab, t_len.as<int32_t>());
+  pat_verify_kernel<<<grid, 256, 0, s>>>(c->d_rowptr, c->d_colidx, n, c->sell_pid, c->sell_tab, t_len.as<int32_t>(), t_bad.as<int>());
+  int hbad = 0;
+  PYN_HIP(hipMemcpyAsync(&hbad, t_bad.p, sizeof(int), hipMemcpyDeviceToHost, s));
+  PYN_HIP(hipStreamSynchronize(s));
+  if (hbad != 0) {  // a hash collision shows up here: fall back to explicit columns
+    PYN_HIP(hipFree(c->sell_pid));
+    PYN_HIP(hipFree(c->sell_tab));
+    c->sell_pid = nullptr;
+    c->sell_tab = nullptr;
+    return PYN_OK;
   }
-  PYN_HIP(hipFree(h));
-  PYN_HIP(hipFree(hs));
-  PYN_HIP(hipFree(hu));
-  PYN_HIP(hipFree(d_nu));
-  c->sell_npat = ok ? (int)nu : 0;
+  c->sell_npat = (int)nu;
   return PYN_OK;
 }
 

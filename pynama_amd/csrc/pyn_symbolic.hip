@@ -38,45 +38,40 @@ extern "C" int pyn_csr_symbolic(pyn_ctx* c) {
   hipStream_t s = c->stream;
   PYN_HIP(hipEventRecord(c->ev0, s));
   const int64_t total = c->n_elem * c->nn * c->nn;
-  unsigned long long *k0 = nullptr, *k1 = nullptr;
-  int64_t* d_nuniq = nullptr;
-  void* tmp = nullptr;
-  PYN_HIP(hipMalloc((void**)&k0, total * sizeof(unsigned long long)));
-  PYN_HIP(hipMalloc((void**)&k1, total * sizeof(unsigned long long)));
-  PYN_HIP(hipMalloc((void**)&d_nuniq, sizeof(int64_t)));
+  DevTmp tk0, tk1, tn, tmp, tcnt;
+  PYN_HIP(tk0.alloc(total * sizeof(unsigned long long)));
+  PYN_HIP(tk1.alloc(total * sizeof(unsigned long long)));
+  PYN_HIP(tn.alloc(sizeof(int64_t)));
+  unsigned long long *k0 = tk0.as<unsigned long long>(), *k1 = tk1.as<unsigned long long>();
+  int64_t* d_nuniq = tn.as<int64_t>();
   int grid = (int)std::min<int64_t>((total + 255) / 256, 65536);
   emit_pairs_kernel<<<grid, 256, 0, s>>>(c->d_conn, c->n_elem, c->nn, c->n_owned, k0);
-
-  int row_bits = 1;
-  while ((1ll << row_bits) <= c->n_owned) ++row_bits;
-  int end_bit = 64;  // invalid keys are all-ones: must sort over the full width to keep them last
-  (void)row_bits;
+  // invalid keys (rows of other ranks) are all-ones: sort over the full width keeps them last
   size_t tb = 0;
-  PYN_HIP(hipcub::DeviceRadixSort::SortKeys(nullptr, tb, k0, k1, total, 0, end_bit, s));
-  PYN_HIP(hipMalloc(&tmp, tb));
-  PYN_HIP(hipcub::DeviceRadixSort::SortKeys(tmp, tb, k0, k1, total, 0, end_bit, s));
-  PYN_HIP(hipFree(tmp));
-  tmp = nullptr;
+  PYN_HIP(hipcub::DeviceRadixSort::SortKeys(nullptr, tb, k0, k1, total, 0, 64, s));
+  PYN_HIP(tmp.alloc(tb));
+  PYN_HIP(hipcub::DeviceRadixSort::SortKeys(tmp.p, tb, k0, k1, total, 0, 64, s));
   tb = 0;
   PYN_HIP(hipcub::DeviceSelect::Unique(nullptr, tb, k1, k0, d_nuniq, total, s));
-  PYN_HIP(hipMalloc(&tmp, tb));
-  PYN_HIP(hipcub::DeviceSelect::Unique(tmp, tb, k1, k0, d_nuniq, total, s));
+  PYN_HIP(hipStreamSynchronize(s));
+  PYN_HIP(tmp.alloc(tb));
+  PYN_HIP(hipcub::DeviceSelect::Unique(tmp.p, tb, k1, k0, d_nuniq, total, s));
   int64_t nuniq = 0;
   unsigned long long last = 0;
   PYN_HIP(hipMemcpyAsync(&nuniq, d_nuniq, sizeof(int64_t), hipMemcpyDeviceToHost, s));
   PYN_HIP(hipStreamSynchronize(s));
+  PYN_CHECK(nuniq > 0, "empty pattern");
   PYN_HIP(hipMemcpy(&last, k0 + (nuniq - 1), sizeof(last), hipMemcpyDeviceToHost));
   if (last == ~0ull) --nuniq;  // the dropped (non-owned) rows
-  PYN_HIP(hipFree(tmp));
-  tmp = nullptr;
   PYN_CHECK(nuniq > 0 && nuniq < (int64_t)INT32_MAX, "pattern has %lld entries (int32 CSR limit)", (long long)nuniq);
 
   (void)hipFree(c->d_rowptr);
   (void)hipFree(c->d_colidx);
   c->d_rowptr = nullptr;
   c->d_colidx = nullptr;
-  int32_t* rowcnt = nullptr;
-  PYN_HIP(hipMalloc((void**)&rowcnt, (c->n_owned + 1) * sizeof(int32_t)));
+  c->nnzb = 0;
+  PYN_HIP(tcnt.alloc((c->n_owned + 1) * sizeof(int32_t)));
+  int32_t* rowcnt = tcnt.as<int32_t>();
   PYN_HIP(hipMalloc((void**)&c->d_rowptr, (c->n_owned + 1) * sizeof(int32_t)));
   PYN_HIP(hipMalloc((void**)&c->d_colidx, nuniq * sizeof(int32_t)));
   PYN_HIP(hipMemsetAsync(rowcnt, 0, (c->n_owned + 1) * sizeof(int32_t), s));
@@ -84,20 +79,16 @@ extern "C" int pyn_csr_symbolic(pyn_ctx* c) {
   split_keys_kernel<<<grid, 256, 0, s>>>(k0, nuniq, c->d_colidx, rowcnt);
   tb = 0;
   PYN_HIP(hipcub::DeviceScan::ExclusiveSum(nullptr, tb, rowcnt, c->d_rowptr, (int)(c->n_owned + 1), s));
-  PYN_HIP(hipMalloc(&tmp, tb));
-  PYN_HIP(hipcub::DeviceScan::ExclusiveSum(tmp, tb, rowcnt, c->d_rowptr, (int)(c->n_owned + 1), s));
+  PYN_HIP(hipStreamSynchronize(s));
+  PYN_HIP(tmp.alloc(tb));
+  PYN_HIP(hipcub::DeviceScan::ExclusiveSum(tmp.p, tb, rowcnt, c->d_rowptr, (int)(c->n_owned + 1), s));
   PYN_HIP(hipEventRecord(c->ev1, s));
   PYN_HIP(hipStreamSynchronize(s));
   float ms = 0;
   PYN_HIP(hipEventElapsedTime(&ms, c->ev0, c->ev1));
   c->timers[PYN_T_SYMBOLIC] = ms;
-  PYN_HIP(hipFree(tmp));
-  PYN_HIP(hipFree(rowcnt));
-  PYN_HIP(hipFree(k0));
-  PYN_HIP(hipFree(k1));
-  PYN_HIP(hipFree(d_nuniq));
   c->nnzb = nuniq;
-  // the patch plan and all matrices are tied to the graph
+  // the patch plans, the SELL structures and all matrices are tied to the graph
   PYN_TRY(pyn_patch_plan_set_kind(c, 0, 0, nullptr, nullptr));
   PYN_TRY(pyn_patch_plan_set_kind(c, 1, 0, nullptr, nullptr));
   for (auto& m : c->mats) {
