@@ -153,7 +153,8 @@ int pyn_vec_norm(pyn_ctx* ctx, int x, int type /*1, 2, 3=inf (PETSc NormType)*/,
  * (mat_generator.py:113-118).  Matrices are zeroed first.  Any id may be -1 (skipped).
  *   K   [dim,dim]  += K_e[free,free]         Krhs[dim,dim] += -K_e[free,bc]
  *   Rw  [dim,dim_w]+= Rw_e[free,:]           Rd  [dim,1]   += Rd_e[free,:]
- * variant: 0 = wave-per-element + FP64 atomics (any mesh), 1 = auto (fastest available). */
+ * variant: 0 = workgroup-per-element + FP64 atomics (any mesh, any ngl), 1 = auto: the tiled atomics-free
+ * kernels for Q1 hexahedra (with the caller's patch plan, else patches of consecutive rows), else 0. */
 int pyn_assemble_kle(pyn_ctx* ctx, double alpha_d, double alpha_w, int K, int Krhs, int Rw, int Rd,
                      int variant);
 /* Scalar forms with the same elimination rule: A[1,1] += A_e[free,free], Arhs += -A_e[free,bc]. */

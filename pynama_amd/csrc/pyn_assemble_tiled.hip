@@ -875,8 +875,23 @@ static int assemble_kle_tiled(pyn_ctx* c, double alpha_d, double alpha_w, double
   return PYN_OK;
 }
 
+// Meshes without a caller-supplied plan get patches of consecutive rows: optimal for no numbering in
+// particular, but any partition is valid and even 8x redundant integration beats the HBM-atomic scatter.
+static int ensure_default_plan(pyn_ctx* c, int kind) {
+  if (c->plan[kind].npatch || c->dim != 3 || c->nn != 8 || getenv("PYNAMA_NO_AUTO_PLAN")) return PYN_OK;
+  const int chunk = kind == 0 ? 343 : 27;
+  const int64_t n = c->n_owned;
+  const int np = (int)((n + chunk - 1) / chunk);
+  std::vector<int32_t> ptr((size_t)np + 1), rows((size_t)n);
+  for (int p = 0; p <= np; ++p) ptr[p] = (int32_t)std::min<int64_t>((int64_t)p * chunk, n);
+  for (int64_t i = 0; i < n; ++i) rows[i] = (int32_t)i;
+  return pyn_patch_plan_set_kind(c, kind, np, ptr.data(), rows.data());
+}
+
 int pyn_assemble_q1_tiled(pyn_ctx* c, int form, double alpha_d, double alpha_w, double* K, double* Krhs, double* Rw, double* Rd, bool* handled) {
   *handled = false;
+  if (form == PYN_FORM_KLE && K && !Rd) PYN_TRY(ensure_default_plan(c, 1));
+  if (form == PYN_FORM_LAPLACE && K && !Rw && !Rd) PYN_TRY(ensure_default_plan(c, 0));
   if (form == PYN_FORM_KLE && K && !Rd) return assemble_kle_tiled(c, alpha_d, alpha_w, K, Krhs, Rw, handled);
   PatchPlan& P = c->plan[0];
   if (!P.npatch || form != PYN_FORM_LAPLACE || !K || Rw || Rd) return PYN_OK;

@@ -434,10 +434,12 @@ def test_random_node_numbering_falls_back_to_explicit_columns(lib):
     rp_o, ci_o = fo.node_graph(mesh)
     assert np.array_equal(rp, rp_o) and np.array_equal(ci, ci_o)
     A = ctx.mat_create(1, 1)
-    ctx.assemble_scalar(lib.FORM_LAPLACE, A)
+    ctx.assemble_scalar(lib.FORM_LAPLACE, A)            # variant auto: tiled kernel on the default plan
     ref = fo.assemble_scalar(mesh, fo.Tables(2, 3), "laplace", dirichlet=mesh.boundary)
     S = mat_to_scipy(ctx, A, 1, 1)
     assert sp_rel_err(S, ref["A"]) < FP_TOL
+    ctx.assemble_scalar(lib.FORM_LAPLACE, A, variant=0)  # HBM-atomic kernel
+    assert sp_rel_err(mat_to_scipy(ctx, A, 1, 1), ref["A"]) < FP_TOL
     b = rng.standard_normal(mesh.n_node)
     b[mesh.boundary] = 0
     vb, vx, vy = ctx.vec_create(1), ctx.vec_create(1), ctx.vec_create(1)
