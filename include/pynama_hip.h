@@ -157,6 +157,14 @@ int pyn_vec_norm(pyn_ctx* ctx, int x, int type /*1, 2, 3=inf (PETSc NormType)*/,
  * kernels for Q1 hexahedra (with the caller's patch plan, else patches of consecutive rows), else 0. */
 int pyn_assemble_kle(pyn_ctx* ctx, double alpha_d, double alpha_w, int K, int Krhs, int Rw, int Rd,
                      int variant);
+/* No-slip / free-slip split of the same pass (NoSlipFreeSlip.buildKLEMats, src/cases/base_problem.py:
+ * 329-454; MatNS, src/matrices/mat_ns.py:17-121).  pyn_bc_set(dim, cls) holds a CLASS per velocity DOF:
+ * 0 free, 1 tangential DOF at a no-slip wall (free in the free-slip solve, imposed in the final one),
+ * 2 imposed in both.  mat_ids[8] = K, Krhs, Rw, Rd, Kfs, Krhsfs, Rwfs, Rdfs (-1 = skipped):
+ *   K[0,0] += v        Krhs[0,{1,2}] += -v       Rw[0,:], Rd[0,:]          unit diagonal on classes 1, 2
+ *   Kfs[1,{0,1}] , Kfs[0,1] += v  (diag -1 on class 1)      Krhsfs[{0,1},2] += -v  (diag 1 on class 2)
+ *   Rwfs[1,:], Rdfs[1,:] */
+int pyn_assemble_kle_noslip(pyn_ctx* ctx, double alpha_d, double alpha_w, const int* mat_ids);
 /* Scalar forms with the same elimination rule: A[1,1] += A_e[free,free], Arhs += -A_e[free,bc]. */
 int pyn_assemble_scalar(pyn_ctx* ctx, int form, int A, int Arhs, int variant);
 /* Single-element entry used for fixture parity: runs the SAME device element routine on one

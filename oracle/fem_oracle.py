@@ -459,6 +459,62 @@ def assemble_kle_freeslip(mesh: BoxMesh, tb: Tables, alpha_d=1e3, alpha_w=1e2, w
     return out
 
 
+def noslip_classes(mesh: BoxMesh, ns_walls, dir_walls=()):
+    """DOF classes of NoSlipFreeSlip.buildKLEMats (base_problem.py:343-379) on a box mesh:
+    0 free; 1 tangential DOF of a node on a no-slip wall (dofFreeFSSetNS); 2 imposed in both solves
+    (dofSetFSNS: the wall-normal DOF of a no-slip node, every DOF of a Dirichlet-wall node)."""
+    axis = ({"down": 1, "up": 1, "left": 0, "right": 0} if mesh.dim == 2 else
+            {"back": 2, "front": 2, "down": 1, "up": 1, "left": 0, "right": 0})
+    cls = np.zeros((mesh.n_node, mesh.dim), dtype=np.uint8)
+    for w in ns_walls:
+        nodes = mesh.borders[w]
+        tang = [d for d in range(mesh.dim) if d != axis[w]]
+        for d in tang:
+            cls[nodes, d] = np.maximum(cls[nodes, d], 1)
+        cls[nodes, axis[w]] = 2
+    for w in dir_walls:
+        cls[mesh.borders[w], :] = 2
+    return cls
+
+
+def assemble_kle_noslip(mesh: BoxMesh, tb: Tables, cls, alpha_d=1e3, alpha_w=1e2):
+    """The eight matrices of NoSlipFreeSlip.buildKLEMats (base_problem.py:329-454), single rank,
+    every cell integrated (the reference reuses cell 0's blocks: uniform meshes only, :333-334)."""
+    dim, dw = tb.dim, tb.dim_w
+    Ke, Rwe, Rde = elem_kle_matrices(tb, mesh.corners(), alpha_d, alpha_w)
+    n = mesh.n_node
+    vdof = dof_indices(mesh.conn, dim)
+    wdof = dof_indices(mesh.conn, dw)
+    c = cls.ravel()[vdof]                                          # [E, dim nn] class of each local DOF
+    ci, cj = c[:, :, None], c[:, None, :]
+    R = np.broadcast_to(vdof[:, :, None], Ke.shape)
+    C = np.broadcast_to(vdof[:, None, :], Ke.shape)
+
+    def mat(mask, vals, rows=R, cols=C, shape=(n * dim, n * dim)):
+        mask = np.broadcast_to(mask, vals.shape)
+        return _scatter(shape, rows[mask], cols[mask], vals[mask])
+    idx1 = np.nonzero(cls.ravel() >= 1)[0]
+    idx_fs = np.nonzero(cls.ravel() == 1)[0]
+    idx_set = np.nonzero(cls.ravel() == 2)[0]
+
+    def diag(idx, val):
+        return sp.coo_matrix((np.full(len(idx), val), (idx, idx)), shape=(n * dim, n * dim)).tocsr()
+    out = {}
+    out["K"] = (mat((ci == 0) & (cj == 0), Ke) + diag(idx1, 1.0)).tocsr()                     # :426-430, 439
+    out["Krhs"] = (mat((ci == 0) & (cj >= 1), -Ke) + diag(idx1, 1.0)).tocsr()                 # :388-395, 439
+    out["Kfs"] = (mat(((ci == 1) & (cj <= 1)) | ((ci == 0) & (cj == 1)), Ke) + diag(idx_fs, -1.0)).tocsr()  # :396-407, 441-442
+    out["Krhsfs"] = (mat((ci <= 1) & (cj == 2), -Ke) + diag(idx_set, 1.0)).tocsr()            # :417-424, 449-450
+    Rr = np.broadcast_to(vdof[:, :, None], Rwe.shape)
+    Rc = np.broadcast_to(wdof[:, None, :], Rwe.shape)
+    out["Rw"] = mat(ci == 0, Rwe, Rr, Rc, (n * dim, n * dw))                                  # :432-433
+    out["Rwfs"] = mat(ci == 1, Rwe, Rr, Rc, (n * dim, n * dw))                                # :412-413
+    Dr = np.broadcast_to(vdof[:, :, None], Rde.shape)
+    Dc = np.broadcast_to(mesh.conn[:, None, :], Rde.shape)
+    out["Rd"] = mat(ci == 0, Rde, Dr, Dc, (n * dim, n))                                       # :435-437
+    out["Rdfs"] = mat(ci == 1, Rde, Dr, Dc, (n * dim, n))                                     # :415-416
+    return out
+
+
 def assemble_scalar(mesh: BoxMesh, tb: Tables, form="laplace", dirichlet=None):
     """Scalar operator (BASELINE 'Poisson' = the L_e block) with the SAME elimination rule
     as the KLE path: A[free,free], Arhs[free,bc] = -A_e, unit diagonal on bc rows."""

@@ -16,10 +16,10 @@ __version__ = "0.1.0"
 _SUBPACKAGES = {
     "elements": ("element", "utilities", "spectral"),
     "domain": ("indices", "dmplex"),
-    "matrices": ("mat_generator",),
+    "matrices": ("mat_generator", "mat_ns"),
     "solver": ("ksp_solver",),
-    "common": ("timer",),
-    "cases": ("base_problem", "uniform", "custom_func"),
+    "common": ("timer", "nswalls", "options", "comm"),
+    "cases": ("base_problem", "uniform", "custom_func", "cavity"),
 }
 
 

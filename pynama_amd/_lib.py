@@ -87,6 +87,7 @@ SIGNATURES = {
     "pyn_vec_dot": [_P, _I, _I, C.POINTER(_D)],
     "pyn_vec_norm": [_P, _I, _I, C.POINTER(_D)],
     "pyn_assemble_kle": [_P, _D, _D, _I, _I, _I, _I, _I],
+    "pyn_assemble_kle_noslip": [_P, _D, _D, C.POINTER(_I)],
     "pyn_assemble_scalar": [_P, _I, _I, _I, _I],
     "pyn_elem_local": [_P, _I, _D, _D, _pf64, _P, _P, _P],
     "pyn_assemble_operator": [_P, _I, _I, _pi32, _pf64, _I],
@@ -334,6 +335,10 @@ class Context:
     # -- hot loops
     def assemble_kle(self, alpha_d, alpha_w, K=-1, Krhs=-1, Rw=-1, Rd=-1, variant=1):
         _check(self.lib.pyn_assemble_kle(self.h, alpha_d, alpha_w, K, Krhs, Rw, Rd, variant))
+
+    def assemble_kle_noslip(self, alpha_d, alpha_w, mat_ids):
+        ids = (_I * 8)(*[int(m) for m in mat_ids])
+        _check(self.lib.pyn_assemble_kle_noslip(self.h, alpha_d, alpha_w, ids))
 
     def assemble_scalar(self, form, A=-1, Arhs=-1, variant=1):
         _check(self.lib.pyn_assemble_scalar(self.h, form, A, Arhs, variant))

@@ -37,6 +37,9 @@ struct AsmArgs {
   double alpha_d, alpha_w;
   // outputs (scatter mode) -- null when skipped
   double *K, *Krhs, *Rw, *Rd;
+  // no-slip / free-slip split (NoSlipFreeSlip.buildKLEMats, base_problem.py:329-454): DOF classes in
+  // bcmask are 0 free, 1 tangential at a no-slip wall (free in the FS solve), 2 imposed in both solves
+  double *Kfs, *Krhsfs, *Rwfs, *Rdfs;
   // dense mode
   const double* corners;  // single element
   double *out0, *out1, *out2;
@@ -255,7 +258,7 @@ __global__ void __launch_bounds__(BLOCK) assemble_generic_kernel(AsmArgs A) {
     }
 
     // ---- KLE stiffness K (dim x dim blocks)
-    if (DENSE ? (A.out0 != nullptr) : (A.K != nullptr || A.Krhs != nullptr)) {
+    if (DENSE ? (A.out0 != nullptr) : (A.K != nullptr || A.Krhs != nullptr || A.Kfs != nullptr || A.Krhsfs != nullptr)) {
       for (int t = tid; t < npair * dd; t += BLOCK) {
         int pq = t / npair, ab = t - pq * npair;
         int a = ab / nn, b = ab - a * nn;
@@ -286,19 +289,22 @@ __global__ void __launch_bounds__(BLOCK) assemble_generic_kernel(AsmArgs A) {
           locate(ab, a, b);
           if (r_len < 0) continue;
           int64_t rd = (int64_t)ids[a] * dim + p, cd = (int64_t)ids[b] * dim + q;
-          bool mr = A.bcmask && A.bcmask[rd], mc = A.bcmask && A.bcmask[cd];
-          if (mr) continue;
+          const int ci = A.bcmask ? A.bcmask[rd] : 0, cj = A.bcmask ? A.bcmask[cd] : 0;
           int64_t off = ((int64_t)r_lo * dim + (int64_t)p * r_len + slot) * dim + q;
-          if (mc) {
-            if (A.Krhs) atomicAdd(&A.Krhs[off], -v);
-          } else if (A.K) {
-            atomicAdd(&A.K[off], v);
+          if (ci == 0) {                                   // base_problem.py:426-427 / 388-390
+            if (cj == 0) {
+              if (A.K) atomicAdd(&A.K[off], v);
+            } else if (A.Krhs) {
+              atomicAdd(&A.Krhs[off], -v);
+            }
           }
+          if (A.Kfs && ((ci == 1 && cj <= 1) || (ci == 0 && cj == 1))) atomicAdd(&A.Kfs[off], v);   // :396-407
+          if (A.Krhsfs && ci <= 1 && cj == 2) atomicAdd(&A.Krhsfs[off], -v);                        // :417-422
         }
       }
     }
     // ---- Rw (dim x dim_w blocks)
-    if (DENSE ? (A.out1 != nullptr) : (A.Rw != nullptr)) {
+    if (DENSE ? (A.out1 != nullptr) : (A.Rw != nullptr || A.Rwfs != nullptr)) {
       for (int t = tid; t < npair * dim * dw; t += BLOCK) {
         int pk = t / npair, ab = t - pk * npair;
         int a = ab / nn, b = ab - a * nn;
@@ -331,14 +337,17 @@ __global__ void __launch_bounds__(BLOCK) assemble_generic_kernel(AsmArgs A) {
           locate(ab, a, b);
           if (r_len < 0) continue;
           int64_t rd = (int64_t)ids[a] * dim + p;
-          if (A.bcmask && A.bcmask[rd]) continue;
+          const int ci = A.bcmask ? A.bcmask[rd] : 0;
           int64_t off = ((int64_t)r_lo * dim + (int64_t)p * r_len + slot) * dw + k;
-          if (v != 0.0) atomicAdd(&A.Rw[off], v);
+          if (v != 0.0) {
+            if (ci == 0 && A.Rw) atomicAdd(&A.Rw[off], v);
+            if (ci == 1 && A.Rwfs) atomicAdd(&A.Rwfs[off], v);      // base_problem.py:412-413
+          }
         }
       }
     }
     // ---- Rd (dim x 1 blocks)
-    if (DENSE ? (A.out2 != nullptr) : (A.Rd != nullptr)) {
+    if (DENSE ? (A.out2 != nullptr) : (A.Rd != nullptr || A.Rdfs != nullptr)) {
       for (int t = tid; t < npair * dim; t += BLOCK) {
         int p = t / npair, ab = t - p * npair;
         int a = ab / nn, b = ab - a * nn;
@@ -357,9 +366,10 @@ __global__ void __launch_bounds__(BLOCK) assemble_generic_kernel(AsmArgs A) {
           locate(ab, a, b);
           if (r_len < 0) continue;
           int64_t rd = (int64_t)ids[a] * dim + p;
-          if (A.bcmask && A.bcmask[rd]) continue;
+          const int ci = A.bcmask ? A.bcmask[rd] : 0;
           int64_t off = (int64_t)r_lo * dim + (int64_t)p * r_len + slot;
-          atomicAdd(&A.Rd[off], v);
+          if (ci == 0 && A.Rd) atomicAdd(&A.Rd[off], v);
+          if (ci == 1 && A.Rdfs) atomicAdd(&A.Rdfs[off], v);        // base_problem.py:415-416
         }
       }
     }
@@ -367,12 +377,15 @@ __global__ void __launch_bounds__(BLOCK) assemble_generic_kernel(AsmArgs A) {
 }
 
 // Unit diagonal on imposed DOFs: Mat.setIndices2One (mat_generator.py:113-118), single-rank
-// semantics (diag = 1).  One thread per owned DOF.
+// semantics (diag = 1).  One thread per owned DOF.  With the no-slip split: K, Krhs get 1 on every
+// non-free DOF, Kfs gets -1 on the tangential no-slip DOFs (base_problem.py:441-442) so that K + Kfs
+// keeps only the doubly imposed DOFs eliminated, Krhsfs gets 1 on those (:449-450).
 __global__ void bc_identity_kernel(const int32_t* __restrict__ rowptr, const int32_t* __restrict__ colidx,
                                    const uint8_t* __restrict__ mask, int64_t n_owned, int ndof, double* __restrict__ K,
-                                   double* __restrict__ Krhs) {
+                                   double* __restrict__ Krhs, double* __restrict__ Kfs, double* __restrict__ Krhsfs) {
   for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < n_owned * ndof; t += (int64_t)gridDim.x * blockDim.x) {
-    if (!mask[t]) continue;
+    const int cls = mask[t];
+    if (!cls) continue;
     int64_t i = t / ndof;
     int p = (int)(t - i * ndof);
     int lo = rowptr[i], len = rowptr[i + 1] - lo;
@@ -380,6 +393,8 @@ __global__ void bc_identity_kernel(const int32_t* __restrict__ rowptr, const int
     int64_t off = ((int64_t)lo * ndof + (int64_t)p * len + slot) * ndof + p;
     if (K) K[off] = 1.0;
     if (Krhs) Krhs[off] = 1.0;
+    if (Kfs && cls == 1) Kfs[off] -= 1.0;
+    if (Krhsfs && cls == 2) Krhsfs[off] = 1.0;
   }
 }
 
@@ -410,6 +425,7 @@ int fill_args(pyn_ctx* c, AsmArgs& A, int form) {
   A.form = form;
   A.alpha_d = A.alpha_w = 0.0;
   A.K = A.Krhs = A.Rw = A.Rd = nullptr;
+  A.Kfs = A.Krhsfs = A.Rwfs = A.Rdfs = nullptr;
   A.corners = nullptr;
   A.out0 = A.out1 = A.out2 = nullptr;
   A.gscratch = nullptr;
@@ -494,7 +510,7 @@ static int run_assembly(pyn_ctx* c, int form, double alpha_d, double alpha_w, do
   if (!handled && c->d_bcmask && (K || Krhs)) {
     int64_t n = c->n_owned * ndof;
     int grid = (int)std::min<int64_t>((n + 255) / 256, 4096);
-    bc_identity_kernel<<<grid, 256, 0, c->stream>>>(c->d_rowptr, c->d_colidx, c->d_bcmask, c->n_owned, ndof, K, Krhs);
+    bc_identity_kernel<<<grid, 256, 0, c->stream>>>(c->d_rowptr, c->d_colidx, c->d_bcmask, c->n_owned, ndof, K, Krhs, nullptr, nullptr);
   }
   PYN_HIP(hipEventRecord(c->ev1, c->stream));
   PYN_HIP(hipStreamSynchronize(c->stream));
@@ -514,6 +530,45 @@ extern "C" int pyn_assemble_kle(pyn_ctx* c, double alpha_d, double alpha_w, int 
   PYN_TRY(mat_ptr(c, Rw, dim, dw, "Rw", &pRw));
   PYN_TRY(mat_ptr(c, Rd, dim, 1, "Rd", &pRd));
   return run_assembly(c, PYN_FORM_KLE, alpha_d, alpha_w, pK, pKr, pRw, pRd, variant);
+}
+
+extern "C" int pyn_assemble_kle_noslip(pyn_ctx* c, double alpha_d, double alpha_w, const int* mat_ids /*[8]*/) {
+  PYN_CHECK(c && mat_ids, "NULL argument");
+  PYN_CHECK(c->d_rowptr, "pyn_csr_symbolic first");
+  PYN_CHECK(c->d_bcmask && c->bc_ndof == c->dim, "pyn_bc_set(dim, classes) first: 0 free, 1 tangential no-slip, 2 imposed");
+  PYN_HIP(hipSetDevice(c->device));
+  const int dim = c->dim, dw = dim == 2 ? 1 : 3;
+  const int shapes[8][2] = {{dim, dim}, {dim, dim}, {dim, dw}, {dim, 1}, {dim, dim}, {dim, dim}, {dim, dw}, {dim, 1}};
+  const char* names[8] = {"K", "Krhs", "Rw", "Rd", "Kfs", "Krhsfs", "Rwfs", "Rdfs"};
+  double* ptr[8];
+  for (int k = 0; k < 8; ++k) {
+    PYN_TRY(mat_ptr(c, mat_ids[k], shapes[k][0], shapes[k][1], names[k], &ptr[k]));
+    if (ptr[k]) PYN_HIP(hipMemsetAsync(ptr[k], 0, (size_t)c->nnzb * shapes[k][0] * shapes[k][1] * sizeof(double), c->stream));
+  }
+  AsmArgs A;
+  PYN_TRY(fill_args(c, A, PYN_FORM_KLE));
+  A.bcmask = c->d_bcmask;
+  A.alpha_d = alpha_d;
+  A.alpha_w = alpha_w;
+  A.K = ptr[0];
+  A.Krhs = ptr[1];
+  A.Rw = ptr[2];
+  A.Rd = ptr[3];
+  A.Kfs = ptr[4];
+  A.Krhsfs = ptr[5];
+  A.Rwfs = ptr[6];
+  A.Rdfs = ptr[7];
+  PYN_HIP(hipEventRecord(c->ev0, c->stream));
+  PYN_TRY(launch_generic<false>(c, A, c->n_elem));
+  int64_t n = c->n_owned * dim;
+  int grid = (int)std::min<int64_t>((n + 255) / 256, 4096);
+  bc_identity_kernel<<<grid, 256, 0, c->stream>>>(c->d_rowptr, c->d_colidx, c->d_bcmask, c->n_owned, dim, A.K, A.Krhs, A.Kfs, A.Krhsfs);
+  PYN_HIP(hipEventRecord(c->ev1, c->stream));
+  PYN_HIP(hipStreamSynchronize(c->stream));
+  float ms = 0;
+  PYN_HIP(hipEventElapsedTime(&ms, c->ev0, c->ev1));
+  c->timers[PYN_T_ASSEMBLE] = ms;
+  return PYN_OK;
 }
 
 extern "C" int pyn_assemble_scalar(pyn_ctx* c, int form, int Aid, int Arhs, int variant) {

@@ -123,3 +123,47 @@ def test_curl_operator_exact_on_rotation():
     fem.dom.applyFunctionVecToVec(fem.dom.getAllNodes(), lambda c: (-c[1], c[0]), v, 2)
     w = fem.operator.Curl * v
     assert np.abs(w.getArray() - 2.0).max() < 1e-11
+
+
+def _cavity(**kw):
+    from cases.cavity import Cavity
+    with open(os.path.join(CASES, 'cavity.yaml')) as f:
+        cfg = yaml.load(f, Loader=yaml.Loader)
+    fem = Cavity(cfg, case='cavity', **kw)
+    fem.setUp()
+    fem.setUpSolver()
+    return fem
+
+
+def test_cavity_two_solve_matches_oracle():
+    """NoSlipFreeSlip.solveKLE (base_problem.py:321-327) on the lid-driven cavity: the device two-solve
+    sequence equals the oracle's restatement with direct solves"""
+    import scipy.sparse.linalg as spla
+    from oracle import fem_oracle as fo
+    fem = _cavity(nelem=[8, 8], ngl=2)
+    fem.solveKLE(0.0, fem.vort)
+    v = fem.vel.getArray()
+    mesh = fo.box_mesh([8, 8], [0, 0], [1, 1], 2)
+    tb = fo.Tables(2, 2)
+    cls = fo.noslip_classes(mesh, ["left", "right", "up", "down"])
+    m = fo.assemble_kle_noslip(mesh, tb, cls)
+    ops = fo.assemble_operators(mesh, tb)
+    vel = np.zeros(mesh.n_node * 2)
+    vel[mesh.borders["up"] * 2] = 1.0                                   # lid: x-velocity 1
+    vort = np.zeros(mesh.n_node)
+    velFS = spla.spsolve((m["K"] + m["Kfs"]).tocsc(), m["Rw"] @ vort + m["Rwfs"] @ vort + m["Krhsfs"] @ vel)
+    velFS[mesh.borders["up"] * 2] = 1.0                                  # applyBoundaryConditionsFS
+    for w, d in (("left", 1), ("right", 1), ("down", 0)):
+        velFS[mesh.borders[w] * 2 + d] = 0.0
+    vort2 = ops["Curl"] @ velFS
+    vref = spla.spsolve(m["K"].tocsc(), m["Rw"] @ vort2 + m["Krhs"] @ vel)
+    assert np.abs(v - vref).max() < 1e-8 * max(1.0, np.abs(vref).max())
+    assert np.abs(v[mesh.borders["up"] * 2] - 1.0).max() < 1e-12        # the lid moves, walls hold
+    assert np.abs(v[mesh.borders["down"] * 2]).max() < 1e-12
+
+
+def test_cavity_default_config_runs():
+    fem = _cavity(nelem=[10, 10])                                       # ngl = 3 from the yaml
+    fem.solveKLE(0.0, fem.vort)
+    assert fem.solver.info.true_resid < 1e-9 and fem.solverFS.info.true_resid < 1e-9
+    assert len(fem.cornerDofs) == 8

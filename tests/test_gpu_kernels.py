@@ -521,3 +521,28 @@ def test_operators_global_vs_oracle(lib, nelem, ngl):
         ctx.spmv(m, vx, vy)
         assert rel_err(ctx.vec_get(vy, br), ref[name] @ x) < 1e-12, name
     ctx.close()
+
+
+# ---- no-slip / free-slip split (scope row f2) --------------------------------------------------------
+@pytest.mark.parametrize("nelem,ns,dr", [([6, 5], ["up", "down", "left", "right"], []),
+                                         ([5, 4], ["up", "down"], ["left", "right"]),
+                                         ([4, 3, 3], ["up", "down", "left", "right", "front", "back"], []),
+                                         ([3, 3, 4], ["up", "left"], ["front"])])
+def test_assemble_kle_noslip_vs_oracle(lib, nelem, ns, dr):
+    dim = len(nelem)
+    dw = 1 if dim == 2 else 3
+    mesh = fo.box_mesh(nelem, [0.0] * dim, [1.0, 0.8, 1.2][:dim], 2, jitter=0.15)
+    cls = fo.noslip_classes(mesh, ns, dr)
+    ref = fo.assemble_kle_noslip(mesh, fo.Tables(2, dim), cls)
+    ctx = make_ctx(lib, mesh, 2)
+    ctx.bc_set(dim, cls)
+    shapes = [("K", dim, dim), ("Krhs", dim, dim), ("Rw", dim, dw), ("Rd", dim, 1),
+              ("Kfs", dim, dim), ("Krhsfs", dim, dim), ("Rwfs", dim, dw), ("Rdfs", dim, 1)]
+    ids = [ctx.mat_create(br, bc) for _, br, bc in shapes]
+    ctx.assemble_kle_noslip(1e3, 1e2, ids)
+    for (name, br, bc), mid in zip(shapes, ids):
+        assert sp_rel_err(mat_to_scipy(ctx, mid, br, bc), ref[name]) < FP_TOL, name
+    # K + Kfs is the operator with only the doubly imposed DOFs eliminated (base_problem.py:318)
+    Kff = (ref["K"] + ref["Kfs"]).toarray()
+    assert np.abs(Kff - Kff.T).max() < 1e-9 * np.abs(Kff).max()
+    ctx.close()
