@@ -61,7 +61,7 @@ class BaseProblem(object):
             self.dom = DMPlexDom(boxMesh=meshData, **opts)
         elif "gmsh-file" in domain:
             self.meshType = 'gmsh'
-            self.dom = DMPlexDom(fileName=domain.get('gmsh-file'))
+            self.dom = DMPlexDom(fileName=domain.get('gmsh-file'), comm=self.comm)
         self.dim = self.dom.getDimension()
         self.dim_w = 1 if self.dim == 2 else 3
         self.dim_s = 3 if self.dim == 2 else 6
@@ -94,6 +94,11 @@ class BaseProblem(object):
             self.nelem = kwargs['nelem']
         elif "box-mesh" in domain:
             self.nelem = box['nelem']
+        elif "gmsh-file" in domain:
+            # the reference stops here ("No Gmsh Implemented", base_problem.py:106); dimension and ngl
+            # come from the file in setUpDomain
+            from pynama_amd.domain.gmsh import read_msh
+            self.nelem = [0] * read_msh(domain['gmsh-file'])["dim"]
         else:
             raise Exception("No Gmsh Implemented")
         self.dim = len(self.nelem)

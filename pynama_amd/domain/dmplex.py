@@ -96,7 +96,13 @@ class DMPlexDom(object):
             self.lower = [float(v) for v in lower[:len(self.nelem)]]
             self.upper = [float(v) for v in upper[:len(self.nelem)]]
         elif 'fileName' in kwargs:
-            raise NotImplementedError("Gmsh import (dmplex.py:22-23) is a later scope row (SURVEY.md 8 f4)")
+            # Gmsh quad/hex mesh (dmplex.py:22-23): explicit connectivity, file node numbering
+            from pynama_amd.domain.gmsh import read_msh
+            self._msh = read_msh(kwargs['fileName'])
+            dimf = self._msh["dim"]
+            self.nelem = [0] * dimf
+            self.lower = [float(v) for v in self._msh["xyz"].min(axis=0)]
+            self.upper = [float(v) for v in self._msh["xyz"].max(axis=0)]
         else:
             raise ValueError("DMPlexDom needs boxMesh=... or nelem/lower/upper")
         self.dim = len(self.nelem)
@@ -113,6 +119,7 @@ class DMPlexDom(object):
         else:
             raise ValueError("dim must be 2 or 3")
         self._ctx = None
+        self._unstructured = hasattr(self, "_msh")
         self.jitter = float(kwargs.get('jitter', 0.0))
         self.jitterSeed = int(kwargs.get('jitterSeed', 12345))
         self._graph = None
@@ -164,6 +171,8 @@ class DMPlexDom(object):
         and upload the local mesh to the GPU (replaces PetscSection set-up, dmplex.py:42-61)."""
         dim = self.dim
         self.indicesManager = IndicesManager(dim, ngl, self.comm)
+        if self._unstructured:
+            return self._setUnstructuredIndexing(ngl)
         m = ngl - 1
         self.ngl = ngl
         self.lattice = tuple(m * n + 1 for n in self.nelem)
@@ -209,6 +218,43 @@ class DMPlexDom(object):
         if not self.comm.rank:
             self.logger.debug("FEM/SEM Indexing SetUp")
 
+    def _setUnstructuredIndexing(self, ngl):
+        """explicit (Gmsh) mesh: Q1 cells, file numbering, one rank"""
+        from pynama_amd.domain.gmsh import exterior_facets
+        if ngl != 2:
+            raise NotImplementedError("imported meshes carry corner nodes only: ngl must be 2")
+        if self.comm.size != 1:
+            raise NotImplementedError("imported meshes are not partitioned yet: run on one GPU")
+        self.ngl = ngl
+        self.conn = self._msh["conn"]
+        self.xyz = self._msh["xyz"]
+        n = self.xyz.shape[0]
+        self.nNodesGlobal = self.nOwned = self.nLocal = n
+        self.nGhost = 0
+        self.rStart, self.rEnd = 0, n
+        self.cellStart, self.cellEnd = 0, self.conn.shape[0]
+        ext = exterior_facets(self.conn, self.dim)
+        on = np.zeros(n, dtype=bool)
+        on[ext.ravel()] = True
+        self._ext_mask = on
+        # named borders: physical tag k of a boundary facet <-> namingConvention[k-1] ("Face Sets", dmplex.py:168-171);
+        # without tagged facets, exterior facets lying in a bounding-box plane are assigned by position
+        self._border_ids = {name: set() for name in self.namingConvention}
+        if self._msh["facets"]:
+            for phys, nodes in self._msh["facets"]:
+                if 1 <= phys <= len(self.namingConvention):
+                    self._border_ids[self.namingConvention[phys - 1]].update(int(v) for v in nodes)
+        else:
+            tol = 1e-9 * max(u - l for l, u in zip(self.lower, self.upper))
+            for name, (d, hi) in self._border_axis.items():
+                ref = self.upper[d] if hi else self.lower[d]
+                flat = np.all(np.abs(self.xyz[ext][:, :, d] - ref) < tol, axis=1)
+                self._border_ids[name].update(int(v) for v in ext[flat].ravel())
+        if self._ctx is not None:
+            self._ctx.close()
+        self._ctx = None
+        self._graph = None
+
     def _local_plane_ids(self):
         a, b = self.part.owned(self.comm.rank)
         return list(range(a, b)) + list(range(*self._ghost_lo)) + list(range(*self._ghost_hi))
@@ -216,6 +262,8 @@ class DMPlexDom(object):
     def _global2local(self, g):
         """global lattice node id -> local id (owned first, ghosts below, ghosts above)"""
         g = np.asarray(g, dtype=np.int64)
+        if self._unstructured:
+            return g.copy()
         plane = self.strides[-1]
         a, b = self.part.owned(self.comm.rank)
         lo, hi = self._ghost_lo[0], self._ghost_hi[1]
@@ -232,6 +280,8 @@ class DMPlexDom(object):
 
     def _local2global(self, l):
         l = np.asarray(l, dtype=np.int64)
+        if self._unstructured:
+            return l.copy()
         plane = self.strides[-1]
         a, b = self.part.owned(self.comm.rank)
         lo = self._ghost_lo[0]
@@ -360,11 +410,17 @@ class DMPlexDom(object):
 
     # ------------------------------------------------------------------ borders / labels
     def _on_border_mask(self, name):
+        if self._unstructured:
+            m = np.zeros(self.nLocal, dtype=bool)
+            m[np.fromiter(self._border_ids[name], dtype=np.int64, count=len(self._border_ids[name]))] = True
+            return m
         d, hi = self._border_axis[name]
         return self._lat_idx[d] == (self.lattice[d] - 1 if hi else 0)
 
     def _global_border_nodes(self, name):
         """all (global) nodes of a border, computed in closed form on every rank"""
+        if self._unstructured:
+            return np.array(sorted(self._border_ids[name]), dtype=np.int64)
         d, hi = self._border_axis[name]
         others = [k for k in range(self.dim) if k != d]
         shape = tuple(self.lattice[k] for k in reversed(others))
@@ -393,10 +449,14 @@ class DMPlexDom(object):
         if label != "External Boundary":
             self.logger.warning(f"Label >> {label} << found")
             return set()
+        if self._unstructured:
+            return set(int(v) for v in np.nonzero(self._ext_mask)[0])
         return self.getBordersNodes()
 
     def boundaryMaskLocal(self):
         """uint8 [nLocal]: 1 on 'External Boundary' nodes (owned + ghost)."""
+        if self._unstructured:
+            return self._ext_mask.astype(np.uint8)
         on = np.zeros(self.nLocal, dtype=np.uint8)
         for name in self.namingConvention:
             on |= self._on_border_mask(name).astype(np.uint8)
@@ -431,6 +491,10 @@ class DMPlexDom(object):
         """Partition of the OWNED rows into lattice tiles for the tiled device assembly
         (pyn_patch_plan_set): returns (patch_ptr [P+1], patch_rows [nOwned]) in local row ids."""
         dim = self.dim
+        if self._unstructured:      # consecutive-row patches in the file's numbering
+            chunk = int(np.prod(tile))
+            ptr = np.minimum(np.arange(0, self.nOwned + chunk, chunk), self.nOwned).astype(np.int32)
+            return ptr, np.arange(self.nOwned, dtype=np.int32)
         a, b = self.part.owned(self.comm.rank)
         shape = list(self.lattice[:-1]) + [b - a]            # owned lattice, x fastest
         idx = np.indices(shape[::-1]).reshape(dim, -1)[::-1]  # idx[d][row], rows in local order
@@ -497,4 +561,5 @@ class DMPlexDom(object):
         return vec
 
     def view(self):
-        return f"DMPlexDom(box {self.nelem}, ngl={getattr(self, 'ngl', None)}, rank {self.comm.rank}/{self.comm.size})"
+        kind = "gmsh" if self._unstructured else f"box {self.nelem}"
+        return f"DMPlexDom({kind}, ngl={getattr(self, 'ngl', None)}, rank {self.comm.rank}/{self.comm.size})"

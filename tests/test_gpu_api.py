@@ -167,3 +167,47 @@ def test_cavity_default_config_runs():
     fem.solveKLE(0.0, fem.vort)
     assert fem.solver.info.true_resid < 1e-9 and fem.solverFS.info.true_resid < 1e-9
     assert len(fem.cornerDofs) == 8
+
+
+def _write_permuted_box(path, nelem, upper, jitter=0.2, seed=5):
+    """box in random node numbering and random cell order -> Gmsh file; returns (conn, xyz) as written"""
+    from oracle import fem_oracle as fo
+    from pynama_amd.domain.gmsh import write_msh
+    dim = len(nelem)
+    box = fo.box_mesh(nelem, [0.0] * dim, upper, 2, jitter=jitter)
+    rng = np.random.default_rng(seed)
+    perm = rng.permutation(box.n_node)
+    xyz = box.xyz[np.argsort(perm)]
+    conn = perm[box.conn][rng.permutation(box.n_elem)]
+    write_msh(path, xyz, conn)
+    return box, perm, conn, xyz
+
+
+@pytest.mark.parametrize("nelem,upper", [([9, 7], [1.0, 0.8]), ([9, 8, 10], [1.0, 0.8, 1.2])])
+def test_gmsh_mesh_uniform_flow(tmp_path, nelem, upper):
+    """DMPlexDom(fileName=...) (dmplex.py:22-23) drives the same device path: an imported,
+    arbitrarily numbered Q1 mesh reproduces the uniform field like test_solver.py:20-27, and its K equals
+    the oracle's matrix on the same connectivity."""
+    from oracle import fem_oracle as fo
+    from cases.uniform import UniformFlow
+    from tests.util import mat_to_scipy, sp_rel_err
+    path = str(tmp_path / "box.msh")
+    box, perm, conn, xyz = _write_permuted_box(path, nelem, upper)
+    with open(os.path.join(CASES, 'uniform.yaml')) as f:
+        cfg = yaml.load(f, Loader=yaml.Loader)
+    cfg["domain"] = {"ngl": 2, "gmsh-file": path}
+    fem = UniformFlow(cfg, case="uniform")
+    fem.setUp()
+    fem.setUpSolver()
+    dim = len(nelem)
+    mesh = fo.BoxMesh(dim, 2, tuple(nelem), box.lattice, conn, xyz, np.sort(perm[box.boundary]),
+                      {k: perm[v] for k, v in box.borders.items()})
+    ref = fo.assemble_kle_freeslip(mesh, fo.Tables(2, dim))
+    ctx = fem.dom.ctx
+    assert sp_rel_err(mat_to_scipy(ctx, fem.mat.K.id, dim, dim), ref["K"]) < 1e-12
+    assert sp_rel_err(mat_to_scipy(ctx, fem.mat.Krhs.id, dim, dim), ref["Krhs"]) < 1e-12
+    dw = 1 if dim == 2 else 3
+    assert sp_rel_err(mat_to_scipy(ctx, fem.mat.Rw.id, dim, dw), ref["Rw"]) < 1e-12
+    exactVel, exactVort = fem.generateExactVecs()
+    fem.solveKLE(time=0.0, vort=exactVort)
+    assert (exactVel - fem.vel).norm(norm_type=2) < 1e-10
