@@ -71,7 +71,10 @@ int pyn_sync(pyn_ctx* ctx);                       /* hipStreamSynchronize on the
 int pyn_comm_unique_id(void* out, int nbytes);    /* rank 0: nbytes >= 128 */
 /* unique_id == NULL with nranks > 1 declares the ranks WITHOUT a transport ("detached"): the rank's
  * slab can be assembled and multiplied in isolation, ghost entries being supplied by the caller
- * through pyn_vec_set_local_host; collectives and pyn_solve are refused. */
+ * through pyn_vec_set_local_host; collectives and pyn_solve are refused.
+ * nranks == 1: unique_id == NULL means serial (no communicator, no RCCL calls); a unique id creates a
+ * real one-rank RCCL communicator, so the collective code paths (and a halo plan whose neighbour is
+ * the rank itself) run exactly as they do at nranks > 1. */
 int pyn_comm_init(pyn_ctx* ctx, int rank, int nranks, const void* unique_id, int nbytes);
 int pyn_comm_barrier(pyn_ctx* ctx);               /* device + host barrier over all ranks */
 int pyn_comm_allreduce_f64(pyn_ctx* ctx, double* inout, int n, int op /*0 sum, 1 max*/);

@@ -148,7 +148,7 @@ extern "C" int pyn_comm_init(pyn_ctx* c, int rank, int nranks, const void* uid, 
   PYN_CHECK(nranks >= 1 && rank >= 0 && rank < nranks, "bad rank %d / %d", rank, nranks);
   c->rank = rank;
   c->nranks = nranks;
-  if (nranks == 1) return PYN_OK;
+  if (nranks == 1 && !uid) return PYN_OK;  // serial: no communicator at all
   if (!uid) {  // detached: this rank's slab is processed in isolation (tests, staged pipelines)
     c->detached = true;
     return PYN_OK;
@@ -163,7 +163,7 @@ extern "C" int pyn_comm_init(pyn_ctx* c, int rank, int nranks, const void* uid, 
 
 extern "C" int pyn_comm_allreduce_f64(pyn_ctx* c, double* inout, int n, int op) {
   PYN_CHECK(c && inout && n > 0 && n <= 32, "bad arguments");
-  if (c->nranks == 1) return PYN_OK;
+  if (c->nranks == 1 && !c->comm) return PYN_OK;
   PYN_CHECK(!c->detached, "detached communicator: no collectives");
   PYN_HIP(hipMemcpyAsync(c->d_scal + 32, inout, n * sizeof(double), hipMemcpyHostToDevice, c->stream));
   PYN_NCCL(ncclAllReduce(c->d_scal + 32, c->d_scal + 32, n, ncclDouble, op == 1 ? ncclMax : ncclSum, c->comm,
@@ -192,7 +192,7 @@ extern "C" int pyn_halo_set(pyn_ctx* c, int64_t n_owned, int64_t n_ghost, int n_
   c->recv_ptr.assign(recv_ptr, recv_ptr + n_neigh + 1);
   PYN_CHECK(c->recv_ptr[n_neigh] == n_ghost, "recv_ptr does not cover the ghosts");
   c->n_send = c->send_ptr[n_neigh];
-  for (int k = 0; k < n_neigh; ++k) PYN_CHECK(neigh[k] >= 0 && neigh[k] < c->nranks && neigh[k] != c->rank, "bad neighbour");
+  for (int k = 0; k < n_neigh; ++k) PYN_CHECK(neigh[k] >= 0 && neigh[k] < c->nranks, "bad neighbour");
   for (int64_t i = 0; i < c->n_send; ++i) PYN_CHECK(send_idx[i] >= 0 && send_idx[i] < n_owned, "send_idx out of range");
   PYN_TRY(dev_upload(&c->d_send_idx, send_idx, (size_t)c->n_send, c->stream));
   if (c->d_send_buf) PYN_HIP(hipFree(c->d_send_buf));
@@ -215,8 +215,9 @@ __global__ void pack_send_kernel(const double* __restrict__ x, const int32_t* __
 }
 
 int pyn_halo_exchange(pyn_ctx* c, double* x, int bs) {
-  if (c->nranks == 1 || c->neigh.empty()) return PYN_OK;
+  if (c->neigh.empty()) return PYN_OK;
   if (c->detached) return PYN_OK;  // ghost entries were written by the caller (pyn_vec_set_local_host)
+  PYN_CHECK(c->comm, "halo exchange needs a communicator (pyn_comm_init with a unique id)");
   PYN_CHECK(bs <= 6, "block size too large for the halo buffer");
   if (c->n_send) {
     int64_t tot = c->n_send * bs;
@@ -615,7 +616,7 @@ __global__ void __launch_bounds__(256) finish_kernel(const double* __restrict__ 
 
 int pyn_reduce_host(pyn_ctx* c, int nslots, int nblocks, int op, double* out) {
   finish_kernel<<<1, 256, 0, c->stream>>>(c->d_part, nslots, nblocks, op, c->d_scal + 40);
-  if (c->nranks > 1 && !c->detached)
+  if (c->comm)
     PYN_NCCL(ncclAllReduce(c->d_scal + 40, c->d_scal + 40, nslots, ncclDouble, op == 1 ? ncclMax : ncclSum, c->comm, c->stream));
   PYN_HIP(hipMemcpyAsync(c->h_scal, c->d_scal + 40, nslots * sizeof(double), hipMemcpyDeviceToHost, c->stream));
   PYN_HIP(hipStreamSynchronize(c->stream));

@@ -498,7 +498,7 @@ extern "C" int pyn_spmv(pyn_ctx* c, int mat_id, int xv, int yv) {
 
 // -----------------------------------------------------------------------------------------------
 static int allreduce_tmp(pyn_ctx* c, int n) {
-  if (c->nranks > 1)
+  if (c->comm)
     PYN_NCCL(ncclAllReduce(c->d_scal + S_TMP0, c->d_scal + S_TMP0, n, ncclDouble, ncclSum, c->comm, c->stream));
   return PYN_OK;
 }
@@ -621,7 +621,7 @@ static int solve_cg_sr(pyn_ctx* c, DMat& A, const double* b, double* x, const py
   hipStream_t s = c->stream;
   const int maxit = o.fixed_iters > 0 ? o.fixed_iters : o.maxit;
   const int check = o.fixed_iters > 0 ? 0 : 1;
-  const bool multi = c->nranks > 1;
+  const bool multi = c->comm != nullptr;
 
   cgsr_setup_kernel<<<1, 1, 0, s>>>(c->d_scal, c->d_flag, check ? o.rtol : 0.0, check ? o.atol : 0.0, o.dtol);
   cgsr_init_kernel<<<g, 256, 0, s>>>(b, dv, x, r, u, p, sv, n, o.norm_type, c->d_part);
@@ -805,7 +805,7 @@ extern "C" int pyn_solve(pyn_ctx* c, int mat_id, int bv, int xv, const pyn_solve
   *info = pyn_solve_info();
   if (opts->method == PYN_KSP_CG) {
     // cg_variant: 0 auto (standard on one GPU, single-reduction across ranks), 1 standard, 2 single-reduction
-    const int v = opts->cg_variant ? opts->cg_variant : (c->nranks > 1 ? 2 : 1);
+    const int v = opts->cg_variant ? opts->cg_variant : (c->comm ? 2 : 1);
     PYN_CHECK(v == 1 || v == 2, "cg_variant must be 0, 1 or 2");
     if (v == 2)
       PYN_TRY(solve_cg_sr(c, A, b, x, *opts, info));

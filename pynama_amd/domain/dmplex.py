@@ -16,6 +16,7 @@ What is different by design (SURVEY.md section 7 "hard parts"):
     (same row-block ownership shape as PETSc MPIAIJ, dmplex.py:307 / mat_generator.py:96).
 """
 import logging
+import os
 from math import floor
 
 import numpy as np
@@ -137,6 +138,10 @@ class DMPlexDom(object):
                 uid = self.comm.unique_id(_lib.Context.unique_id)
                 ctx.comm_init(self.comm.rank, self.comm.size, uid)
                 ctx.halo_set(*self._halo_plan())
+            elif os.environ.get("PYNAMA_FORCE_COMM") == "1":
+                # one rank, but with a real RCCL communicator: the collective code paths of a multi-GPU
+                # run (single-reduction CG, all-reduced scalars) can be timed and tested on one GPU
+                ctx.comm_init(0, 1, _lib.Context.unique_id())
             ctx.mesh_set(self.dim, self.conn, self.xyz)
             ctx.row_start = self.rStart
             self._ctx = ctx

@@ -546,3 +546,94 @@ def test_assemble_kle_noslip_vs_oracle(lib, nelem, ns, dr):
     Kff = (ref["K"] + ref["Kfs"]).toarray()
     assert np.abs(Kff - Kff.T).max() < 1e-9 * np.abs(Kff).max()
     ctx.close()
+
+
+# ---- RCCL code paths on one GPU: a real one-rank communicator ---------------------------------
+def test_rccl_one_rank_halo_exchange_and_collectives(lib):
+    """The transport used at nranks > 1 (pack kernel + grouped ncclSend/ncclRecv into the ghost range,
+    ncclAllReduce behind dot/norm/CG) exercised on one GPU: the rank is its own neighbour, its ghosts
+    are copies of one node plane.  Expected values come from the oracle on the cut mesh."""
+    nelem = [4, 5, 6]
+    mesh = fo.box_mesh(nelem, [0, 0, 0], [1, 1, 1], 2, jitter=0.2)
+    N = mesh.n_node
+    per_plane = (nelem[0] + 1) * (nelem[1] + 1)
+    plane = np.arange(3 * per_plane, 4 * per_plane)                     # node plane z-index 3 (lexicographic ids)
+    cells_per_layer = nelem[0] * nelem[1]
+    conn = mesh.conn.copy()
+    upper = conn[3 * cells_per_layer:]                                  # cell layers 3.. reference ghost copies
+    ghost_of = np.full(N, -1)
+    ghost_of[plane] = N + np.arange(per_plane)
+    hit = ghost_of[upper] >= 0
+    upper[hit] = ghost_of[upper][hit]
+    xyz = np.vstack([mesh.xyz, mesh.xyz[plane]])
+    cut = fo.BoxMesh(3, 2, tuple(nelem), mesh.lattice, conn.astype(np.int32), xyz, mesh.boundary, mesh.borders)
+    ref = fo.assemble_scalar(cut, fo.Tables(2, 3), "laplace")["A"][:N]
+
+    ctx = lib.Context(0)
+    ctx.comm_init(0, 1, lib.Context.unique_id())                        # real RCCL communicator, one rank
+    ctx.halo_set(N, per_plane, [0], [0, per_plane], plane.astype(np.int32), [0, per_plane])
+    ctx.mesh_set(3, cut.conn, cut.xyz)
+    from pynama_amd.elements.spectral import Spectral
+    for t in Spectral(2, 3).deviceTables():
+        ctx.tables_set(*t)
+    ctx.csr_symbolic()
+    A = ctx.mat_create(1, 1)
+    ctx.assemble_scalar(lib.FORM_LAPLACE, A)
+    assert sp_rel_err(mat_to_scipy(ctx, A, 1, 1), ref) < FP_TOL
+    rng = np.random.default_rng(3)
+    x = rng.standard_normal(N)
+    vx, vy = ctx.vec_create(1), ctx.vec_create(1)
+    ctx.vec_set(vx, x)                                                  # owned entries only: ghosts arrive by RCCL
+    ctx.spmv(A, vx, vy)
+    assert rel_err(ctx.vec_get(vy, 1), ref @ np.concatenate([x, x[plane]])) < 1e-13
+    # 3-component vectors use the same plan with block size 3
+    K = ctx.mat_create(3, 3)
+    ctx.assemble_kle(1e3, 1e2, K, -1, -1, -1)
+    S3 = mat_to_scipy(ctx, K, 3, 3)
+    x3 = rng.standard_normal(3 * N)
+    v3, w3 = ctx.vec_create(3), ctx.vec_create(3)
+    ctx.vec_set(v3, x3)
+    ctx.spmv(K, v3, w3)
+    ext = np.concatenate([x3, x3.reshape(N, 3)[plane].ravel()])
+    assert rel_err(ctx.vec_get(w3, 3), S3 @ ext) < 1e-12
+    # reductions through ncclAllReduce
+    assert abs(ctx.vec_dot(vx, vx) - x @ x) < 1e-11 * (x @ x)
+    assert abs(ctx.vec_norm(vx, 2) - np.linalg.norm(x)) < 1e-12 * np.linalg.norm(x)
+    assert np.allclose(ctx.allreduce([1.5, -2.0]), [1.5, -2.0])
+    assert np.allclose(ctx.allreduce([1.5, -2.0], op="max"), [1.5, -2.0])
+    ctx.barrier()
+    ctx.close()
+
+
+@pytest.mark.parametrize("method", ["cg", "gmres"])
+def test_rccl_one_rank_solve_equals_serial(lib, method):
+    """with a communicator the solve takes the distributed code path (single-reduction CG, all-reduced
+    scalars); one rank must reproduce the serial iterates"""
+    out = []
+    for with_comm in (False, True):
+        mesh = fo.box_mesh([10, 9, 8], [0, 0, 0], [1, 1, 1], 2, jitter=0.1)
+        ctx = lib.Context(0)
+        if with_comm:
+            ctx.comm_init(0, 1, lib.Context.unique_id())
+        ctx.mesh_set(3, mesh.conn, mesh.xyz)
+        from pynama_amd.elements.spectral import Spectral
+        for t in Spectral(2, 3).deviceTables():
+            ctx.tables_set(*t)
+        mask = np.zeros((mesh.n_node, 1), np.uint8)
+        mask[mesh.boundary] = 1
+        ctx.bc_set(1, mask)
+        ctx.csr_symbolic()
+        A = ctx.mat_create(1, 1)
+        ctx.assemble_scalar(lib.FORM_LAPLACE, A)
+        b = np.random.default_rng(0).standard_normal(mesh.n_node)
+        vb, vx = ctx.vec_create(1), ctx.vec_create(1)
+        ctx.vec_set(vb, b)
+        kw = dict(method=lib.KSP_CG, cg_variant=2) if method == "cg" else dict(method=lib.KSP_GMRES, restart=30)
+        info = ctx.solve(A, vb, vx, pc=lib.PC_JACOBI, rtol=1e-10, **kw)
+        out.append((info.iters, info.reason, ctx.vec_get(vx, 1)))
+        if with_comm and method == "cg":                                  # default variant with a communicator
+            info = ctx.solve(A, vb, vx, pc=lib.PC_JACOBI, rtol=1e-10)
+            assert info.iters == out[0][0]
+        ctx.close()
+    assert out[0][0] == out[1][0] and out[0][1] == out[1][1] == 2
+    assert rel_err(out[1][2], out[0][2]) < 1e-12
