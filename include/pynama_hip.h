@@ -91,7 +91,10 @@ int pyn_halo_set(pyn_ctx* ctx, int64_t n_owned, int64_t n_ghost, int n_neigh, co
  * DMPlexDom.getCellCornersCoords (src/domain/dmplex.py:97-104) and getGlobalNodesFromCell
  * (dmplex.py:197-200 -> src/domain/indices.py:66-88) for every cell at once:
  * conn[e*nn + a] = local node id of element-local node a (reference order; the
- * first 2^dim entries are the corners in DMPlex closure order), xyz[n*dim + d]. */
+ * first 2^dim entries are the corners in DMPlex closure order), xyz[n*dim + d].
+ * nn == dim + 1 selects linear simplices (triangles / tetrahedra; no counterpart in the reference, which
+ * is tensor-product only -- BASELINE.json configs[4]): the geometry nodes are the element's own nodes,
+ * HrsCoo has dim+1 columns, and every entry point below works unchanged. */
 int pyn_mesh_set(pyn_ctx* ctx, int dim, int nn, int64_t n_elem, int64_t n_node,
                  const int32_t* conn, const double* xyz);
 /* One quadrature's tables -- Spectral.computeMats2D/3D output (spectral.py:220-344):

@@ -170,6 +170,7 @@ class Tables:
         self.dim_w = 1 if dim == 2 else 3
         self.dim_s = 3 if dim == 2 else 6
         self.nn = ngl ** dim
+        self.nc = 2 ** dim                       # geometry (corner) nodes
         nod, w_nod = gauss_lobatto(ngl)
         full, w_full = gauss_legendre(ngl) if ngl <= 3 else gauss_lobatto(ngl)   # :41-42
         red, w_red = gauss_legendre(ngl - 1)                                      # :43
@@ -182,6 +183,34 @@ class Tables:
         self.coo_op = tensor_tables(cor, nod, w_nod, dim)
         self.HCoo1D, _ = lagrange_1d(cor, nod)
         self.nodes1d = nod
+
+
+class SimplexTables:
+    """P1 triangle / tetrahedron (NO reference counterpart: the reference is tensor-product only,
+    src/domain/indices.py:116-122; BASELINE.json configs[4] asks for a tetrahedral mesh).  Textbook linear
+    simplex: barycentric basis on the reference simplex {0, e_1..e_dim}; full rule = the symmetric
+    degree-2 rule (3 / 4 points), reduced = centroid, nodal = vertex rule.  Pinned by the closed forms
+    L_ab = V grad(l_a).grad(l_b) and M_ab = V (1 + delta_ab) / ((dim+1)(dim+2)) in tests/test_simplex_host.py."""
+
+    def __init__(self, dim: int):
+        self.ngl, self.dim = 2, dim
+        self.dim_w = 1 if dim == 2 else 3
+        self.dim_s = 3 if dim == 2 else 6
+        self.nn = self.nc = dim + 1
+        vol = 0.5 if dim == 2 else 1.0 / 6.0
+        if dim == 2:
+            full = np.array([[1 / 6, 1 / 6], [2 / 3, 1 / 6], [1 / 6, 2 / 3]])
+        else:
+            a, b = 0.5854101966249685, 0.1381966011250105
+            full = np.array([[b, b, b], [a, b, b], [b, a, b], [b, b, a]])
+        grad = np.hstack([-np.ones((dim, 1)), np.eye(dim)])
+
+        def quad(pts):
+            H = np.hstack([1.0 - pts.sum(axis=1, keepdims=True), pts])
+            return Quad(H, np.repeat(grad[None], len(pts), axis=0), pts, np.full(len(pts), vol / len(pts)))
+        self.full = self.coo = quad(full)
+        self.red = self.coo_red = quad(np.full((1, dim), 1.0 / (dim + 1)))
+        self.op = self.coo_op = quad(np.vstack([np.zeros(dim), np.eye(dim)]))
 
 
 # --------------------------------------------------------------------------------------
@@ -216,7 +245,7 @@ def elem_kle_matrices(tb: Tables, coords, alpha_d=1e3, alpha_w=1e2):
     returns K [E, dim nn, dim nn], Rw [E, dim nn, dim_w nn], Rd [E, dim nn, nn].
     """
     dim, dw, nn = tb.dim, tb.dim_w, tb.nn
-    X = np.asarray(coords, dtype=np.float64).reshape(-1, 2 ** dim, dim)
+    X = np.asarray(coords, dtype=np.float64).reshape(-1, tb.nc, dim)
     E = X.shape[0]
     K = np.zeros((E, dim * nn, dim * nn))
     Rw = np.zeros((E, dim * nn, dw * nn))
@@ -261,7 +290,7 @@ def elem_kle_matrices(tb: Tables, coords, alpha_d=1e3, alpha_w=1e2):
 def elem_kle_operators(tb: Tables, coords):
     """SrT_e, DivSrT_e, Curl_e and lumped weights at the nodal (GLL) rule.  spectral.py:159-218."""
     dim, dw, ds, nn = tb.dim, tb.dim_w, tb.dim_s, tb.nn
-    X = np.asarray(coords, dtype=np.float64).reshape(-1, 2 ** dim, dim)
+    X = np.asarray(coords, dtype=np.float64).reshape(-1, tb.nc, dim)
     E = X.shape[0]
     ind_bdiv = [[0, 1], [1, 2]] if dim == 2 else [[0, 1, 5], [1, 2, 3], [5, 3, 4]]  # :28,33
     _, vcurl = _curl_rows(dim)
@@ -308,7 +337,7 @@ def elem_kle_operators(tb: Tables, coords):
 def elem_laplace(tb: Tables, coords):
     """Scalar stiffness L_e = sum_full c G^T G -- the `kron(., I_dim)` block of K_e
     (spectral.py:125,131 restricted to one velocity component)."""
-    X = np.asarray(coords, dtype=np.float64).reshape(-1, 2 ** tb.dim, tb.dim)
+    X = np.asarray(coords, dtype=np.float64).reshape(-1, tb.nc, tb.dim)
     G, c = _geom(tb.coo, tb.full, X)
     return np.einsum("eg,egda,egdb->eab", c, G, G)
 
@@ -316,7 +345,7 @@ def elem_laplace(tb: Tables, coords):
 def elem_mass(tb: Tables, coords, rule="nodal"):
     """Scalar mass matrix.  rule='nodal' is the reference's elWeigMat (spectral.py:215,
     GLL collocation => diagonal); rule='full' uses the full quadrature."""
-    X = np.asarray(coords, dtype=np.float64).reshape(-1, 2 ** tb.dim, tb.dim)
+    X = np.asarray(coords, dtype=np.float64).reshape(-1, tb.nc, tb.dim)
     qg, q = (tb.coo_op, tb.op) if rule == "nodal" else (tb.coo, tb.full)
     _, c = _geom(qg, q, X)
     return np.einsum("eg,ga,gb->eab", c, q.H, q.H)
@@ -339,6 +368,7 @@ class BoxMesh:
     xyz: np.ndarray         # [n_node, dim]
     boundary: np.ndarray    # sorted node ids on "External Boundary"
     borders: dict           # name -> node ids
+    nc: int = 0             # geometry nodes per element (0: 2^dim)
 
     @property
     def n_node(self):
@@ -350,7 +380,7 @@ class BoxMesh:
 
     def corners(self):
         """[n_elem, 2^dim * dim] corner coordinates in closure order.  dmplex.py:97-104."""
-        nc = 2 ** self.dim
+        nc = self.nc or 2 ** self.dim
         return self.xyz[self.conn[:, :nc]].reshape(self.n_elem, nc * self.dim)
 
 
@@ -407,6 +437,39 @@ def box_mesh(nelem, lower, upper, ngl=2, jitter=0.0, seed=12345) -> BoxMesh:
 # --------------------------------------------------------------------------------------
 # global assembly with Dirichlet elimination            base_problem.py:499-552
 # --------------------------------------------------------------------------------------
+
+
+def simplex_box_mesh(nelem, lower, upper, jitter=0.0, seed=12345, permute_seed=None) -> BoxMesh:
+    """Build-generated simplicial mesh of a box: the Q1 lattice of `box_mesh` with every
+    quad cut into 2 triangles / every hex into 6 tetrahedra (Kuhn's conforming subdivision, positive
+    orientation).  `permute_seed` applies a random node permutation to destroy index locality."""
+    from itertools import permutations
+    dim = len(nelem)
+    box = box_mesh(nelem, lower, upper, 2, jitter=jitter, seed=seed)
+    lat = box.lattice
+    strides = np.cumprod((1,) + lat[:-1])
+    cells = np.stack(np.meshgrid(*[np.arange(n) for n in nelem], indexing="ij"), axis=-1).reshape(-1, dim)
+    # keep the cell order of box_mesh (x fastest)
+    order = np.lexsort([cells[:, d] for d in range(dim)])
+    base = cells[order] @ strides
+    conn = []
+    for perm in permutations(range(dim)):
+        offs = [0]
+        for d in perm:
+            offs.append(offs[-1] + strides[d])
+        inv = sum(1 for a in range(dim) for b in range(a + 1, dim) if perm[a] > perm[b])
+        if inv % 2:                                   # odd permutation: swap two vertices -> det J > 0
+            offs[-1], offs[-2] = offs[-2], offs[-1]
+        conn.append(base[:, None] + np.array(offs)[None, :])
+    conn = np.stack(conn, axis=1).reshape(-1, dim + 1)
+    xyz, boundary, borders = box.xyz, box.boundary, box.borders
+    if permute_seed is not None:
+        perm = np.random.default_rng(permute_seed).permutation(box.n_node)     # old id -> new id
+        xyz = xyz[np.argsort(perm)]
+        conn = perm[conn]
+        boundary = np.sort(perm[boundary])
+        borders = {k: perm[v] for k, v in borders.items()}
+    return BoxMesh(dim, 2, tuple(nelem), lat, conn.astype(np.int32), xyz, boundary, borders, nc=dim + 1)
 
 
 def dof_indices(nodes, ndof):

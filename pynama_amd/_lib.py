@@ -347,7 +347,7 @@ class Context:
         dim, nn = self.dim, self.nn
         dw = 1 if dim == 2 else 3
         c = _f64(corners).ravel()
-        assert c.size == (2 ** dim) * dim
+        assert c.size == (nn if nn == dim + 1 else 2 ** dim) * dim
         if form == FORM_KLE:
             o0 = np.empty((dim * nn, dim * nn))
             o1 = np.empty((dim * nn, dw * nn))

@@ -71,7 +71,11 @@ class BaseProblem(object):
             self.logger.info("DMPlex dom created")
 
     def setUpElement(self):
-        self.elemType = Spectral(self.ngl, self.dim)
+        if getattr(self.dom, "cellType", "tensor") == "simplex":    # imported triangles / tetrahedra
+            from pynama_amd.elements.simplex import Simplex
+            self.elemType = Simplex(self.dim)
+        else:
+            self.elemType = Spectral(self.ngl, self.dim)
         if not self.comm.rank:
             self.logger.info(f"{self.dim}-D ngl:{self.ngl} Spectral element created")
 

@@ -247,7 +247,9 @@ extern "C" int pyn_mesh_set(pyn_ctx* c, int dim, int nn, int64_t n_elem, int64_t
     for (int d = 0; d < dim; ++d) p *= g;
     if (p == nn) ngl = g;
   }
-  PYN_CHECK(ngl >= 2, "nn=%d is not ngl^dim", nn);
+  // nn == dim + 1: linear simplex (triangle / tetrahedron) -- geometry nodes = the element's nodes
+  const bool simplex = nn == dim + 1;
+  PYN_CHECK(ngl >= 2 || simplex, "nn=%d is neither ngl^dim nor a linear simplex (dim+1)", nn);
   PYN_CHECK(n_elem > 0 && n_node > 0 && n_node < (int64_t)INT32_MAX, "bad sizes");
   if (!c->halo_set) {
     c->n_owned = n_node;
@@ -259,8 +261,8 @@ extern "C" int pyn_mesh_set(pyn_ctx* c, int dim, int nn, int64_t n_elem, int64_t
     PYN_CHECK(conn[i] >= 0 && conn[i] < n_node, "conn[%lld]=%d out of range", (long long)i, conn[i]);
   c->dim = dim;
   c->nn = nn;
-  c->nc = 1 << dim;
-  c->ngl = ngl;
+  c->nc = simplex ? nn : 1 << dim;
+  c->ngl = simplex ? 0 : ngl;
   c->n_elem = n_elem;
   c->n_node = n_node;
   PYN_HIP(hipSetDevice(c->device));

@@ -81,6 +81,29 @@ class DeviceGraph:
             yield self[i]
 
 
+def _morton_order(xyz):
+    """argsort of the nodes along a Z-order curve (21 bits per axis)"""
+    lo, hi = xyz.min(axis=0), xyz.max(axis=0)
+    q = ((xyz - lo) / np.where(hi > lo, hi - lo, 1.0) * ((1 << 21) - 1)).astype(np.uint64)
+    key = np.zeros(xyz.shape[0], dtype=np.uint64)
+    for d in range(xyz.shape[1]):
+        v = q[:, d]
+        if xyz.shape[1] == 3:                 # spread 21 bits to every third position
+            v = (v | (v << np.uint64(32))) & np.uint64(0x1F00000000FFFF)
+            v = (v | (v << np.uint64(16))) & np.uint64(0x1F0000FF0000FF)
+            v = (v | (v << np.uint64(8))) & np.uint64(0x100F00F00F00F00F)
+            v = (v | (v << np.uint64(4))) & np.uint64(0x10C30C30C30C30C3)
+            v = (v | (v << np.uint64(2))) & np.uint64(0x1249249249249249)
+        else:                                 # every second position
+            v = (v | (v << np.uint64(16))) & np.uint64(0x0000FFFF0000FFFF)
+            v = (v | (v << np.uint64(8))) & np.uint64(0x00FF00FF00FF00FF)
+            v = (v | (v << np.uint64(4))) & np.uint64(0x0F0F0F0F0F0F0F0F)
+            v = (v | (v << np.uint64(2))) & np.uint64(0x3333333333333333)
+            v = (v | (v << np.uint64(1))) & np.uint64(0x5555555555555555)
+        key |= v << np.uint64(d)
+    return np.argsort(key, kind="stable")
+
+
 class DMPlexDom(object):
     def __init__(self, **kwargs):
         self.comm = kwargs.get('comm') or get_world()
@@ -121,6 +144,7 @@ class DMPlexDom(object):
             raise ValueError("dim must be 2 or 3")
         self._ctx = None
         self._unstructured = hasattr(self, "_msh")
+        self.reorder = kwargs.get('reorder', 'morton')
         self.jitter = float(kwargs.get('jitter', 0.0))
         self.jitterSeed = int(kwargs.get('jitterSeed', 12345))
         self._graph = None
@@ -224,37 +248,89 @@ class DMPlexDom(object):
             self.logger.debug("FEM/SEM Indexing SetUp")
 
     def _setUnstructuredIndexing(self, ngl):
-        """explicit (Gmsh) mesh: Q1 cells, file numbering, one rank"""
+        """explicit (Gmsh) mesh: first-order cells.  Nodes are renumbered along a Morton curve (locality for
+        the SpMV gathers and the scatter; PETSc renumbers imported meshes too), rows are split in contiguous
+        blocks over the ranks, every rank keeps the cells touching an owned node (owner-computes) and the
+        ghost nodes are addressed through an index list."""
         from pynama_amd.domain.gmsh import exterior_facets
         if ngl != 2:
             raise NotImplementedError("imported meshes carry corner nodes only: ngl must be 2")
-        if self.comm.size != 1:
-            raise NotImplementedError("imported meshes are not partitioned yet: run on one GPU")
+        rank, size = self.comm.rank, self.comm.size
         self.ngl = ngl
-        self.conn = self._msh["conn"]
-        self.xyz = self._msh["xyz"]
-        n = self.xyz.shape[0]
-        self.nNodesGlobal = self.nOwned = self.nLocal = n
-        self.nGhost = 0
-        self.rStart, self.rEnd = 0, n
-        self.cellStart, self.cellEnd = 0, self.conn.shape[0]
-        ext = exterior_facets(self.conn, self.dim)
-        on = np.zeros(n, dtype=bool)
-        on[ext.ravel()] = True
-        self._ext_mask = on
+        self.cellType = self._msh["cell"]
+        conn = self._msh["conn"].astype(np.int64)
+        xyz = self._msh["xyz"]
+        n = xyz.shape[0]
+        facets = self._msh["facets"]
+        if self.reorder == "morton":
+            new_of_old = np.empty(n, dtype=np.int64)
+            new_of_old[_morton_order(xyz)] = np.arange(n)
+            xyz = xyz[np.argsort(new_of_old)]
+            conn = new_of_old[conn]
+            facets = [(p, new_of_old[f]) for p, f in facets]
+        self.nNodesGlobal = n
+        ext = exterior_facets(conn, self.dim)
+        ext_mask = np.zeros(n, dtype=bool)
+        ext_mask[ext.ravel()] = True
         # named borders: physical tag k of a boundary facet <-> namingConvention[k-1] ("Face Sets", dmplex.py:168-171);
         # without tagged facets, exterior facets lying in a bounding-box plane are assigned by position
         self._border_ids = {name: set() for name in self.namingConvention}
-        if self._msh["facets"]:
-            for phys, nodes in self._msh["facets"]:
+        if facets:
+            for phys, nodes in facets:
                 if 1 <= phys <= len(self.namingConvention):
                     self._border_ids[self.namingConvention[phys - 1]].update(int(v) for v in nodes)
         else:
             tol = 1e-9 * max(u - l for l, u in zip(self.lower, self.upper))
             for name, (d, hi) in self._border_axis.items():
                 ref = self.upper[d] if hi else self.lower[d]
-                flat = np.all(np.abs(self.xyz[ext][:, :, d] - ref) < tol, axis=1)
+                flat = np.all(np.abs(xyz[ext][:, :, d] - ref) < tol, axis=1)
                 self._border_ids[name].update(int(v) for v in ext[flat].ravel())
+        # ---- row blocks + owner-computes cell sets
+        bounds = np.array([(r * n) // size for r in range(size + 1)], dtype=np.int64)
+        if size > 1 and np.any(np.diff(bounds) == 0):
+            raise ValueError(f"{n} nodes cannot be split over {size} ranks")
+        self._bounds = bounds
+        self.rStart, self.rEnd = int(bounds[rank]), int(bounds[rank + 1])
+        self.nOwned = self.rEnd - self.rStart
+        owner = np.searchsorted(bounds, conn, side="right") - 1                 # [E, nn]
+        mine = np.any(owner == rank, axis=1)
+        lconn = conn[mine]
+        ghosts = np.unique(lconn[(lconn < self.rStart) | (lconn >= self.rEnd)])    # sorted => grouped by owner
+        self._ghost_gids = ghosts
+        self.nGhost = int(ghosts.size)
+        self.nLocal = self.nOwned + self.nGhost
+        self.cellStart, self.cellEnd = 0, int(mine.sum())
+        self.conn = self._global2local(lconn).astype(np.int32)
+        gids = self._local2global(np.arange(self.nLocal))
+        self.xyz = xyz[gids]
+        self._ext_mask = ext_mask[gids]
+        self._ext_ids_global = np.nonzero(ext_mask)[0].tolist()
+        # ---- halo plan: node g is a ghost on rank k iff some cell holds g and a node owned by k != owner(g)
+        self._unstructured_plan = None
+        if size > 1:
+            iface = np.any(owner != owner[:, :1], axis=1)
+            ic, io = conn[iface], owner[iface]
+            nn = ic.shape[1]
+            g = np.repeat(ic, nn, axis=1).ravel()                 # node a, paired with ...
+            go = np.repeat(io, nn, axis=1).ravel()
+            k = np.tile(io, (1, nn)).ravel()                      # ... the owner of node b
+            sel = go != k
+            pairs = np.unique(np.stack([k[sel], g[sel]], axis=1), axis=0)       # (rank holding the ghost, node)
+            pown = np.searchsorted(bounds, pairs[:, 1], side="right") - 1
+            send = pairs[pown == rank]                            # my nodes that are ghosts elsewhere
+            recv = pairs[pairs[:, 0] == rank]                     # my ghosts, with their owners
+            assert np.array_equal(np.sort(recv[:, 1]), ghosts)
+            rown = pown[pairs[:, 0] == rank]
+            neigh = sorted(set(send[:, 0].tolist()) | set(rown.tolist()))
+            send_ptr, recv_ptr, send_idx = [0], [0], []
+            for nb in neigh:
+                ids = np.sort(send[send[:, 0] == nb][:, 1]) - self.rStart
+                send_idx.append(ids)
+                send_ptr.append(send_ptr[-1] + ids.size)
+                recv_ptr.append(recv_ptr[-1] + int((rown == nb).sum()))
+            sidx = np.concatenate(send_idx).astype(np.int32) if send_idx else np.zeros(0, np.int32)
+            self._unstructured_plan = (self.nOwned, self.nGhost, np.array(neigh, np.int32),
+                                       np.array(send_ptr, np.int64), sidx, np.array(recv_ptr, np.int64))
         if self._ctx is not None:
             self._ctx.close()
         self._ctx = None
@@ -268,7 +344,14 @@ class DMPlexDom(object):
         """global lattice node id -> local id (owned first, ghosts below, ghosts above)"""
         g = np.asarray(g, dtype=np.int64)
         if self._unstructured:
-            return g.copy()
+            out = np.full(g.shape, -1, dtype=np.int64)
+            own = (g >= self.rStart) & (g < self.rEnd)
+            out[own] = g[own] - self.rStart
+            if self.nGhost:
+                pos = np.minimum(np.searchsorted(self._ghost_gids, g), self.nGhost - 1)
+                gh = (~own) & (self._ghost_gids[pos] == g)
+                out[gh] = self.nOwned + pos[gh]
+            return out
         plane = self.strides[-1]
         a, b = self.part.owned(self.comm.rank)
         lo, hi = self._ghost_lo[0], self._ghost_hi[1]
@@ -286,7 +369,10 @@ class DMPlexDom(object):
     def _local2global(self, l):
         l = np.asarray(l, dtype=np.int64)
         if self._unstructured:
-            return l.copy()
+            out = l + self.rStart
+            gh = l >= self.nOwned
+            out[gh] = self._ghost_gids[l[gh] - self.nOwned]
+            return out
         plane = self.strides[-1]
         a, b = self.part.owned(self.comm.rank)
         lo = self._ghost_lo[0]
@@ -302,6 +388,8 @@ class DMPlexDom(object):
 
     def _halo_plan(self):
         """(n_owned, n_ghost, neigh, send_ptr, send_idx, recv_ptr) for pyn_halo_set."""
+        if self._unstructured:
+            return self._unstructured_plan
         rank, size = self.comm.rank, self.comm.size
         plane = self.strides[-1]
         a, b = self.part.owned(rank)
@@ -416,9 +504,8 @@ class DMPlexDom(object):
     # ------------------------------------------------------------------ borders / labels
     def _on_border_mask(self, name):
         if self._unstructured:
-            m = np.zeros(self.nLocal, dtype=bool)
-            m[np.fromiter(self._border_ids[name], dtype=np.int64, count=len(self._border_ids[name]))] = True
-            return m
+            ids = np.fromiter(self._border_ids[name], dtype=np.int64, count=len(self._border_ids[name]))
+            return np.isin(self._local2global(np.arange(self.nLocal)), ids)
         d, hi = self._border_axis[name]
         return self._lat_idx[d] == (self.lattice[d] - 1 if hi else 0)
 
@@ -455,7 +542,7 @@ class DMPlexDom(object):
             self.logger.warning(f"Label >> {label} << found")
             return set()
         if self._unstructured:
-            return set(int(v) for v in np.nonzero(self._ext_mask)[0])
+            return set(self._ext_ids_global)
         return self.getBordersNodes()
 
     def boundaryMaskLocal(self):

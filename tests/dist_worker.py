@@ -25,7 +25,11 @@ def main():
     dist.init_process_group("gloo")
     rank, size = dist.get_rank(), dist.get_world_size()
     dim = len(nelem)
-    dom = DMPlexDom(boxMesh={"nelem": nelem, "lower": [0.0] * dim, "upper": [1.0] * dim}, comm=Comm(rank, size), jitter=0.2 if ngl == 2 else 0.0)
+    msh = sys.argv[3] if len(sys.argv) > 3 else None          # imported (Gmsh) mesh instead of the box
+    if msh:
+        dom = DMPlexDom(fileName=msh, comm=Comm(rank, size))
+    else:
+        dom = DMPlexDom(boxMesh={"nelem": nelem, "lower": [0.0] * dim, "upper": [1.0] * dim}, comm=Comm(rank, size), jitter=0.2 if ngl == 2 else 0.0)
     dom.setFemIndexing(ngl)
     n_owned, n_ghost, neigh, send_ptr, send_idx, recv_ptr = dom._halo_plan()
 
@@ -35,9 +39,10 @@ def main():
     m = Local()
     m.dim, m.conn, m.xyz = dim, dom.conn, dom.xyz
     m.n_node, m.n_elem = dom.nLocal, dom.conn.shape[0]
-    m.corners = lambda: m.xyz[m.conn[:, :2 ** dim]].reshape(m.n_elem, -1)
+    simplex = dom.conn.shape[1] == dim + 1
+    tb = fo.SimplexTables(dim) if simplex else fo.Tables(ngl, dim)
+    m.corners = lambda: m.xyz[m.conn[:, :tb.nc]].reshape(m.n_elem, -1)
     bmask = dom.boundaryMaskLocal()
-    tb = fo.Tables(ngl, dim)
     A_loc = fo.assemble_scalar(m, tb, "laplace", dirichlet=np.nonzero(bmask)[0])["A"][:n_owned]   # owned rows, local cols
 
     def halo(x):
@@ -60,7 +65,12 @@ def main():
         return float(t[0])
 
     # ---- right-hand side: same global random vector on every rank, zero on the boundary
-    glob = fo.box_mesh(nelem, [0.0] * dim, [1.0] * dim, ngl, jitter=0.2 if ngl == 2 else 0.0)
+    if msh:                      # the whole mesh in the build's numbering, read by a one-rank domain
+        one = DMPlexDom(fileName=msh, comm=Comm())
+        one.setFemIndexing(ngl)
+        glob = fo.BoxMesh(dim, 2, tuple(nelem), (), one.conn, one.xyz, np.nonzero(one.boundaryMaskLocal())[0], {}, nc=tb.nc)
+    else:
+        glob = fo.box_mesh(nelem, [0.0] * dim, [1.0] * dim, ngl, jitter=0.2 if ngl == 2 else 0.0)
     rng = np.random.default_rng(5)
     b_glob = rng.standard_normal(glob.n_node)
     b_glob[glob.boundary] = 0.0

@@ -56,7 +56,7 @@ def test_read_hand_written_hex_file(tmp_path):
     assert np.allclose(A.sum(axis=(1, 2)), 1.0)                  # volume of each unit cell
     ref = fo.box_mesh([1, 1, 1], [0, 0, 0], [1, 1, 1], 2)
     assert np.allclose(m["xyz"][m["conn"][0]], ref.xyz[ref.conn[0]])
-    d = DMPlexDom(fileName=str(p), comm=Comm())
+    d = DMPlexDom(fileName=str(p), comm=Comm(), reorder=None)
     d.setFemIndexing(2)
     assert d.getDimension() == 3 and d.nOwned == 12
     assert d.boundaryMaskLocal().all()                           # no interior node in a 2x1x1 box
@@ -76,7 +76,7 @@ def test_roundtrip_permuted_box(tmp_path, nelem):
     conn = perm[box.conn][rng.permutation(box.n_elem)]
     p = str(tmp_path / "box.msh")
     write_msh(p, xyz, conn)                                       # no tagged facets: borders by position
-    d = DMPlexDom(fileName=p, comm=Comm())
+    d = DMPlexDom(fileName=p, comm=Comm(), reorder=None)          # keep the file's numbering
     d.setFemIndexing(2)
     assert np.array_equal(d.conn, conn) and np.allclose(d.xyz, xyz)
     assert set(np.nonzero(d.boundaryMaskLocal())[0]) == set(perm[box.boundary])
@@ -90,8 +90,8 @@ def test_roundtrip_permuted_box(tmp_path, nelem):
 def test_rejects_unsupported(tmp_path):
     p = tmp_path / "tri.msh"
     p.write_text("$MeshFormat\n2.2 0 8\n$EndMeshFormat\n$Nodes\n3\n1 0 0 0\n2 1 0 0\n3 0 1 0\n$EndNodes\n"
-                 "$Elements\n1\n1 2 2 0 0 1 2 3\n$EndElements\n")
-    with pytest.raises(ValueError, match="only lines, quadrangles and hexahedra"):
+                 "$Elements\n1\n1 9 2 0 0 1 2 3 1 2 3\n$EndElements\n")     # 6-node triangle
+    with pytest.raises(ValueError, match="only first-order"):
         read_msh(str(p))
     q = tmp_path / "v4.msh"
     q.write_text("$MeshFormat\n4.1 0 8\n$EndMeshFormat\n")
@@ -103,3 +103,73 @@ def test_rejects_unsupported(tmp_path):
     d = DMPlexDom(fileName=r, comm=Comm())
     with pytest.raises(NotImplementedError, match="ngl must be 2"):
         d.setFemIndexing(3)
+
+
+@pytest.mark.parametrize("cell,nelem,size", [("tet", [4, 3, 5], 3), ("hex", [4, 4, 6], 2), ("tri", [7, 6], 4), ("tet", [5, 5, 5], 5)])
+def test_row_block_partition_of_imported_mesh(tmp_path, cell, nelem, size):
+    """imported meshes: Morton renumbering is a pure permutation; contiguous row blocks; every rank holds the
+    cells touching an owned node; ghosts addressed through a sorted index list; halo plans are symmetric
+    between ANY pair of ranks (not only rank +-1 as for the box slabs)."""
+    dim = len(nelem)
+    up = [1.0, 0.8, 1.2][:dim]
+    if cell == "hex":
+        src = fo.box_mesh(nelem, [0.0] * dim, up, 2, jitter=0.2)
+    else:
+        src = fo.simplex_box_mesh(nelem, [0.0] * dim, up, jitter=0.2)
+    rng = np.random.default_rng(8)
+    perm = rng.permutation(src.n_node)
+    p = str(tmp_path / "m.msh")
+    write_msh(p, src.xyz[np.argsort(perm)], perm[src.conn])
+    doms = [DMPlexDom(fileName=p, comm=Comm(r, size)) for r in range(size)]
+    for d in doms:
+        d.setFemIndexing(2)
+    one = DMPlexDom(fileName=p, comm=Comm())
+    one.setFemIndexing(2)                                   # the global mesh in the build's (Morton) numbering
+    assert one.nOwned == src.n_node and one.nGhost == 0
+    # the renumbering only permutes: same node set, same cells
+    key = lambda x: np.round(x * 1e9).astype(np.int64)
+    assert set(map(tuple, key(one.xyz))) == set(map(tuple, key(src.xyz)))
+    cells_a = np.sort(np.sort(key(one.xyz[one.conn]).reshape(one.conn.shape[0], -1), axis=1), axis=0)
+    cells_b = np.sort(np.sort(key(src.xyz[src.conn]).reshape(src.n_elem, -1), axis=1), axis=0)
+    assert np.array_equal(cells_a, cells_b)
+    assert doms[0].rStart == 0 and doms[-1].rEnd == src.n_node
+    plans = [d._halo_plan() for d in doms]
+    far = False
+    for r, d in enumerate(doms):
+        if r:
+            assert doms[r - 1].rEnd == d.rStart
+        n_owned, n_ghost, neigh, sp_, sidx, rp_ = plans[r]
+        assert n_owned == d.nOwned and n_ghost == d.nGhost and rp_[-1] == n_ghost
+        g = d._local2global(np.arange(d.nLocal))
+        assert len(np.unique(g)) == d.nLocal
+        assert np.array_equal(d._global2local(g), np.arange(d.nLocal))
+        np.testing.assert_array_equal(d.xyz, one.xyz[g])
+        touching = ((one.conn >= d.rStart) & (one.conn < d.rEnd)).any(axis=1)
+        assert np.array_equal(g[d.conn], one.conn[touching])
+        assert np.array_equal(d.boundaryMaskLocal(), one.boundaryMaskLocal()[g])
+        for name in one.getBordersNames():
+            assert np.array_equal(d._on_border_mask(name), one._on_border_mask(name)[g])
+        far |= any(abs(int(nb) - r) > 1 for nb in neigh)
+        for k, nb in enumerate(neigh):
+            sent_global = d._local2global(sidx[sp_[k]:sp_[k + 1]])
+            n2 = plans[nb]
+            k2 = list(n2[2]).index(r)
+            ghosts = doms[nb]._local2global(np.arange(n2[0] + n2[5][k2], n2[0] + n2[5][k2 + 1]))
+            assert np.array_equal(sent_global, ghosts)
+    if size >= 4:
+        assert far                                          # Morton blocks do touch non-adjacent ranks
+
+
+def test_simplex_files(tmp_path):
+    """tetrahedra keep Gmsh's order; a negatively oriented cell is fixed on import"""
+    m = fo.simplex_box_mesh([2, 2, 2], [0, 0, 0], [1, 1, 1])
+    conn = m.conn.copy()
+    conn[3, [2, 3]] = conn[3, [3, 2]]                       # flip one tetrahedron
+    p = str(tmp_path / "t.msh")
+    write_msh(p, m.xyz, conn)
+    r = read_msh(p)
+    assert r["cell"] == "simplex" and r["dim"] == 3
+    X = r["xyz"][r["conn"]]
+    assert (np.linalg.det(X[:, 1:] - X[:, :1]) > 0).all()
+    assert np.array_equal(r["conn"], m.conn)
+    assert len(exterior_facets(r["conn"], 3)) == 6 * 2 * 4   # 6 faces x 4 squares x 2 triangles

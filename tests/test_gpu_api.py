@@ -200,8 +200,9 @@ def test_gmsh_mesh_uniform_flow(tmp_path, nelem, upper):
     fem.setUp()
     fem.setUpSolver()
     dim = len(nelem)
-    mesh = fo.BoxMesh(dim, 2, tuple(nelem), box.lattice, conn, xyz, np.sort(perm[box.boundary]),
-                      {k: perm[v] for k, v in box.borders.items()})
+    dom = fem.dom                              # one rank: the whole mesh in the build's (Morton) numbering
+    assert sorted(map(tuple, np.round(dom.xyz, 12))) == sorted(map(tuple, np.round(xyz, 12)))
+    mesh = fo.BoxMesh(dim, 2, tuple(nelem), box.lattice, dom.conn, dom.xyz, np.nonzero(dom.boundaryMaskLocal())[0], {})
     ref = fo.assemble_kle_freeslip(mesh, fo.Tables(2, dim))
     ctx = fem.dom.ctx
     assert sp_rel_err(mat_to_scipy(ctx, fem.mat.K.id, dim, dim), ref["K"]) < 1e-12
