@@ -398,6 +398,83 @@ __global__ void bc_identity_kernel(const int32_t* __restrict__ rowptr, const int
   }
 }
 
+// Linear simplices (constant gradients): one element per lane, no LDS, no barriers.  L_ab = (sum_g w_g) detJ
+// G_a.G_b with G = J^-1 Hrs; rows owned by this rank and not eliminated are scatter-added with FP64 atomics,
+// the slot found by bisection in the (short: ~7 / ~15 entries) sorted row.  Same elimination rule as the
+// generic kernel.  The irregular-indexing workload of BASELINE.json configs[4].
+template <int DIM>
+__global__ void __launch_bounds__(256) assemble_p1_laplace_kernel(const int32_t* __restrict__ conn, const double* __restrict__ xyz,
+                                                                    int64_t n_elem, int64_t n_owned,
+                                                                    const int32_t* __restrict__ rowptr,
+                                                                    const int32_t* __restrict__ colidx,
+                                                                    const uint8_t* __restrict__ bcmask,
+                                                                    const double* __restrict__ hrs, double wsum,
+                                                                    double* __restrict__ A, double* __restrict__ Arhs) {
+  constexpr int NN = DIM + 1;
+  const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= n_elem) return;
+  int ids[NN];
+  double X[NN][DIM];
+  if (DIM == 3) {
+    const int4 q = *reinterpret_cast<const int4*>(conn + e * 4);
+    ids[0] = q.x, ids[1] = q.y, ids[2] = q.z, ids[NN - 1] = q.w;
+  } else {
+#pragma unroll
+    for (int a = 0; a < NN; ++a) ids[a] = conn[e * NN + a];
+  }
+#pragma unroll
+  for (int a = 0; a < NN; ++a)
+#pragma unroll
+    for (int d = 0; d < DIM; ++d) X[a][d] = xyz[(int64_t)ids[a] * DIM + d];
+  double H[DIM][NN];
+#pragma unroll
+  for (int d = 0; d < DIM; ++d)
+#pragma unroll
+    for (int a = 0; a < NN; ++a) H[d][a] = hrs[d * NN + a];  // uniform: scalar loads
+  double J[DIM * DIM], Ji[DIM * DIM];
+#pragma unroll
+  for (int d = 0; d < DIM; ++d)
+#pragma unroll
+    for (int x = 0; x < DIM; ++x) {
+      double s = 0.0;
+#pragma unroll
+      for (int a = 0; a < NN; ++a) s += H[d][a] * X[a][x];
+      J[d * DIM + x] = s;
+    }
+  const double cw = wsum * inv_det(J, Ji, DIM);
+  double G[DIM][NN];
+#pragma unroll
+  for (int x = 0; x < DIM; ++x)
+#pragma unroll
+    for (int a = 0; a < NN; ++a) {
+      double s = 0.0;
+#pragma unroll
+      for (int d = 0; d < DIM; ++d) s += Ji[x * DIM + d] * H[d][a];
+      G[x][a] = s;
+    }
+  bool mc[NN];
+#pragma unroll
+  for (int a = 0; a < NN; ++a) mc[a] = bcmask && bcmask[ids[a]];
+#pragma unroll
+  for (int a = 0; a < NN; ++a) {
+    if (ids[a] >= n_owned || mc[a]) continue;
+    const int lo = rowptr[ids[a]], len = rowptr[ids[a] + 1] - lo;
+#pragma unroll
+    for (int b = 0; b < NN; ++b) {
+      double v = 0.0;
+#pragma unroll
+      for (int x = 0; x < DIM; ++x) v += G[x][a] * G[x][b];
+      v *= cw;
+      const int64_t off = (int64_t)lo + find_slot(colidx, lo, len, ids[b]);
+      if (mc[b]) {
+        if (Arhs) atomicAdd(&Arhs[off], -v);
+      } else if (A) {
+        atomicAdd(&A[off], v);
+      }
+    }
+  }
+}
+
 size_t generic_smem(const pyn_ctx* c, int ngt, bool pt_lds) {
   size_t s = (size_t)c->nc * c->dim * sizeof(double) + (size_t)((c->nn + 1) & ~1) * sizeof(int32_t);
   if (pt_lds) s += (size_t)ngt * (c->dim * c->dim + 1 + c->dim * c->nn) * sizeof(double);
@@ -505,7 +582,19 @@ static int run_assembly(pyn_ctx* c, int form, double alpha_d, double alpha_w, do
     if (Krhs) PYN_HIP(hipMemsetAsync(Krhs, 0, nb * ndof * ndof, c->stream));
     if (Rw) PYN_HIP(hipMemsetAsync(Rw, 0, nb * ndof * dw, c->stream));
     if (Rd) PYN_HIP(hipMemsetAsync(Rd, 0, nb * ndof, c->stream));
-    PYN_TRY(launch_generic<false>(c, A, c->n_elem));
+    const QuadTab& q0 = c->quad[0];
+    if (form == PYN_FORM_LAPLACE && c->nn == c->dim + 1 && q0.const_grad && !getenv("PYNAMA_NO_P1")) {
+      const int grid = (int)((c->n_elem + 255) / 256);
+      if (c->dim == 3)
+        assemble_p1_laplace_kernel<3><<<grid, 256, 0, c->stream>>>(c->d_conn, c->d_xyz, c->n_elem, c->n_owned, c->d_rowptr,
+                                                                  c->d_colidx, c->d_bcmask, q0.Hrs, q0.wsum, K, Krhs);
+      else
+        assemble_p1_laplace_kernel<2><<<grid, 256, 0, c->stream>>>(c->d_conn, c->d_xyz, c->n_elem, c->n_owned, c->d_rowptr,
+                                                                  c->d_colidx, c->d_bcmask, q0.Hrs, q0.wsum, K, Krhs);
+      PYN_HIP(hipGetLastError());
+    } else {
+      PYN_TRY(launch_generic<false>(c, A, c->n_elem));
+    }
   }
   if (!handled && c->d_bcmask && (K || Krhs)) {
     int64_t n = c->n_owned * ndof;

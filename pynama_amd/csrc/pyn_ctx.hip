@@ -290,6 +290,15 @@ extern "C" int pyn_elem_tables_set(pyn_ctx* c, int which, int ngp, const double*
   PYN_TRY(dev_upload(&q.H, H, (size_t)ngp * c->nn, c->stream));
   PYN_TRY(dev_upload(&q.Hrs, Hrs, (size_t)ngp * c->dim * c->nn, c->stream));
   PYN_TRY(dev_upload(&q.HrsCoo, HrsCoo, (size_t)ngp * c->dim * c->nc, c->stream));
+  q.wsum = 0.0;
+  for (int g = 0; g < ngp; ++g) q.wsum += w[g];
+  q.const_grad = c->nc == c->nn;
+  for (int g = 0; g < ngp && q.const_grad; ++g)
+    for (int t = 0; t < c->dim * c->nn; ++t)
+      if (Hrs[(size_t)g * c->dim * c->nn + t] != Hrs[t] || HrsCoo[(size_t)g * c->dim * c->nn + t] != Hrs[t]) {
+        q.const_grad = false;
+        break;
+      }
   if (which == PYN_Q_FULL && c->dim == 3 && c->nn == 8 && ngp == 8) {
     // Tables of the affine shortcut of the tiled Q1-hex kernel (exact for parallelepipeds, where
     // J is constant):  L_ab = detJ * sum_{r<=s} Q_rs T_rs[ab],  Q = J^-T J^-1 (reference axes),

@@ -70,6 +70,9 @@ struct QuadTab {
   double* H = nullptr;       // [ngp][nn]
   double* Hrs = nullptr;     // [ngp][dim][nn]
   double* HrsCoo = nullptr;  // [ngp][dim][nc]
+  // host facts about the tables (set by pyn_elem_tables_set)
+  double wsum = 0.0;         // sum of the weights
+  bool const_grad = false;   // Hrs and HrsCoo identical at every point and to each other (affine simplex)
 };
 
 struct DMat {

@@ -130,3 +130,73 @@ def test_c3_kle_128cubed_properties():
     assert info.reason == 2 and info.true_resid <= 1e-10
     assert np.abs(x - [1.0, 0.0, 0.0]).max() < 1e-7
     ctx.close()
+
+
+def test_c5_unstructured_tets_gmsh_gmres(tmp_path):
+    """configs[4]: ~5M tetrahedra (94^3 hexes cut in 6, randomly renumbered nodes), written to and imported
+    from a Gmsh file, Poisson with GMRES(30)+Jacobi -- the irregular-indexing configuration"""
+    import os
+    from pynama_amd import _lib
+    from pynama_amd.domain.dmplex import DMPlexDom
+    from pynama_amd.domain.gmsh import write_msh
+    from pynama_amd.elements.simplex import Simplex
+    n = 94
+    src = fo.simplex_box_mesh([n, n, n], [0.0] * 3, [1.0] * 3, jitter=0.2, permute_seed=2024)
+    assert src.n_elem == 4983504
+    path = str(tmp_path / "c5.msh")
+    write_msh(path, src.xyz, src.conn)
+    dom = DMPlexDom(fileName=path)
+    dom.setFemIndexing(2)
+    os.remove(path)
+    assert dom.cellType == "simplex" and dom.nOwned == (n + 1) ** 3 and dom.conn.shape == (src.n_elem, 4)
+    ctx = dom.ctx
+    for t in Simplex(3).deviceTables():
+        ctx.tables_set(*t)
+    n_rows, nnz = ctx.csr_symbolic()
+    edges = np.sort(src.conn[:, [[0, 1], [0, 2], [0, 3], [1, 2], [1, 3], [2, 3]]].reshape(-1, 2), axis=1)
+    n_edges = len(np.unique(edges[:, 0].astype(np.int64) * src.n_node + edges[:, 1]))
+    assert nnz == n_rows + 2 * n_edges                                  # node graph = mesh edges + diagonal
+    del edges
+    # (1) no mask: the one-lane-per-cell kernel and the table-driven generic kernel agree entry by entry
+    A, B = ctx.mat_create(1, 1), ctx.mat_create(1, 1)
+    ctx.assemble_scalar(_lib.FORM_LAPLACE, A)
+    os.environ["PYNAMA_NO_P1"] = "1"
+    try:
+        ctx.assemble_scalar(_lib.FORM_LAPLACE, B)
+    finally:
+        del os.environ["PYNAMA_NO_P1"]
+    va, vb_ = ctx.mat_values(A, 1, 1), ctx.mat_values(B, 1, 1)
+    assert np.abs(va - vb_).max() < 2e-13 * np.abs(vb_).max()
+    del va, vb_
+    # (2) constants are annihilated, linear fields are discretely harmonic (P1 exactness), A is symmetric
+    bm = dom.boundaryMaskLocal()
+    u, v, Au, Av = (ctx.vec_create(1) for _ in range(4))
+    ctx.vec_fill(u, 1.0)
+    ctx.spmv(A, u, Au)
+    assert ctx.vec_norm(Au, 3) < 1e-12
+    ctx.vec_set(u, dom.xyz @ np.array([1.0, 2.0, 3.0]))
+    ctx.spmv(A, u, Au)
+    assert np.abs(ctx.vec_get(Au, 1)[bm == 0]).max() < 1e-12
+    rng = np.random.default_rng(3)
+    ctx.vec_set(u, rng.standard_normal(n_rows))
+    ctx.vec_set(v, rng.standard_normal(n_rows))
+    ctx.spmv(A, u, Au)
+    ctx.spmv(A, v, Av)
+    assert abs(ctx.vec_dot(v, Au) - ctx.vec_dot(u, Av)) < 1e-10 * abs(ctx.vec_dot(v, Au))
+    # (3) Dirichlet problem: GMRES(30)+Jacobi to the 1e-10 residual bar; CG lands on the same solution
+    ctx.bc_set(1, bm)
+    ctx.assemble_scalar(_lib.FORM_LAPLACE, A)
+    X = dom.xyz
+    f = (1.0 + X[:, 0] + 2.0 * X[:, 1] ** 2 + np.exp(X[:, 0] * X[:, 1] * X[:, 2])) / n ** 3
+    f[bm != 0] = 0.0
+    ctx.vec_set(u, f)
+    # (GMRES tests its recurrence estimate of the residual; after ~50 restarts it drifts from the true one in
+    # the third digit, so the 1e-10 bar on the TRUE residual is asked with rtol 5e-11)
+    info = ctx.solve(A, u, v, method=_lib.KSP_GMRES, pc=_lib.PC_JACOBI, rtol=5e-11, restart=30, maxit=100000,
+                     norm_type=_lib.NORM_UNPRECONDITIONED)
+    assert info.reason == 2 and info.true_resid <= 1e-10
+    xg = ctx.vec_get(v, 1)
+    info = ctx.solve(A, u, v, method=_lib.KSP_CG, pc=_lib.PC_JACOBI, rtol=1e-12, norm_type=_lib.NORM_UNPRECONDITIONED)
+    assert info.reason == 2
+    assert rel_err(xg, ctx.vec_get(v, 1)) < 1e-6
+    ctx.close()
