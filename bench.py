@@ -82,7 +82,9 @@ def main():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--nel", type=int, default=215, help="elements per side (215 -> 10,077,696 DOFs)")
     ap.add_argument("--cg-iters", type=int, default=100, help="fixed CG iterations per step")
-    ap.add_argument("--variant", type=int, default=1, help="assembly kernel: 0 generic atomics, 1 auto")
+    ap.add_argument("--variant", type=int, default=1, help="assembly kernel: 0 generic atomics, 1 auto (plan-free lattice kernel on box meshes), "
+                    "2 patch-plan kernel on 7x7x7 tiles")
+    ap.add_argument("--jitter", type=float, default=0.0, help="diagnostics: perturb interior nodes by jitter*h (general geometry)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-check", action="store_true")
     args = ap.parse_args()
@@ -97,7 +99,7 @@ def main():
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world.size}: launch with "
                          f"python -m torch.distributed.run --nproc-per-node {args.gpus} bench.py ...")
     n = args.nel
-    dom = DMPlexDom(boxMesh={"nelem": [n, n, n], "lower": [0, 0, 0], "upper": [1, 1, 1]})
+    dom = DMPlexDom(boxMesh={"nelem": [n, n, n], "lower": [0, 0, 0], "upper": [1, 1, 1]}, jitter=args.jitter)
     dom.setFemIndexing(2)
     ctx = dom.ctx                                     # creates the context, RCCL comm, uploads the mesh
     for t in Spectral(2, 3).deviceTables():
@@ -106,8 +108,8 @@ def main():
     ctx.bc_set(1, bmask)
     n_rows, nnz = ctx.csr_symbolic()
     symbolic_ms = ctx.timers()["symbolic_ms"]
-    if args.variant == 1:
-        ctx.patch_plan_set(*dom.patchPlan((7, 7, 7)))       # plan of the tiled (atomics-free) assembly
+    if args.variant == 2:
+        ctx.patch_plan_set(*dom.patchPlan((7, 7, 7)))       # explicit plan: the patch-plan kernel instead of the lattice one
     A = ctx.mat_create(1, 1)
     vb, vx = ctx.vec_create(1), ctx.vec_create(1)
     h = 1.0 / n

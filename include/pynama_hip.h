@@ -97,6 +97,10 @@ int pyn_halo_set(pyn_ctx* ctx, int64_t n_owned, int64_t n_ghost, int n_neigh, co
  * HrsCoo has dim+1 columns, and every entry point below works unchanged. */
 int pyn_mesh_set(pyn_ctx* ctx, int dim, int nn, int64_t n_elem, int64_t n_node,
                  const int32_t* conn, const double* xyz);
+/* Topology recognised by pyn_mesh_set: kind 0 = general connectivity, 1 = structured lattice of Q1
+ * hexahedra (the reference's box mesh, src/domain/dmplex.py:8-21, or a rank's z-slab of one): nx, ny =
+ * nodes per x / y line, nz = node planes of the local mesh.  Lattices are assembled by a plan-free kernel. */
+int pyn_mesh_topology(pyn_ctx* ctx, int* kind, int* nx, int* ny, int* nz);
 /* One quadrature's tables -- Spectral.computeMats2D/3D output (spectral.py:220-344):
  * w[ngp], H[ngp*nn], Hrs[ngp*dim*nn], HrsCoo[ngp*dim*2^dim] (geometry basis, spectral.py:54-61). */
 int pyn_elem_tables_set(pyn_ctx* ctx, int which, int ngp, const double* w, const double* H,

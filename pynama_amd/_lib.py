@@ -60,6 +60,7 @@ SIGNATURES = {
     "pyn_comm_allreduce_f64": [_P, _pf64, _I, _I],
     "pyn_halo_set": [_P, _L, _L, _I, _pi32, _pi64, _pi32, _pi64],
     "pyn_mesh_set": [_P, _I, _I, _L, _L, _pi32, _pf64],
+    "pyn_mesh_topology": [_P, C.POINTER(_I), C.POINTER(_I), C.POINTER(_I), C.POINTER(_I)],
     "pyn_elem_tables_set": [_P, _I, _I, _pf64, _pf64, _pf64, _pf64],
     "pyn_bc_set": [_P, _I, _P],
     "pyn_csr_symbolic": [_P],
@@ -222,6 +223,12 @@ class Context:
         self.dim, self.nn, self.n_elem, self.n_node = dim, nn, n_elem, n_node
         if not getattr(self, "_halo", False):
             self.n_owned, self.n_ghost = n_node, 0
+
+    def mesh_topology(self):
+        """('lattice', nx, ny, nz) for structured Q1 hex meshes, ('general', 0, 0, 0) otherwise"""
+        k, a, b, c = _I(0), _I(0), _I(0), _I(0)
+        _check(self.lib.pyn_mesh_topology(self.h, C.byref(k), C.byref(a), C.byref(b), C.byref(c)))
+        return ("lattice" if k.value else "general", a.value, b.value, c.value)
 
     def tables_set(self, which, w, H, Hrs, HrsCoo):
         w = _f64(w)

@@ -432,6 +432,380 @@ __global__ void __launch_bounds__(TILE_THREADS, 2) assemble_q1_hex_tiled_kernel(
 }
 
 
+
+// =================================================================================================
+// Plan-free variant for meshes with STRUCTURED topology (box meshes: the reference's primary mesh,
+// DMPlexDom.createBoxMesh, src/domain/dmplex.py:8-21; a rank's z-slab of one included).  Same scheme
+// as the patch kernel -- a workgroup owns a TX x TY x TZ tile of rows, integrates every element touching
+// it (one per lane), accumulates in LDS, writes each CSR row once -- but every index comes from integer
+// arithmetic on the lattice descriptor instead of from HBM: no element list, no row-slot / scatter-map
+// stream (84 B per patch-element in the plan), no dependent load chains in front of the stores.
+// LDS accumulators use a fixed 27-point stencil layout acc[row][(dz+1)*9 + (dy+1)*3 + (dx+1)], so the
+// LDS address of pair (a, b) is row_slot(a)*27 + a compile-time constant; the store phase maps CSR slot
+// k of a row (columns sorted by node id: z-plane order from `zord`, then y, then x, clipped at the
+// domain faces) back to the stencil position.
+struct LatArgs {
+  const double* xyz;
+  const int32_t* rowptr;
+  const uint8_t* bcmask;   // per node, may be null
+  const int32_t* P;        // [npl] first node id of every z-plane
+  const int32_t* zord;     // [npl]
+  int nx, ny, npl, p_own0, n_own;
+  int ntx, nty;            // tiles per direction
+  int ablate;              // diagnostics (PYNAMA_LATTICE_ABLATE): 1 no element phase, 2 no LDS adds, 3 no coordinate loads
+  TileArgs q;              // quadrature tables (w, hrs, hcoo, aff) -- only those fields are used
+  double* A;
+  double* Arhs;
+};
+
+template <int TX, int TY, int TZ>
+struct LatTile {
+  static constexpr int NR = TX * TY * TZ, EX = TX + 1, EY = TY + 1, EZ = TZ + 1, NE = EX * EY * EZ;
+  static constexpr int BX = TX + 2, BY = TY + 2, BZ = TZ + 2, NB = BX * BY * BZ;
+  static constexpr int ACC = NR * 27;                                  // doubles
+  static constexpr int META_INTS = NR + TZ + (NB + 3) / 4;             // rlo[NR], zrd[TZ], nbc[NB] bytes
+  static constexpr size_t BYTES = ACC * sizeof(double) + META_INTS * sizeof(int);
+};
+
+// row offsets, z-order codes and Dirichlet flags of a tile -> LDS (loads only; nt threads, index t)
+template <int TX, int TY, int TZ>
+__device__ __forceinline__ int lat_preload(const LatArgs& T, int x0, int y0, int z0, int* rlo, int* zrd, unsigned char* nbc,
+                                           int t, int nt) {
+  using L = LatTile<TX, TY, TZ>;
+  const int nx = T.nx, ny = T.ny;
+  const int32_t* __restrict__ P = T.P;
+  int any = 0;
+  for (int i = t; i < L::NB; i += nt) {
+    const int qx = i % L::BX, qy = (i / L::BX) % L::BY, qz = i / (L::BX * L::BY);
+    const int x = x0 - 1 + qx, y = y0 - 1 + qy, pl = T.p_own0 + z0 - 1 + qz;
+    unsigned char f = 0;
+    if (T.bcmask && x >= 0 && x < nx && y >= 0 && y < ny && pl >= 0 && pl < T.npl) f = T.bcmask[P[pl] + y * nx + x] ? 1 : 0;
+    nbc[i] = f;
+    any |= f;
+  }
+  for (int s = t; s < L::NR; s += nt) {
+    const int rx = s % TX, ry = (s / TX) % TY, rz = s / (TX * TY);
+    const int x = x0 + rx, y = y0 + ry, zo = z0 + rz;
+    rlo[s] = (x < nx && y < ny && zo < T.n_own) ? T.rowptr[P[T.p_own0 + zo] + y * nx + x] : -1;
+  }
+  if (t < TZ) zrd[t] = (z0 + t < T.n_own) ? T.zord[T.p_own0 + z0 + t] : 0;
+  return any;
+}
+
+// integrate every element touching the tile (one per lane) and add the rows the tile owns into acc
+template <int TX, int TY, int TZ>
+__device__ __forceinline__ void lat_integrate(const LatArgs& T, int x0, int y0, int z0, double* acc, int t0, int nt) {
+  using LT = LatTile<TX, TY, TZ>;
+  const int nx = T.nx, ny = T.ny;
+  const int32_t* __restrict__ P = T.P;
+  // corner offsets (dx, dy, dz) in the reference's closure order
+  constexpr int CX[8] = {0, 0, 1, 1, 0, 1, 1, 0};
+  constexpr int CY[8] = {0, 1, 1, 0, 0, 0, 1, 1};
+  constexpr int CZ[8] = {0, 0, 0, 0, 1, 1, 1, 1};
+  for (int t = t0; t < LT::NE; t += nt) {
+    const int lx = t % LT::EX, ly = (t / LT::EX) % LT::EY, lz = t / (LT::EX * LT::EY);
+    const int gx = x0 - 1 + lx, gy = y0 - 1 + ly, gl = T.p_own0 + z0 - 1 + lz;
+    if (gx < 0 || gx >= nx - 1 || gy < 0 || gy >= ny - 1 || gl < 0 || gl >= T.npl - 1) continue;
+    const int n00 = gy * nx + gx;
+    const int pb = P[gl] + n00, pt = P[gl + 1] + n00;
+    double X[8][3];
+#pragma unroll
+    for (int a = 0; a < 8; ++a) {
+      const int node = (CZ[a] ? pt : pb) + CY[a] * nx + CX[a];
+      const double* q = T.xyz + (int64_t)node * 3;
+      X[a][0] = q[0];
+      X[a][1] = q[1];
+      X[a][2] = q[2];
+    }
+    double L[36];
+    if (T.q.aff && __all(element_is_affine(T.q, X) ? 1 : 0)) {
+      affine_laplace(T.q, X, L);
+    } else {
+#pragma unroll
+      for (int i = 0; i < 36; ++i) L[i] = 0.0;
+#pragma nounroll
+      for (int g = 0; g < 8; ++g) gauss_point(T.q, g, X, L);
+    }
+#pragma unroll
+    for (int a = 0; a < 8; ++a) {
+      const int rx = lx - 1 + CX[a], ry = ly - 1 + CY[a], rz = lz - 1 + CZ[a];
+      // the row exists in x, y (the element does); in z it must be one of this tile's OWNED planes
+      if (rx < 0 || rx >= TX || ry < 0 || ry >= TY || rz < 0 || rz >= TZ || z0 + rz >= T.n_own) continue;
+      double* row = acc + ((rz * TY + ry) * TX + rx) * 27;
+#pragma unroll
+      for (int c = 0; c < 8; ++c) {
+        const int kk = (CZ[c] - CZ[a] + 1) * 9 + (CY[c] - CY[a] + 1) * 3 + (CX[c] - CX[a] + 1);
+        atomicAdd(&row[kk], L[tri(a, c)]);
+      }
+    }
+  }
+}
+
+// write every row of the tile once (half a wave per row, UNROLL rows in flight): A gets the free columns,
+// Arhs the imposed ones (negated), imposed rows become identity rows (mat_generator.py:113-118).
+// ZERO: clear each accumulator after reading it (the buffer is reused by the next tile).
+template <int TX, int TY, int TZ, bool ZERO>
+__device__ __forceinline__ void lat_store(const LatArgs& T, int x0, int y0, double* acc, const int* rlo, const int* zrd,
+                                          const unsigned char* nbc, int t, int nt) {
+  using LT = LatTile<TX, TY, TZ>;
+  const int nx = T.nx, ny = T.ny;
+  double* __restrict__ outA = T.A;
+  double* __restrict__ outR = T.Arhs;
+  const int half = t >> 5, k = t & 31;
+  const int NH = nt >> 5;
+  constexpr int UNROLL = 4;
+  for (int s0 = half; s0 < LT::NR; s0 += NH * UNROLL) {
+    int lo[UNROLL];
+    double va[UNROLL], vr[UNROLL];
+#pragma unroll
+    for (int u = 0; u < UNROLL; ++u) {
+      const int s = s0 + u * NH;
+      lo[u] = -1;
+      if (s >= LT::NR) continue;
+      const int rl = rlo[s];
+      const int rx = s % TX, ry = (s / TX) % TY, rz = s / (TX * TY);
+      const int x = x0 + rx, y = y0 + ry;
+      const int zi = zrd[rz];
+      const int cx = 3 - (x == 0) - (x == nx - 1), cy = 3 - (y == 0) - (y == ny - 1), cz = zi & 3;
+      const int cc = cx * cy;
+      if (rl < 0 || k >= cc * cz) {
+        if (ZERO && k < 27) acc[s * 27 + k] = 0.0;   // rows outside the domain never receive adds; keep them clean anyway
+        continue;
+      }
+      const int kz = (k >= cc) + (k >= 2 * cc);
+      const int r = k - kz * cc;
+      const int ky = (r >= cx) + (r >= 2 * cx);
+      const int kx = r - ky * cx;
+      const int dz = ((zi >> (2 + 2 * kz)) & 3) - 1;
+      const int dy = ky - (y != 0), dx = kx - (x != 0);
+      const int ai = s * 27 + (dz + 1) * 9 + (dy + 1) * 3 + (dx + 1);
+      const double v = acc[ai];
+      if (ZERO) acc[ai] = 0.0;
+      const int bi = ((rz + 1) * LT::BY + ry + 1) * LT::BX + rx + 1;
+      if (nbc[bi]) {
+        va[u] = vr[u] = (dx == 0 && dy == 0 && dz == 0) ? 1.0 : 0.0;
+      } else if (nbc[bi + (dz * LT::BY + dy) * LT::BX + dx]) {
+        va[u] = 0.0;
+        vr[u] = -v;
+      } else {
+        va[u] = v;
+        vr[u] = 0.0;
+      }
+      lo[u] = rl + k;
+    }
+#pragma unroll
+    for (int u = 0; u < UNROLL; ++u) {
+      if (lo[u] < 0) continue;
+      outA[lo[u]] = va[u];
+      if (outR) outR[lo[u]] = vr[u];
+    }
+  }
+}
+
+// Store phase of a "plain" tile -- no row on a domain face, the three z-neighbour planes in ascending id order,
+// no imposed node in the node box: CSR slot k of a row IS stencil position k, and the TX rows of an x-line are
+// one contiguous run of TX*27 doubles both in LDS and in the CSR value array.  Straight coalesced copy.
+constexpr int ZCODE_STD = 3 | (0 << 2) | (1 << 4) | (2 << 6);
+template <int TX, int TY, int TZ, bool ZERO>
+__device__ __forceinline__ void lat_store_plain(const LatArgs& T, double* acc, const int* rlo, int t, int nt) {
+  constexpr int LINE = TX * 27, NL = TY * TZ, PER = (LINE + 63) / 64;
+  double* __restrict__ outA = T.A;
+  double* __restrict__ outR = T.Arhs;
+  const int w = t >> 6, lane = t & 63, nw = nt >> 6;
+  for (int l = w; l < NL; l += nw) {
+    const int base = rlo[l * TX];
+    double v[PER];
+#pragma unroll
+    for (int j = 0; j < PER; ++j) {
+      const int i = lane + 64 * j;
+      v[j] = (i < LINE) ? acc[l * LINE + i] : 0.0;
+      if (ZERO && i < LINE) acc[l * LINE + i] = 0.0;
+    }
+#pragma unroll
+    for (int j = 0; j < PER; ++j) {
+      const int i = lane + 64 * j;
+      if (i < LINE) {
+        outA[base + i] = v[j];
+        if (outR) outR[base + i] = 0.0;
+      }
+    }
+  }
+}
+
+template <int TX, int TY, int TZ>
+__device__ __forceinline__ bool lat_tile_plain(const LatArgs& T, int x0, int y0, int z0, const int* zrd, int anybc) {
+  bool plain = !anybc && x0 >= 1 && x0 + TX <= T.nx - 1 && y0 >= 1 && y0 + TY <= T.ny - 1 && z0 + TZ <= T.n_own;
+  for (int j = 0; j < TZ; ++j) plain = plain && zrd[j] == ZCODE_STD;
+  return plain;
+}
+
+// 72 * T_rs[a][b] of the trilinear hexahedron in the reference's corner order, in closed form from the corner
+// signs s_d(a) (tensor product of the 1-D integrals  int N_i N_j = (3 + s_i s_j)/6,  int N_i' N_j' = s_i s_j/2,
+// int N_i' N_j = s_i/2):  rr: s_r(a)s_r(b)(3+s_p s_p)(3+s_q s_q);  rs: 3(3+s_u s_u)(s_r(a)s_s(b)+s_s(a)s_r(b)).
+// pyn_elem_tables_set checks the uploaded tables against it (lat_aff_standard) before the lean path is used.
+__host__ __device__ constexpr int q1_aff_int(int t, int a, int b) {
+  constexpr int SG[3][8] = {{-1, -1, 1, 1, -1, 1, 1, -1}, {-1, 1, 1, -1, -1, -1, 1, 1}, {-1, -1, -1, -1, 1, 1, 1, 1}};
+  constexpr int RS[6][2] = {{0, 0}, {1, 1}, {2, 2}, {0, 1}, {0, 2}, {1, 2}};
+  const int r = RS[t][0], s2 = RS[t][1];
+  if (r == s2) {
+    const int p = (r + 1) % 3, q = (r + 2) % 3;
+    return SG[r][a] * SG[r][b] * (3 + SG[p][a] * SG[p][b]) * (3 + SG[q][a] * SG[q][b]);
+  }
+  const int u = 3 - r - s2;
+  return 3 * (3 + SG[u][a] * SG[u][b]) * (SG[r][a] * SG[s2][b] + SG[s2][a] * SG[r][b]);
+}
+
+// Lean integration for meshes whose elements are ALL parallelepipeds (every box mesh the reference creates,
+// src/domain/dmplex.py:8-21): four corner loads instead of eight, J = S.E from the three edge vectors
+// (S[d][m] = sum_c hcoo[d][c] C_m[c], a table constant), L_ab = detJ sum_{r<=s} Q_rs T_rs[ab]; no quadrature
+// loop, no affinity test: ~110 VGPRs instead of ~170, i.e. 4 instead of 2-3 waves per SIMD to hide the gather
+// and store latencies.
+template <int TX, int TY, int TZ>
+__device__ __forceinline__ void lat_integrate_affine(const LatArgs& T, int x0, int y0, int z0, double* acc, int t0, int nt) {
+  using LT = LatTile<TX, TY, TZ>;
+  const int nx = T.nx, ny = T.ny;
+  const int32_t* __restrict__ P = T.P;
+  const double* __restrict__ S = T.q.aff + 248;
+  constexpr int CX[8] = {0, 0, 1, 1, 0, 1, 1, 0};
+  constexpr int CY[8] = {0, 1, 1, 0, 0, 0, 1, 1};
+  constexpr int CZ[8] = {0, 0, 0, 0, 1, 1, 1, 1};
+  for (int t = t0; t < LT::NE; t += nt) {
+    const int lx = t % LT::EX, ly = (t / LT::EX) % LT::EY, lz = t / (LT::EX * LT::EY);
+    const int gx = x0 - 1 + lx, gy = y0 - 1 + ly, gl = T.p_own0 + z0 - 1 + lz;
+    if (gx < 0 || gx >= nx - 1 || gy < 0 || gy >= ny - 1 || gl < 0 || gl >= T.npl - 1) continue;
+    const int n00 = gy * nx + gx;
+    const double* q0 = T.xyz + (int64_t)(P[gl] + n00) * 3;
+    const double* qz = T.xyz + (int64_t)(P[gl + 1] + n00) * 3;
+    double E[3][3];  // edge vectors along the lattice x, y, z directions
+#pragma unroll
+    for (int x = 0; x < 3; ++x) {
+      const double o = q0[x];
+      E[0][x] = q0[3 + x] - o;
+      E[1][x] = q0[3 * nx + x] - o;
+      E[2][x] = qz[x] - o;
+    }
+    double J[3][3];
+#pragma unroll
+    for (int d = 0; d < 3; ++d)
+#pragma unroll
+      for (int x = 0; x < 3; ++x) J[d][x] = fma(S[d * 3 + 2], E[2][x], fma(S[d * 3 + 1], E[1][x], S[d * 3] * E[0][x]));
+    const double c00 = J[1][1] * J[2][2] - J[1][2] * J[2][1];
+    const double c01 = J[1][2] * J[2][0] - J[1][0] * J[2][2];
+    const double c02 = J[1][0] * J[2][1] - J[1][1] * J[2][0];
+    const double det = J[0][0] * c00 + J[0][1] * c01 + J[0][2] * c02;
+    const double r = 1.0 / det;
+    double Ji[3][3];
+    Ji[0][0] = c00 * r;
+    Ji[0][1] = (J[0][2] * J[2][1] - J[0][1] * J[2][2]) * r;
+    Ji[0][2] = (J[0][1] * J[1][2] - J[0][2] * J[1][1]) * r;
+    Ji[1][0] = c01 * r;
+    Ji[1][1] = (J[0][0] * J[2][2] - J[0][2] * J[2][0]) * r;
+    Ji[1][2] = (J[0][2] * J[1][0] - J[0][0] * J[1][2]) * r;
+    Ji[2][0] = c02 * r;
+    Ji[2][1] = (J[0][1] * J[2][0] - J[0][0] * J[2][1]) * r;
+    Ji[2][2] = (J[0][0] * J[1][1] - J[0][1] * J[1][0]) * r;
+    double Q[6];
+    {
+      constexpr int RS[6][2] = {{0, 0}, {1, 1}, {2, 2}, {0, 1}, {0, 2}, {1, 2}};
+#pragma unroll
+      for (int u = 0; u < 6; ++u) {
+        const int a = RS[u][0], b = RS[u][1];
+        Q[u] = det * (Ji[0][a] * Ji[0][b] + Ji[1][a] * Ji[1][b] + Ji[2][a] * Ji[2][b]);
+      }
+    }
+    // 72 T_rs[ab] are small integers for the trilinear element (q1_aff_int): 15 products, then signed sums --
+    // no table traffic at all inside the loop
+    double L[36];
+    {
+      double D[3][3], M[3][2];
+#pragma unroll
+      for (int u = 0; u < 3; ++u) {
+        const double qd = Q[u] * (1.0 / 72.0), qm = Q[3 + u] * (1.0 / 72.0);
+        D[u][0] = 4.0 * qd;
+        D[u][1] = 8.0 * qd;
+        D[u][2] = 16.0 * qd;
+        M[u][0] = 12.0 * qm;
+        M[u][1] = 24.0 * qm;
+      }
+      int idx = 0;
+#pragma unroll
+      for (int a = 0; a < 8; ++a)
+#pragma unroll
+        for (int c = a; c < 8; ++c, ++idx) {
+          double v = 0.0;
+#pragma unroll
+          for (int u = 0; u < 6; ++u) {
+            const int n = q1_aff_int(u, a, c);
+            const int an = n < 0 ? -n : n;
+            if (an == 0) continue;
+            const double x = u < 3 ? D[u][an == 4 ? 0 : (an == 8 ? 1 : 2)] : M[u - 3][an == 12 ? 0 : 1];
+            v = n > 0 ? v + x : v - x;
+          }
+          L[idx] = v;
+        }
+    }
+#pragma unroll
+    for (int a = 0; a < 8; ++a) {
+      const int rx = lx - 1 + CX[a], ry = ly - 1 + CY[a], rz = lz - 1 + CZ[a];
+      if (rx < 0 || rx >= TX || ry < 0 || ry >= TY || rz < 0 || rz >= TZ || z0 + rz >= T.n_own) continue;
+      double* row = acc + ((rz * TY + ry) * TX + rx) * 27;
+#pragma unroll
+      for (int c = 0; c < 8; ++c) {
+        const int kk = (CZ[c] - CZ[a] + 1) * 9 + (CY[c] - CY[a] + 1) * 3 + (CX[c] - CX[a] + 1);
+        atomicAdd(&row[kk], L[tri(a, c)]);
+      }
+    }
+  }
+}
+
+// one-off check behind the lean path: is every element of the lattice a parallelepiped?
+__global__ void lattice_all_affine_kernel(LatArgs T, int64_t n_elem, int* flag) {
+  const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= n_elem) return;
+  const int ex = T.nx - 1, ey = T.ny - 1;
+  const int ix = (int)(e % ex), iy = (int)((e / ex) % ey), l = (int)(e / ((int64_t)ex * ey));
+  constexpr int CX[8] = {0, 0, 1, 1, 0, 1, 1, 0};
+  constexpr int CY[8] = {0, 1, 1, 0, 0, 0, 1, 1};
+  constexpr int CZ[8] = {0, 0, 0, 0, 1, 1, 1, 1};
+  double X[8][3];
+#pragma unroll
+  for (int a = 0; a < 8; ++a) {
+    const double* q = T.xyz + (int64_t)(T.P[l + CZ[a]] + (iy + CY[a]) * T.nx + ix + CX[a]) * 3;
+    X[a][0] = q[0];
+    X[a][1] = q[1];
+    X[a][2] = q[2];
+  }
+  if (!element_is_affine(T.q, X)) *flag = 0;
+}
+
+// one tile per workgroup
+template <int TX, int TY, int TZ, bool AFF>
+__global__ void __launch_bounds__(TILE_THREADS, AFF ? 3 : 2) assemble_q1_hex_lattice_kernel(LatArgs T) {
+  using LT = LatTile<TX, TY, TZ>;
+  extern __shared__ __align__(16) double lds[];
+  double* acc = lds;
+  int* rlo = reinterpret_cast<int*>(acc + LT::ACC);
+  int* zrd = rlo + LT::NR;
+  unsigned char* nbc = reinterpret_cast<unsigned char*>(zrd + TZ);
+  const int tid = threadIdx.x;
+  const int b = blockIdx.x;
+  const int bx = b % T.ntx, by = (b / T.ntx) % T.nty, bz = b / (T.ntx * T.nty);
+  const int x0 = bx * TX, y0 = by * TY, z0 = bz * TZ;
+  for (int i = tid; i < LT::ACC; i += TILE_THREADS) acc[i] = 0.0;
+  const int anybc = __syncthreads_or(lat_preload<TX, TY, TZ>(T, x0, y0, z0, rlo, zrd, nbc, tid, TILE_THREADS));
+  if (T.ablate != 1) {
+    if (AFF)
+      lat_integrate_affine<TX, TY, TZ>(T, x0, y0, z0, acc, tid, TILE_THREADS);
+    else
+      lat_integrate<TX, TY, TZ>(T, x0, y0, z0, acc, tid, TILE_THREADS);
+  }
+  __syncthreads();
+  if (lat_tile_plain<TX, TY, TZ>(T, x0, y0, z0, zrd, anybc) && T.ablate != 4)
+    lat_store_plain<TX, TY, TZ, false>(T, acc, rlo, tid, TILE_THREADS);
+  else
+    lat_store<TX, TY, TZ, false>(T, x0, y0, acc, rlo, zrd, nbc, tid, TILE_THREADS);
+}
+
 // =================================================================================================
 // Tiled KLE assembly (3 DOF per node): K, Krhs (WHICH = 0) and Rw (WHICH = 1) of
 // FreeSlip.buildKLEMats (src/cases/base_problem.py:499-552) without HBM atomics.
@@ -720,10 +1094,23 @@ static size_t kle_lds_bytes(int max_rows, int maxlen) {
 
 }  // namespace
 
+bool pyn_q1_affine_tables_standard(const double* aff) {  // aff[6][36] as built by pyn_elem_tables_set
+  for (int t = 0; t < 6; ++t) {
+    int idx = 0;
+    for (int a = 0; a < 8; ++a)
+      for (int b = a; b < 8; ++b, ++idx)
+        if (fabs(aff[t * 36 + idx] - q1_aff_int(t, a, b) / 72.0) > 1e-13) return false;
+  }
+  return true;
+}
+
+
 // -------------------------------------------------------------------------------------------------
 extern "C" int pyn_patch_plan_set(pyn_ctx* c, int n_patch, const int32_t* patch_ptr, const int32_t* patch_rows) {
   return pyn_patch_plan_set_kind(c, 0, n_patch, patch_ptr, patch_rows);
 }
+
+static bool g_default_plan = false;  // pyn_patch_plan_set_kind called by ensure_default_plan
 
 extern "C" int pyn_patch_plan_set_kind(pyn_ctx* c, int kind, int n_patch, const int32_t* patch_ptr, const int32_t* patch_rows) {
   PYN_CHECK(c, "ctx is NULL");
@@ -806,6 +1193,7 @@ extern "C" int pyn_patch_plan_set_kind(pyn_ctx* c, int kind, int n_patch, const 
   int maxlen = 0;
   for (int64_t i = 0; i < c->n_owned; ++i) maxlen = std::max(maxlen, rp[i + 1] - rp[i]);
   P.npatch = n_patch;
+  P.user = !g_default_plan;
   P.npe = npe;
   P.maxrows = max_rows;
   P.maxlen = maxlen;
@@ -877,6 +1265,163 @@ static int assemble_kle_tiled(pyn_ctx* c, double alpha_d, double alpha_w, double
 
 // Meshes without a caller-supplied plan get patches of consecutive rows: optimal for no numbering in
 // particular, but any partition is valid and even 8x redundant integration beats the HBM-atomic scatter.
+
+// ---- structured topology: detection (host, once per pyn_mesh_set) and launch -------------------------
+int pyn_lattice_detect(pyn_ctx* c, const int32_t* conn) {
+  Lattice& L = c->lat;
+  (void)hipFree(L.d_P);
+  (void)hipFree(L.d_zord);
+  L = Lattice();
+  if (c->dim != 3 || c->nn != 8 || c->n_elem < 1 || getenv("PYNAMA_NO_LATTICE")) return PYN_OK;
+  const int64_t ne = c->n_elem;
+  const int64_t nx = (int64_t)conn[1] - conn[0];
+  if (nx < 2 || conn[3] != conn[0] + 1) return PYN_OK;
+  const int64_t ex = nx - 1;
+  if (ne % ex) return PYN_OK;
+  // rows of elements per layer: the first element row that does not continue the bottom plane of layer 0
+  int64_t ey = 0;
+  for (int64_t j = 0; j * ex < ne; ++j) {
+    if (conn[j * ex * 8] != conn[0] + j * nx) break;
+    ey = j + 1;
+  }
+  if (ey < 1 || (ne / ex) % ey) return PYN_OK;
+  const int64_t ny = ey + 1, ezl = ne / (ex * ey), npl = ezl + 1, nxny = nx * ny;
+  if (nxny * npl != c->n_node || nxny > INT32_MAX / 2) return PYN_OK;
+  std::vector<int32_t> P((size_t)npl);
+  for (int64_t l = 0; l < ezl; ++l) {
+    const int32_t* e0 = conn + l * ex * ey * 8;
+    P[l] = e0[0];
+    if (l + 1 == ezl) P[l + 1] = e0[4];
+    if (l > 0 && P[l] != conn[(l - 1) * ex * ey * 8 + 4]) return PYN_OK;
+  }
+  for (int64_t l = 0; l < ezl; ++l)
+    for (int64_t iy = 0; iy < ey; ++iy)
+      for (int64_t ix = 0; ix < ex; ++ix) {
+        const int32_t* q = conn + ((l * ey + iy) * ex + ix) * 8;
+        const int32_t lo = (int32_t)(P[l] + iy * nx + ix), hi = (int32_t)(P[l + 1] + iy * nx + ix);
+        if (q[0] != lo || q[1] != lo + nx || q[2] != lo + nx + 1 || q[3] != lo + 1 || q[4] != hi || q[5] != hi + 1 ||
+            q[6] != hi + nx + 1 || q[7] != hi + nx)
+          return PYN_OK;
+      }
+  // planes are disjoint blocks of nx*ny ids; the owned ones are consecutive in z and carry ids 0..n_owned-1
+  std::vector<int32_t> sorted(P);
+  std::sort(sorted.begin(), sorted.end());
+  for (int64_t j = 0; j < npl; ++j)
+    if (sorted[j] != j * nxny) return PYN_OK;
+  if (c->n_owned % nxny) return PYN_OK;
+  const int n_own = (int)(c->n_owned / nxny);
+  int p0 = -1;
+  for (int64_t j = 0; j < npl; ++j)
+    if (P[j] == 0) p0 = (int)j;
+  if (p0 < 0 || p0 + n_own > npl) return PYN_OK;
+  for (int j = 0; j < n_own; ++j)
+    if (P[p0 + j] != (int64_t)j * nxny) return PYN_OK;
+  std::vector<int32_t> zord((size_t)npl);
+  for (int64_t j = 0; j < npl; ++j) {
+    int dz[3], n = 0;
+    for (int d = -1; d <= 1; ++d)
+      if (j + d >= 0 && j + d < npl) dz[n++] = d;
+    std::sort(dz, dz + n, [&](int a, int b2) { return P[j + a] < P[j + b2]; });
+    int code = n;
+    for (int i = 0; i < n; ++i) code |= (dz[i] + 1) << (2 + 2 * i);
+    zord[j] = code;
+  }
+  PYN_HIP(hipMalloc((void**)&L.d_P, npl * sizeof(int32_t)));
+  PYN_HIP(hipMalloc((void**)&L.d_zord, npl * sizeof(int32_t)));
+  PYN_HIP(hipMemcpy(L.d_P, P.data(), npl * sizeof(int32_t), hipMemcpyHostToDevice));
+  PYN_HIP(hipMemcpy(L.d_zord, zord.data(), npl * sizeof(int32_t), hipMemcpyHostToDevice));
+  L.nx = (int)nx;
+  L.ny = (int)ny;
+  L.npl = (int)npl;
+  L.p_own0 = p0;
+  L.n_own = n_own;
+  L.valid = true;
+  return PYN_OK;
+}
+
+template <int TX, int TY, int TZ>
+static int launch_lattice(pyn_ctx* c, LatArgs& T, bool affine) {
+  using LT = LatTile<TX, TY, TZ>;
+  T.ntx = (T.nx + TX - 1) / TX;
+  T.nty = (T.ny + TY - 1) / TY;
+  const int ntz = (T.n_own + TZ - 1) / TZ;
+  const int n_tiles = T.ntx * T.nty * ntz;
+  static bool attr_done = false;
+  if (!attr_done) {
+    PYN_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(assemble_q1_hex_lattice_kernel<TX, TY, TZ, false>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)LT::BYTES));
+    PYN_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(assemble_q1_hex_lattice_kernel<TX, TY, TZ, true>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)LT::BYTES));
+    attr_done = true;
+  }
+  if (affine)
+    assemble_q1_hex_lattice_kernel<TX, TY, TZ, true><<<n_tiles, TILE_THREADS, LT::BYTES, c->stream>>>(T);
+  else
+    assemble_q1_hex_lattice_kernel<TX, TY, TZ, false><<<n_tiles, TILE_THREADS, LT::BYTES, c->stream>>>(T);
+  PYN_HIP(hipGetLastError());
+  return PYN_OK;
+}
+
+static int assemble_lattice(pyn_ctx* c, double* A, double* Arhs, bool* handled) {
+  Lattice& L = c->lat;
+  if (!L.valid || c->quad[0].ngp != 8) return PYN_OK;
+  LatArgs T;
+  T.xyz = c->d_xyz;
+  T.rowptr = c->d_rowptr;
+  T.bcmask = c->d_bcmask;
+  T.P = L.d_P;
+  T.zord = L.d_zord;
+  T.nx = L.nx;
+  T.ny = L.ny;
+  T.npl = L.npl;
+  T.p_own0 = L.p_own0;
+  T.n_own = L.n_own;
+  T.ntx = T.nty = 0;
+  T.q = TileArgs();
+  T.q.w = c->quad[0].w;
+  T.q.hrs = c->quad[0].Hrs;
+  T.q.hcoo = c->quad[0].HrsCoo;
+  T.q.aff = getenv("PYNAMA_NO_AFFINE") ? nullptr : c->d_aff;
+  T.A = A;
+  T.Arhs = Arhs;
+  const char* ab = getenv("PYNAMA_LATTICE_ABLATE");  // diagnostics: 1 = no element phase, 4 = no plain-tile store path
+  T.ablate = ab ? atoi(ab) : 0;
+  if (L.all_affine < 0) {  // once per mesh: does the lean parallelepiped path apply?
+    L.all_affine = 0;
+    if (c->d_aff) {
+      DevTmp flag;
+      PYN_HIP(flag.alloc(sizeof(int)));
+      const int one = 1;
+      PYN_HIP(hipMemcpyAsync(flag.p, &one, sizeof(int), hipMemcpyHostToDevice, c->stream));
+      LatArgs Tc = T;
+      Tc.q.aff = c->d_aff;
+      const int64_t ne = (int64_t)(L.nx - 1) * (L.ny - 1) * (L.npl - 1);
+      lattice_all_affine_kernel<<<(int)((ne + 255) / 256), 256, 0, c->stream>>>(Tc, ne, flag.as<int>());
+      int h = 0;
+      PYN_HIP(hipMemcpyAsync(&h, flag.p, sizeof(int), hipMemcpyDeviceToHost, c->stream));
+      PYN_HIP(hipStreamSynchronize(c->stream));
+      L.all_affine = h;
+    }
+  }
+  const bool affine = L.all_affine == 1 && T.q.aff != nullptr && c->aff_standard;
+  const char* tl = getenv("PYNAMA_LATTICE_TILE");
+  const int sel = tl ? atoi(tl) : 0;
+  switch (sel) {
+    case 1: PYN_TRY((launch_lattice<7, 7, 7>(c, T, affine))); break;
+    case 2: PYN_TRY((launch_lattice<6, 6, 6>(c, T, affine))); break;
+    case 3: PYN_TRY((launch_lattice<8, 6, 6>(c, T, affine))); break;
+    case 4: PYN_TRY((launch_lattice<7, 6, 6>(c, T, affine))); break;
+    case 5: PYN_TRY((launch_lattice<6, 6, 4>(c, T, affine))); break;
+    case 6: PYN_TRY((launch_lattice<6, 5, 5>(c, T, affine))); break;
+    case 7: PYN_TRY((launch_lattice<7, 4, 4>(c, T, affine))); break;
+    case 8: PYN_TRY((launch_lattice<14, 3, 3>(c, T, affine))); break;
+    case 9: PYN_TRY((launch_lattice<7, 5, 5>(c, T, affine))); break;
+    default: PYN_TRY((launch_lattice<7, 5, 4>(c, T, affine))); break;
+  }
+  *handled = true;
+  return PYN_OK;
+}
+
 static int ensure_default_plan(pyn_ctx* c, int kind) {
   if (c->plan[kind].npatch || c->dim != 3 || c->nn != 8 || getenv("PYNAMA_NO_AUTO_PLAN")) return PYN_OK;
   const int chunk = kind == 0 ? 343 : 27;
@@ -885,11 +1430,18 @@ static int ensure_default_plan(pyn_ctx* c, int kind) {
   std::vector<int32_t> ptr((size_t)np + 1), rows((size_t)n);
   for (int p = 0; p <= np; ++p) ptr[p] = (int32_t)std::min<int64_t>((int64_t)p * chunk, n);
   for (int64_t i = 0; i < n; ++i) rows[i] = (int32_t)i;
-  return pyn_patch_plan_set_kind(c, kind, np, ptr.data(), rows.data());
+  g_default_plan = true;
+  const int rc = pyn_patch_plan_set_kind(c, kind, np, ptr.data(), rows.data());
+  g_default_plan = false;
+  return rc;
 }
 
 int pyn_assemble_q1_tiled(pyn_ctx* c, int form, double alpha_d, double alpha_w, double* K, double* Krhs, double* Rw, double* Rd, bool* handled) {
   *handled = false;
+  if (form == PYN_FORM_LAPLACE && K && !Rw && !Rd && c->lat.valid && !c->plan[0].user) {
+    PYN_TRY(assemble_lattice(c, K, Krhs, handled));
+    if (*handled) return PYN_OK;
+  }
   if (form == PYN_FORM_KLE && K && !Rd) PYN_TRY(ensure_default_plan(c, 1));
   if (form == PYN_FORM_LAPLACE && K && !Rw && !Rd) PYN_TRY(ensure_default_plan(c, 0));
   if (form == PYN_FORM_KLE && K && !Rd) return assemble_kle_tiled(c, alpha_d, alpha_w, K, Krhs, Rw, handled);

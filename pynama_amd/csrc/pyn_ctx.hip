@@ -269,12 +269,22 @@ extern "C" int pyn_mesh_set(pyn_ctx* c, int dim, int nn, int64_t n_elem, int64_t
   PYN_TRY(dev_upload(&c->d_conn, conn, (size_t)n_elem * nn, c->stream));
   PYN_TRY(dev_upload(&c->d_xyz, xyz, (size_t)n_node * dim, c->stream));
   PYN_HIP(hipStreamSynchronize(c->stream));
+  PYN_TRY(pyn_lattice_detect(c, conn));
   // graph + matrices depend on the mesh
   (void)hipFree(c->d_rowptr);
   (void)hipFree(c->d_colidx);
   c->d_rowptr = nullptr;
   c->d_colidx = nullptr;
   c->nnzb = 0;
+  return PYN_OK;
+}
+
+extern "C" int pyn_mesh_topology(pyn_ctx* c, int* kind, int* nx, int* ny, int* nz) {
+  PYN_CHECK(c && c->n_elem > 0, "pyn_mesh_set first");
+  if (kind) *kind = c->lat.valid ? 1 : 0;
+  if (nx) *nx = c->lat.nx;
+  if (ny) *ny = c->lat.ny;
+  if (nz) *nz = c->lat.npl;
   return PYN_OK;
 }
 
@@ -303,7 +313,7 @@ extern "C" int pyn_elem_tables_set(pyn_ctx* c, int which, int ngp, const double*
     // Tables of the affine shortcut of the tiled Q1-hex kernel (exact for parallelepipeds, where
     // J is constant):  L_ab = detJ * sum_{r<=s} Q_rs T_rs[ab],  Q = J^-T J^-1 (reference axes),
     // T_rr = sum_g w hr[r][a] hr[r][b],  T_rs = sum_g w (hr[r][a] hr[s][b] + hr[s][a] hr[r][b]).
-    double aff[6 * 36 + 4 * 8];
+    double aff[6 * 36 + 4 * 8 + 9];
     const int RS[6][2] = {{0, 0}, {1, 1}, {2, 2}, {0, 1}, {0, 2}, {1, 2}};
     for (int t = 0; t < 6; ++t) {
       const int r = RS[t][0], s2 = RS[t][1];
@@ -328,7 +338,17 @@ extern "C" int pyn_elem_tables_set(pyn_ctx* c, int which, int ngp, const double*
       aff[216 + 2 * 8 + a] = xs * xt;
       aff[216 + 3 * 8 + a] = xr * xs * xt;
     }
-    PYN_TRY(dev_upload(&c->d_aff, aff, (size_t)(6 * 36 + 32), c->stream));
+    // S[d][m] = sum_c hcoo[d][c] C_m[c]: d(reference axis d) of the lattice coordinate m (corner offsets in the
+    // closure order of SURVEY.md A.2) -- for a parallelepiped J = S . (edge vectors along x, y, z)
+    const int CO[3][8] = {{0, 0, 1, 1, 0, 1, 1, 0}, {0, 1, 1, 0, 0, 0, 1, 1}, {0, 0, 0, 0, 1, 1, 1, 1}};
+    for (int d = 0; d < 3; ++d)
+      for (int m = 0; m < 3; ++m) {
+        double sacc = 0.0;
+        for (int cc = 0; cc < 8; ++cc) sacc += HrsCoo[d * 8 + cc] * CO[m][cc];
+        aff[248 + d * 3 + m] = sacc;
+      }
+    c->aff_standard = pyn_q1_affine_tables_standard(aff);
+    PYN_TRY(dev_upload(&c->d_aff, aff, (size_t)(6 * 36 + 32 + 9), c->stream));
   }
   PYN_HIP(hipStreamSynchronize(c->stream));
   return PYN_OK;

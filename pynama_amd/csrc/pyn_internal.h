@@ -84,10 +84,23 @@ struct DMat {
 };
 
 struct PatchPlan {
+  bool user = false;  // set through the C ABI (not the automatic consecutive-row plan)
   int32_t *rowptr = nullptr, *rows = nullptr, *eptr = nullptr, *elem = nullptr;
   void *rowslot4 = nullptr, *kmap4 = nullptr;
   int npatch = 0, maxrows = 0, maxlen = 0;
   int64_t npe = 0;
+};
+
+// Structured-topology descriptor of a Q1 hex mesh (detected in pyn_mesh_set, verified entry by entry):
+// nodes form nx*ny planes stacked in z; plane j (z order) starts at node id P[j]; element
+// e = ix + (nx-1)*(iy + (ny-1)*l) sits between planes l and l+1.  Owned rows = planes
+// [p_own0, p_own0 + n_own) (ids 0 .. n_owned-1); ghost planes of a rank's slab have ids >= n_owned.
+struct Lattice {
+  bool valid = false;
+  int nx = 0, ny = 0, npl = 0, p_own0 = 0, n_own = 0;
+  int all_affine = -1;         // every element a parallelepiped? (-1: not checked yet)
+  int32_t* d_P = nullptr;      // [npl]
+  int32_t* d_zord = nullptr;   // [npl]: count | (dz+1) codes of the z-neighbour planes sorted by node id
 };
 
 struct SellShape {
@@ -131,7 +144,8 @@ struct pyn_ctx {
   int32_t* d_conn = nullptr;
   double* d_xyz = nullptr;
   QuadTab quad[3];
-  double* d_aff = nullptr;  // Q1-hex affine tables: [6][36] reference matrices + [4][8] non-affine monomial signs
+  bool aff_standard = false;  // the uploaded tables are those of the trilinear hexahedron in closed form
+  double* d_aff = nullptr;  // Q1-hex affine tables: [6][36] reference matrices + [4][8] non-affine monomial signs + [3][3] S
 
   // boundary condition
   int bc_ndof = 0;
@@ -145,6 +159,7 @@ struct pyn_ctx {
 
   // patch plans of the tiled assemblies (pyn_assemble_tiled.hip): [0] scalar forms, [1] KLE (3x3 blocks)
   PatchPlan plan[2];
+  Lattice lat;  // structured topology, if the mesh has one (plan-free assembly kernel)
 
   // SELL-64 structures, one per block shape, + the node-level column-pattern dictionary (pyn_sell.hip)
   std::vector<SellShape> sell_shapes;
@@ -185,3 +200,5 @@ int pyn_sell_ensure(pyn_ctx* c, DMat& A);
 bool pyn_sell_supported(const DMat& A);
 int pyn_sell_spmv(pyn_ctx* c, const DMat& A, const double* x, double* y, bool dot, int* grid_out);
 void pyn_sell_drop_structure(pyn_ctx* c);
+int pyn_lattice_detect(pyn_ctx* c, const int32_t* conn_host);  // pyn_assemble_tiled.hip
+bool pyn_q1_affine_tables_standard(const double* aff);

@@ -430,6 +430,7 @@ def test_random_node_numbering_falls_back_to_explicit_columns(lib):
     mesh.xyz = mesh.xyz[inv]
     mesh.boundary = np.sort(perm[mesh.boundary])
     ctx = make_ctx(lib, mesh, 2, bc_ndof=1, bc_nodes=mesh.boundary)
+    assert ctx.mesh_topology()[0] == "general"
     rp, ci = ctx.csr_get()
     rp_o, ci_o = fo.node_graph(mesh)
     assert np.array_equal(rp, rp_o) and np.array_equal(ci, ci_o)
@@ -637,3 +638,98 @@ def test_rccl_one_rank_solve_equals_serial(lib, method):
         ctx.close()
     assert out[0][0] == out[1][0] and out[0][1] == out[1][1] == 2
     assert rel_err(out[1][2], out[0][2]) < 1e-12
+
+
+# ---- plan-free kernel for structured topology ---------------------------------------------------
+@pytest.mark.parametrize("tile", [0, 1, 2, 3, 4, 5, 6, 7, 8, 9])
+@pytest.mark.parametrize("nelem,jitter", [([11, 9, 10], 0.2), ([17, 6, 5], 0.0), ([2, 1, 3], 0.2), ([23, 19, 17], 0.1)])
+def test_assemble_lattice_kernel(lib, tile, nelem, jitter):
+    """box meshes are recognised as lattices and assembled without a patch plan (index arithmetic instead
+    of plan streams): every tile shape, domain sizes that are not multiples of the tile, general and affine
+    geometry, with / without the Dirichlet mask and the Arhs output -- all equal the oracle and the
+    plan-based kernel"""
+    import os
+    mesh = fo.box_mesh(nelem, [0, 0, 0], [1.0, 0.8, 1.1], 2, jitter=jitter)
+    ref = fo.assemble_scalar(mesh, fo.Tables(2, 3), "laplace", dirichlet=mesh.boundary)
+    ref0 = fo.assemble_scalar(mesh, fo.Tables(2, 3), "laplace")
+    os.environ["PYNAMA_LATTICE_TILE"] = str(tile)
+    try:
+        ctx = make_ctx(lib, mesh, 2, bc_ndof=1, bc_nodes=mesh.boundary)
+        assert ctx.mesh_topology() == ("lattice", nelem[0] + 1, nelem[1] + 1, nelem[2] + 1)
+        A, Arhs = ctx.mat_create(1, 1), ctx.mat_create(1, 1)
+        ctx.assemble_scalar(lib.FORM_LAPLACE, A, Arhs)
+        assert sp_rel_err(mat_to_scipy(ctx, A, 1, 1), ref["A"]) < FP_TOL
+        assert sp_rel_err(mat_to_scipy(ctx, Arhs, 1, 1), ref["Arhs"]) < FP_TOL
+        ctx.assemble_scalar(lib.FORM_LAPLACE, A, -1)
+        assert sp_rel_err(mat_to_scipy(ctx, A, 1, 1), ref["A"]) < FP_TOL
+        ctx.bc_set(1, None)
+        ctx.assemble_scalar(lib.FORM_LAPLACE, A, -1)
+        assert sp_rel_err(mat_to_scipy(ctx, A, 1, 1), ref0["A"]) < FP_TOL
+        # an interior Dirichlet node set (not the lattice boundary): the mask is data, not topology
+        rng = np.random.default_rng(5)
+        some = np.sort(rng.choice(mesh.n_node, size=max(1, mesh.n_node // 7), replace=False))
+        mask = np.zeros((mesh.n_node, 1), np.uint8)
+        mask[some] = 1
+        ctx.bc_set(1, mask)
+        ctx.assemble_scalar(lib.FORM_LAPLACE, A, Arhs)
+        ref2 = fo.assemble_scalar(mesh, fo.Tables(2, 3), "laplace", dirichlet=some)
+        assert sp_rel_err(mat_to_scipy(ctx, A, 1, 1), ref2["A"]) < FP_TOL
+        assert sp_rel_err(mat_to_scipy(ctx, Arhs, 1, 1), ref2["Arhs"]) < FP_TOL
+        ctx.close()
+    finally:
+        del os.environ["PYNAMA_LATTICE_TILE"]
+
+
+@pytest.mark.parametrize("kind", ["sheared", "mixed", "stretched"])
+def test_lattice_kernel_parallelepipeds(lib, kind):
+    """all-parallelepiped lattices take the lean path (4 corner loads, J from the edge vectors, L_ab formed on the
+    fly); one non-affine element anywhere sends the whole mesh through the quadrature path.  Both equal the oracle's
+    8-point rule."""
+    mesh = fo.box_mesh([14, 9, 16], [0, 0, 0], [1.0, 0.7, 1.3], 2)
+    if kind == "sheared":
+        M = np.array([[1.0, 0.3, -0.2], [0.1, 0.9, 0.25], [-0.15, 0.2, 1.1]])
+        mesh.xyz = mesh.xyz @ M.T + np.array([0.5, -1.0, 2.0])
+    if kind == "stretched":                              # graded spacing: every cell still a brick
+        mesh.xyz = mesh.xyz ** np.array([1.7, 1.0, 2.3])
+    if kind == "mixed":
+        mv = np.zeros_like(mesh.xyz)
+        mv[mesh.n_node // 2] = [0.01, -0.008, 0.012]     # one interior node off the lattice
+        mesh.xyz = mesh.xyz + mv
+    ref = fo.assemble_scalar(mesh, fo.Tables(2, 3), "laplace", dirichlet=mesh.boundary)
+    ctx = make_ctx(lib, mesh, 2, bc_ndof=1, bc_nodes=mesh.boundary)
+    assert ctx.mesh_topology()[0] == "lattice"
+    A, Arhs = ctx.mat_create(1, 1), ctx.mat_create(1, 1)
+    ctx.assemble_scalar(lib.FORM_LAPLACE, A, Arhs)
+    assert sp_rel_err(mat_to_scipy(ctx, A, 1, 1), ref["A"]) < FP_TOL
+    assert sp_rel_err(mat_to_scipy(ctx, Arhs, 1, 1), ref["Arhs"]) < FP_TOL
+    ctx.close()
+
+
+@pytest.mark.parametrize("size", [2, 3])
+def test_lattice_kernel_on_rank_slabs(lib, size):
+    """a rank's z-slab is a lattice whose ghost planes carry the LAST node ids: the z-order table of the
+    plan-free kernel sorts the column blocks of interface rows accordingly"""
+    from pynama_amd.common.comm import Comm
+    from pynama_amd.domain.dmplex import DMPlexDom
+    from pynama_amd.elements.spectral import Spectral
+    nelem = [6, 5, 9]
+    glob = fo.box_mesh(nelem, [0, 0, 0], [1, 1, 1], 2, jitter=0.2)
+    ref = fo.assemble_scalar(glob, fo.Tables(2, 3), "laplace", dirichlet=glob.boundary)
+    for r in range(size):
+        dom = DMPlexDom(boxMesh={'nelem': nelem, 'lower': [0, 0, 0], 'upper': [1, 1, 1]}, comm=Comm(r, size), jitter=0.2)
+        dom.setFemIndexing(2)
+        ctx = lib.Context(0)
+        ctx.comm_init(r, size, None)
+        ctx.halo_set(*dom._halo_plan())
+        ctx.mesh_set(3, dom.conn, dom.xyz)
+        for t in Spectral(2, 3).deviceTables():
+            ctx.tables_set(*t)
+        ctx.bc_set(1, dom.boundaryMaskLocal())
+        ctx.csr_symbolic()
+        assert ctx.mesh_topology() == ("lattice", 7, 6, dom.nLocal // 42)
+        A, Ar = ctx.mat_create(1, 1), ctx.mat_create(1, 1)
+        ctx.assemble_scalar(lib.FORM_LAPLACE, A, Ar)          # no plan set: lattice kernel
+        cols = dom._local2global(np.arange(dom.nLocal))
+        assert sp_rel_err(mat_to_scipy(ctx, A, 1, 1), ref["A"][dom.rStart:dom.rEnd][:, cols]) < FP_TOL
+        assert sp_rel_err(mat_to_scipy(ctx, Ar, 1, 1), ref["Arhs"][dom.rStart:dom.rEnd][:, cols]) < FP_TOL
+        ctx.close()
