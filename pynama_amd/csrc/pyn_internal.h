@@ -99,6 +99,8 @@ struct Lattice {
   bool valid = false;
   int nx = 0, ny = 0, npl = 0, p_own0 = 0, n_own = 0;
   int all_affine = -1;         // every element a parallelepiped? (-1: not checked yet)
+  bool std_shape = false;      // all planes owned, in id order (single rank)
+  int std_ok = -1;             // closed-form row offsets verified against the graph (-1: not checked yet)
   int32_t* d_P = nullptr;      // [npl]
   int32_t* d_zord = nullptr;   // [npl]: count | (dz+1) codes of the z-neighbour planes sorted by node id
 };

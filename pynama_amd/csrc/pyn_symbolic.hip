@@ -97,6 +97,7 @@ extern "C" int pyn_csr_symbolic(pyn_ctx* c) {
   }
   c->mats.clear();
   pyn_sell_drop_structure(c);
+  c->lat.std_ok = -1;  // closed-form row offsets are re-verified against the new graph
   return PYN_OK;
 }
 
