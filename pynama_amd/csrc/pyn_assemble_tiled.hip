@@ -1472,8 +1472,10 @@ static int assemble_lattice(pyn_ctx* c, double* A, double* Arhs, bool* handled) 
   }
   T.std_lat = L.std_ok == 1;
   const bool affine = L.all_affine == 1 && T.q.aff != nullptr && c->aff_standard;
+  // measured at 10M DOFs: parallelepipeds are store-bound -> small tiles, 5 workgroups per CU;
+  // the quadrature path is FP64-bound -> 7x7x7 tiles (least redundant integration that fits the LDS twice)
   const char* tl = getenv("PYNAMA_LATTICE_TILE");
-  const int sel = tl ? atoi(tl) : 0;
+  const int sel = tl ? atoi(tl) : (affine ? 0 : 1);
   switch (sel) {
     case 1: PYN_TRY((launch_lattice<7, 7, 7>(c, T, affine))); break;
     case 2: PYN_TRY((launch_lattice<6, 6, 6>(c, T, affine))); break;

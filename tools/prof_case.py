@@ -24,7 +24,7 @@ for t in Spectral(2, 3).deviceTables():
 bm = dom.boundaryMaskLocal()
 ctx.bc_set(1, bm)
 ctx.csr_symbolic()
-if variant == 1:
+if variant == 2:      # explicit plan: the patch-plan kernel instead of the plan-free lattice kernel
     tile = tuple(int(v) for v in os.environ.get("PYNAMA_TILE", "7,7,7").split(","))
     ctx.patch_plan_set(*dom.patchPlan(tile))
 A = ctx.mat_create(1, 1)

@@ -1,0 +1,55 @@
+#!/usr/bin/env python3
+"""Turn rocprofv3 result databases (rocpd sqlite, the default output of this ROCm) into the small text files
+committed under profiles/.
+  rocprof_summary.py stats  <results.db> <out.csv> [out.md]     --kernel-trace --stats run
+  rocprof_summary.py pmc    <fetch.db> <write.db> <out.json>    --pmc FETCH_SIZE / --pmc WRITE_SIZE runs"""
+import json
+import re
+import sqlite3
+import sys
+
+
+def short(name, n=110):
+    return name if len(name) <= n else name[:n] + "..."
+
+
+def stats(db, out_csv, out_md=None):
+    con = sqlite3.connect(db)
+    rows = con.execute("select name, total_calls, total_duration, average, percentage from top_kernels "
+                       "order by total_duration desc").fetchall()
+    with open(out_csv, "w") as f:
+        f.write("Name,Calls,TotalDurationNs,AverageNs,Percentage\n")
+        for name, calls, tot, avg, pct in rows:
+            f.write('"%s",%d,%.0f,%.1f,%.4f\n' % (short(name, 200).replace('"', "'"), calls, tot * 1e3, avg * 1e3, pct))
+    if out_md:
+        with open(out_md, "w") as f:
+            f.write("| kernel | calls | total ms | avg us | % |\n|---|---|---|---|---|\n")
+            for name, calls, tot, avg, pct in rows[:18]:
+                f.write("| `%s` | %d | %.2f | %.1f | %.2f |\n" % (short(name, 90), calls, tot / 1e3, avg, pct))
+
+
+def pmc(fetch_db, write_db, out_json):
+    res = {}
+    for db, counter in ((fetch_db, "FETCH_SIZE"), (write_db, "WRITE_SIZE")):
+        con = sqlite3.connect(db)
+        q = ("select kernel_name, count(*), sum(value) from counters_collection where counter_name = ? "
+             "group by kernel_name")
+        for name, n, total in con.execute(q, (counter,)):
+            key = re.sub(r"^void\s+", "", name).replace("(anonymous namespace)::", "")
+            key = re.split(r"[<(]", key)[0].strip()
+            res.setdefault(key, {"full_name": short(name, 160)})[counter + "_KB"] = total / n
+            res[key]["launches"] = n
+    for k, v in res.items():
+        if "FETCH_SIZE_KB" in v and "WRITE_SIZE_KB" in v:
+            # gfx950: FETCH_SIZE counts 64 B per 128-B request (MI355X_MICROARCH.md, HBM section) -> x2
+            v["hbm_bytes_per_launch"] = (2.0 * v["FETCH_SIZE_KB"] + v["WRITE_SIZE_KB"]) * 1024.0
+    with open(out_json, "w") as f:
+        json.dump({"correction": "(2*FETCH_SIZE + WRITE_SIZE)*1024 bytes per launch (gfx950 FETCH_SIZE counts 64 B per "
+                                 "128-B request; separate --pmc passes)", "kernels": res}, f, indent=1)
+
+
+if __name__ == "__main__":
+    if sys.argv[1] == "stats":
+        stats(*sys.argv[2:5])
+    else:
+        pmc(*sys.argv[2:5])
