@@ -695,6 +695,14 @@ __host__ __device__ constexpr int q1_aff_int(int t, int a, int b) {
   return 3 * (3 + SG[u][a] * SG[u][b]) * (SG[r][a] * SG[s2][b] + SG[s2][a] * SG[r][b]);
 }
 
+// 72 * int N_a d_d N_b over the reference cube = s_d(b) (3 + s_e(a)s_e(b)) (3 + s_f(a)s_f(b)), e, f the other axes
+// (pyn_elem_tables_set checks sum_g w_g H_g[a] Hrs_g[d][b] against it before the affine Rw path is used)
+__host__ __device__ constexpr int q1_mix_int(int d, int a, int b) {
+  constexpr int SG[3][8] = {{-1, -1, 1, 1, -1, 1, 1, -1}, {-1, 1, 1, -1, -1, -1, 1, 1}, {-1, -1, -1, -1, 1, 1, 1, 1}};
+  const int e = (d + 1) % 3, f = (d + 2) % 3;
+  return SG[d][b] * (3 + SG[e][a] * SG[e][b]) * (3 + SG[f][a] * SG[f][b]);
+}
+
 // Lean integration for meshes whose elements are ALL parallelepipeds (every box mesh the reference creates,
 // src/domain/dmplex.py:8-21): four corner loads instead of eight, J = S.E from the three edge vectors
 // (S[d][m] = sum_c hcoo[d][c] C_m[c], a table constant), L_ab = detJ sum_{r<=s} Q_rs T_rs[ab]; no quadrature
@@ -797,24 +805,20 @@ __device__ __forceinline__ void lat_integrate_affine(const LatArgs& T, int x0, i
   }
 }
 
-// one-off check behind the lean path: is every element of the lattice a parallelepiped?
-__global__ void lattice_all_affine_kernel(LatArgs T, int64_t n_elem, int* flag) {
+// one-off check for any Q1 hex mesh (connectivity-driven): is every element a parallelepiped?
+__global__ void mesh_all_affine_kernel(const int32_t* __restrict__ conn, const double* __restrict__ xyz, int64_t n_elem,
+                                       TileArgs q, int* flag) {
   const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (e >= n_elem) return;
-  const int ex = T.nx - 1, ey = T.ny - 1;
-  const int ix = (int)(e % ex), iy = (int)((e / ex) % ey), l = (int)(e / ((int64_t)ex * ey));
-  constexpr int CX[8] = {0, 0, 1, 1, 0, 1, 1, 0};
-  constexpr int CY[8] = {0, 1, 1, 0, 0, 0, 1, 1};
-  constexpr int CZ[8] = {0, 0, 0, 0, 1, 1, 1, 1};
   double X[8][3];
 #pragma unroll
   for (int a = 0; a < 8; ++a) {
-    const double* q = T.xyz + (int64_t)(lat_plane(T, l + CZ[a]) + (iy + CY[a]) * T.nx + ix + CX[a]) * 3;
-    X[a][0] = q[0];
-    X[a][1] = q[1];
-    X[a][2] = q[2];
+    const double* p = xyz + (int64_t)conn[e * 8 + a] * 3;
+    X[a][0] = p[0];
+    X[a][1] = p[1];
+    X[a][2] = p[2];
   }
-  if (!element_is_affine(T.q, X)) *flag = 0;
+  if (!element_is_affine(q, X)) *flag = 0;
 }
 
 // one-off check behind std_lat: the closed-form row offsets equal the symbolic phase's rowptr
@@ -886,6 +890,7 @@ struct KleArgs {
   const double *w, *H, *hrs, *hcoo;          // full rule
   const double *wr, *Hr, *hrsr, *hcoor;      // reduced rule (one point)
   const double* aff;
+  int aff_rw;    // the closed-form int N_a d N_b table was verified: affine elements skip the Gauss loop of Rw
   double alpha_d, alpha_w;
   double* K;     // WHICH 0: K     | WHICH 1: Rw
   double* Krhs;  // WHICH 0: Krhs (may be null)
@@ -930,6 +935,35 @@ __device__ __forceinline__ double point_gradients(const double* __restrict__ hc,
       s = fma(Ji[d][2], hr[16 + a], s);
       G[d][a] = s;
     }
+  return det;
+}
+
+// Ji[x][d] = (hc . X)^-1 (physical axis x, reference axis d), returns detJ
+__device__ __forceinline__ double jacobian_inverse(const double* __restrict__ hc, const double (&X)[8][3], double (&Ji)[3][3]) {
+  double J[3][3];
+#pragma unroll
+  for (int d = 0; d < 3; ++d)
+#pragma unroll
+    for (int x = 0; x < 3; ++x) {
+      double s = 0.0;
+#pragma unroll
+      for (int c = 0; c < 8; ++c) s = fma(hc[d * 8 + c], X[c][x], s);
+      J[d][x] = s;
+    }
+  const double c00 = J[1][1] * J[2][2] - J[1][2] * J[2][1];
+  const double c01 = J[1][2] * J[2][0] - J[1][0] * J[2][2];
+  const double c02 = J[1][0] * J[2][1] - J[1][1] * J[2][0];
+  const double det = J[0][0] * c00 + J[0][1] * c01 + J[0][2] * c02;
+  const double r = 1.0 / det;
+  Ji[0][0] = c00 * r;
+  Ji[0][1] = (J[0][2] * J[2][1] - J[0][1] * J[2][2]) * r;
+  Ji[0][2] = (J[0][1] * J[1][2] - J[0][2] * J[1][1]) * r;
+  Ji[1][0] = c01 * r;
+  Ji[1][1] = (J[0][0] * J[2][2] - J[0][2] * J[2][0]) * r;
+  Ji[1][2] = (J[0][2] * J[1][0] - J[0][0] * J[1][2]) * r;
+  Ji[2][0] = c02 * r;
+  Ji[2][1] = (J[0][1] * J[2][0] - J[0][0] * J[2][1]) * r;
+  Ji[2][2] = (J[0][0] * J[1][1] - J[0][1] * J[1][0]) * r;
   return det;
 }
 
@@ -1019,7 +1053,7 @@ __global__ void __launch_bounds__(KLE_THREADS, 2) assemble_q1_hex_kle_tiled_kern
       X[a][2] = q[2];
     }
     unsigned bcn = 0;  // bit 3*b + q = DOF (node b, comp q) imposed
-    if (WHICH == 0 && T.bcmask) {
+    if ((WHICH == 0 || WHICH == 3) && T.bcmask) {
 #pragma unroll
       for (int b = 0; b < 8; ++b)
 #pragma unroll
@@ -1033,10 +1067,54 @@ __global__ void __launch_bounds__(KLE_THREADS, 2) assemble_q1_hex_kle_tiled_kern
     const unsigned kmw[16] = {km4[0].x, km4[0].y, km4[0].z, km4[0].w, km4[1].x, km4[1].y, km4[1].z, km4[1].w,
                               km4[2].x, km4[2].y, km4[2].z, km4[2].w, km4[3].x, km4[3].y, km4[3].z, km4[3].w};
     // reduced (centroid) point
-    if (WHICH == 0) {
+    if (WHICH == 0 || WHICH == 3) {
       double Gr[3][8];
-      const double cr = T.wr[0] * point_gradients(T.hcoor, T.hrsr, X, Gr);
+      double cr;
       double L[36];
+      if (WHICH == 3) {
+        // every element a parallelepiped (checked once per mesh): one Jacobian serves the centroid gradients and
+        // the Laplacian block, whose reference matrices are compile-time integers (q1_aff_int)
+        double Ji[3][3];
+        const double det = jacobian_inverse(T.hcoor, X, Ji);
+        cr = T.wr[0] * det;
+        const double* __restrict__ hr = T.hrsr;
+#pragma unroll
+        for (int d = 0; d < 3; ++d)
+#pragma unroll
+          for (int a = 0; a < 8; ++a) Gr[d][a] = fma(Ji[d][2], hr[16 + a], fma(Ji[d][1], hr[8 + a], Ji[d][0] * hr[a]));
+        double D[3][3], M2[3][2];
+        {
+          constexpr int RS[6][2] = {{0, 0}, {1, 1}, {2, 2}, {0, 1}, {0, 2}, {1, 2}};
+#pragma unroll
+          for (int u = 0; u < 3; ++u) {
+            const int a0 = RS[u][0], a1 = RS[3 + u][0], b1 = RS[3 + u][1];
+            const double qd = det * (Ji[0][a0] * Ji[0][a0] + Ji[1][a0] * Ji[1][a0] + Ji[2][a0] * Ji[2][a0]) * (1.0 / 72.0);
+            const double qm = det * (Ji[0][a1] * Ji[0][b1] + Ji[1][a1] * Ji[1][b1] + Ji[2][a1] * Ji[2][b1]) * (1.0 / 72.0);
+            D[u][0] = 4.0 * qd;
+            D[u][1] = 8.0 * qd;
+            D[u][2] = 16.0 * qd;
+            M2[u][0] = 12.0 * qm;
+            M2[u][1] = 24.0 * qm;
+          }
+        }
+        int idx = 0;
+#pragma unroll
+        for (int a = 0; a < 8; ++a)
+#pragma unroll
+          for (int c2 = a; c2 < 8; ++c2, ++idx) {
+            double v = 0.0;
+#pragma unroll
+            for (int u = 0; u < 6; ++u) {
+              const int n = q1_aff_int(u, a, c2);
+              const int an = n < 0 ? -n : n;
+              if (an == 0) continue;
+              const double x = u < 3 ? D[u][an == 4 ? 0 : (an == 8 ? 1 : 2)] : M2[u - 3][an == 12 ? 0 : 1];
+              v = n > 0 ? v + x : v - x;
+            }
+            L[idx] = v;
+          }
+      } else {
+      cr = T.wr[0] * point_gradients(T.hcoor, T.hrsr, X, Gr);
 #pragma unroll
       for (int i = 0; i < 36; ++i) L[i] = 0.0;
       {
@@ -1051,6 +1129,7 @@ __global__ void __launch_bounds__(KLE_THREADS, 2) assemble_q1_hex_kle_tiled_kern
 #pragma nounroll
           for (int g = 0; g < 8; ++g) gauss_point(S, g, X, L);
         }
+      }
       }
       const double caw = cr * T.alpha_w, cad = cr * T.alpha_d;
 #pragma unroll
@@ -1081,15 +1160,64 @@ __global__ void __launch_bounds__(KLE_THREADS, 2) assemble_q1_hex_kle_tiled_kern
     } else {
       // Rw: passes over the derivative axis m (x the two halves of the row nodes, to keep one 4x8
       // block of T_m live): (p, kc) = the two other axes in both orders
+      if (WHICH == 2) {
+        // every element of the mesh is a parallelepiped (checked once per mesh): constant G, so
+        //   T_m[a][b] = detJ sum_d Ji[m][d] int N_a d_d N_b   (integrals = small integers / 72, q1_mix_int)
+        // and the whole 8x8 block of 3x3 entries comes straight from Ji -- no Gauss loop, no passes
+        double Ji[3][3];
+        const double det = jacobian_inverse(T.hcoor, X, Ji);
+        const double caw = T.wr[0] * det * T.alpha_w;
+        const double* __restrict__ hr = T.hrsr;
+        double D[3][3][3];   // [m][d][4|8|16] = detJ Ji[m][d] {4, 8, 16} / 72
+#pragma unroll
+        for (int m = 0; m < 3; ++m)
+#pragma unroll
+          for (int d = 0; d < 3; ++d) {
+            const double x = det * Ji[m][d] * (1.0 / 72.0);
+            D[m][d][0] = 4.0 * x;
+            D[m][d][1] = 8.0 * x;
+            D[m][d][2] = 16.0 * x;
+          }
+#pragma unroll
+        for (int a = 0; a < 8; ++a) {
+          const unsigned slot = (rsw[a >> 1] >> (16 * (a & 1))) & 0xFFFFu;
+          if (slot == 0xFFFFu) continue;
+          double* rowp = acc + (size_t)slot * rowsz;
+          double gra[3];     // alpha_w c G_r[m][a] at the centroid
+#pragma unroll
+          for (int m = 0; m < 3; ++m) gra[m] = caw * fma(Ji[m][2], hr[16 + a], fma(Ji[m][1], hr[8 + a], Ji[m][0] * hr[a]));
+#pragma unroll
+          for (int b = 0; b < 8; ++b) {
+            const unsigned k = (kmw[2 * a + (b >> 2)] >> (8 * (b & 3))) & 0xFFu;
+            const double hb = T.Hr[b];
+#pragma unroll
+            for (int m = 0; m < 3; ++m) {
+              double tv = 0.0;
+#pragma unroll
+              for (int d = 0; d < 3; ++d) {
+                const int n = q1_mix_int(d, a, b);
+                const int an = n < 0 ? -n : n;
+                const double x = D[m][d][an == 4 ? 0 : (an == 8 ? 1 : 2)];
+                tv = n > 0 ? tv + x : tv - x;
+              }
+              const double wv = tv - gra[m] * hb;
+              const int P1 = (m + 1) % 3, P2 = (m + 2) % 3;
+              atomicAdd(&rowp[(P2 * ml + k) * 3 + P1], wv);
+              atomicAdd(&rowp[(P1 * ml + k) * 3 + P2], -wv);
+            }
+          }
+        }
+      } else {
 #pragma nounroll
-      for (int it = 0; it < 6; ++it) {  // a rolled loop keeps the passes from being interleaved (registers)
-        switch (it) {
-          case 0: rw_pass<0, 0>(T, X, rsw, kmw, acc, rowsz, ml); break;
-          case 1: rw_pass<0, 1>(T, X, rsw, kmw, acc, rowsz, ml); break;
-          case 2: rw_pass<1, 0>(T, X, rsw, kmw, acc, rowsz, ml); break;
-          case 3: rw_pass<1, 1>(T, X, rsw, kmw, acc, rowsz, ml); break;
-          case 4: rw_pass<2, 0>(T, X, rsw, kmw, acc, rowsz, ml); break;
-          default: rw_pass<2, 1>(T, X, rsw, kmw, acc, rowsz, ml); break;
+        for (int it = 0; it < 6; ++it) {  // a rolled loop keeps the passes from being interleaved (registers)
+          switch (it) {
+            case 0: rw_pass<0, 0>(T, X, rsw, kmw, acc, rowsz, ml); break;
+            case 1: rw_pass<0, 1>(T, X, rsw, kmw, acc, rowsz, ml); break;
+            case 2: rw_pass<1, 0>(T, X, rsw, kmw, acc, rowsz, ml); break;
+            case 3: rw_pass<1, 1>(T, X, rsw, kmw, acc, rowsz, ml); break;
+            case 4: rw_pass<2, 0>(T, X, rsw, kmw, acc, rowsz, ml); break;
+            default: rw_pass<2, 1>(T, X, rsw, kmw, acc, rowsz, ml); break;
+          }
         }
       }
     }
@@ -1115,9 +1243,9 @@ __global__ void __launch_bounds__(KLE_THREADS, 2) assemble_q1_hex_kle_tiled_kern
         const double v = src[idx];
         double va, vr;
         if (rowbc) {
-          const bool dg = (WHICH == 0) && q == pp && T.colidx[lo + k] == T.p_rows[r_lo + slot];
+          const bool dg = (WHICH == 0 || WHICH == 3) && q == pp && T.colidx[lo + k] == T.p_rows[r_lo + slot];
           va = vr = dg ? 1.0 : 0.0;
-        } else if (WHICH == 0 && ((cflag[slot * 3 + q] >> k) & 1u)) {
+        } else if ((WHICH == 0 || WHICH == 3) && ((cflag[slot * 3 + q] >> k) & 1u)) {
           va = 0.0;
           vr = -v;
         } else {
@@ -1125,7 +1253,7 @@ __global__ void __launch_bounds__(KLE_THREADS, 2) assemble_q1_hex_kle_tiled_kern
           vr = 0.0;
         }
         outA[gbase + idx] = va;
-        if (WHICH == 0 && outR) outR[gbase + idx] = vr;
+        if ((WHICH == 0 || WHICH == 3) && outR) outR[gbase + idx] = vr;
       }
     }
   }
@@ -1142,6 +1270,17 @@ static size_t kle_lds_bytes(int max_rows, int maxlen) {
 }
 
 }  // namespace
+
+bool pyn_q1_mixed_tables_standard(const double* w, const double* H, const double* Hrs) {  // full rule, 8 points
+  for (int d = 0; d < 3; ++d)
+    for (int a = 0; a < 8; ++a)
+      for (int b = 0; b < 8; ++b) {
+        double u = 0.0;
+        for (int g = 0; g < 8; ++g) u += w[g] * H[g * 8 + a] * Hrs[g * 24 + d * 8 + b];
+        if (fabs(u - q1_mix_int(d, a, b) / 72.0) > 1e-13) return false;
+      }
+  return true;
+}
 
 bool pyn_q1_affine_tables_standard(const double* aff) {  // aff[6][36] as built by pyn_elem_tables_set
   for (int t = 0; t < 6; ++t) {
@@ -1263,7 +1402,37 @@ extern "C" int pyn_patch_plan_set_kind(pyn_ctx* c, int kind, int n_patch, const 
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     PYN_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(assemble_q1_hex_kle_tiled_kernel<1>),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    PYN_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(assemble_q1_hex_kle_tiled_kernel<2>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    PYN_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(assemble_q1_hex_kle_tiled_kernel<3>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   }
+  return PYN_OK;
+}
+
+// 1 iff every element of the (Q1 hex) mesh is a parallelepiped; computed once per mesh, cached in the context
+static int mesh_all_affine(pyn_ctx* c, int* out) {
+  if (!c->d_aff || c->dim != 3 || c->nn != 8) {  // tables not uploaded (yet): nothing to cache
+    *out = 0;
+    return PYN_OK;
+  }
+  if (c->mesh_affine < 0) {
+    c->mesh_affine = 0;
+    {
+      DevTmp flag;
+      PYN_HIP(flag.alloc(sizeof(int)));
+      const int one = 1;
+      PYN_HIP(hipMemcpyAsync(flag.p, &one, sizeof(int), hipMemcpyHostToDevice, c->stream));
+      TileArgs q = TileArgs();
+      q.aff = c->d_aff;
+      mesh_all_affine_kernel<<<(int)((c->n_elem + 255) / 256), 256, 0, c->stream>>>(c->d_conn, c->d_xyz, c->n_elem, q, flag.as<int>());
+      int h = 0;
+      PYN_HIP(hipMemcpyAsync(&h, flag.p, sizeof(int), hipMemcpyDeviceToHost, c->stream));
+      PYN_HIP(hipStreamSynchronize(c->stream));
+      c->mesh_affine = h;
+    }
+  }
+  *out = c->mesh_affine;
   return PYN_OK;
 }
 
@@ -1294,18 +1463,29 @@ static int assemble_kle_tiled(pyn_ctx* c, double alpha_d, double alpha_w, double
   T.hrsr = c->quad[1].Hrs;
   T.hcoor = c->quad[1].HrsCoo;
   T.aff = getenv("PYNAMA_NO_AFFINE") ? nullptr : c->d_aff;
+  T.aff_rw = (T.aff && c->aff_rw_standard) ? 1 : 0;
   T.alpha_d = alpha_d;
   T.alpha_w = alpha_w;
   const size_t lds = kle_lds_bytes(P.maxrows, P.maxlen);
   if (K) {
     T.K = K;
     T.Krhs = Krhs;
-    assemble_q1_hex_kle_tiled_kernel<0><<<P.npatch, KLE_THREADS, lds, c->stream>>>(T);
+    int all_aff = 0;
+    if (T.aff && c->aff_standard) PYN_TRY(mesh_all_affine(c, &all_aff));
+    if (all_aff)
+      assemble_q1_hex_kle_tiled_kernel<3><<<P.npatch, KLE_THREADS, lds, c->stream>>>(T);
+    else
+      assemble_q1_hex_kle_tiled_kernel<0><<<P.npatch, KLE_THREADS, lds, c->stream>>>(T);
   }
   if (Rw) {
     T.K = Rw;
     T.Krhs = nullptr;
-    assemble_q1_hex_kle_tiled_kernel<1><<<P.npatch, KLE_THREADS, lds, c->stream>>>(T);
+    int all_aff = 0;
+    if (T.aff_rw) PYN_TRY(mesh_all_affine(c, &all_aff));
+    if (all_aff)
+      assemble_q1_hex_kle_tiled_kernel<2><<<P.npatch, KLE_THREADS, lds, c->stream>>>(T);
+    else
+      assemble_q1_hex_kle_tiled_kernel<1><<<P.npatch, KLE_THREADS, lds, c->stream>>>(T);
   }
   PYN_HIP(hipGetLastError());
   *handled = true;
@@ -1437,23 +1617,8 @@ static int assemble_lattice(pyn_ctx* c, double* A, double* Arhs, bool* handled) 
   T.Arhs = Arhs;
   const char* ab = getenv("PYNAMA_LATTICE_ABLATE");  // diagnostics: 1 = no element phase, 4 = no plain-tile store path
   T.ablate = ab ? atoi(ab) : 0;
-  if (L.all_affine < 0) {  // once per mesh: does the lean parallelepiped path apply?
-    L.all_affine = 0;
-    if (c->d_aff) {
-      DevTmp flag;
-      PYN_HIP(flag.alloc(sizeof(int)));
-      const int one = 1;
-      PYN_HIP(hipMemcpyAsync(flag.p, &one, sizeof(int), hipMemcpyHostToDevice, c->stream));
-      LatArgs Tc = T;
-      Tc.q.aff = c->d_aff;
-      const int64_t ne = (int64_t)(L.nx - 1) * (L.ny - 1) * (L.npl - 1);
-      lattice_all_affine_kernel<<<(int)((ne + 255) / 256), 256, 0, c->stream>>>(Tc, ne, flag.as<int>());
-      int h = 0;
-      PYN_HIP(hipMemcpyAsync(&h, flag.p, sizeof(int), hipMemcpyDeviceToHost, c->stream));
-      PYN_HIP(hipStreamSynchronize(c->stream));
-      L.all_affine = h;
-    }
-  }
+  int mesh_aff = 0;
+  PYN_TRY(mesh_all_affine(c, &mesh_aff));
   if (L.std_ok < 0) {      // once per graph: may the index arithmetic replace P / zord / rowptr?
     L.std_ok = 0;
     if (L.std_shape && !getenv("PYNAMA_NO_STD_LATTICE")) {
@@ -1471,7 +1636,7 @@ static int assemble_lattice(pyn_ctx* c, double* A, double* Arhs, bool* handled) 
     }
   }
   T.std_lat = L.std_ok == 1;
-  const bool affine = L.all_affine == 1 && T.q.aff != nullptr && c->aff_standard;
+  const bool affine = mesh_aff == 1 && T.q.aff != nullptr && c->aff_standard;
   // measured at 10M DOFs: parallelepipeds are store-bound -> small tiles, 5 workgroups per CU;
   // the quadrature path is FP64-bound -> 7x7x7 tiles (least redundant integration that fits the LDS twice)
   const char* tl = getenv("PYNAMA_LATTICE_TILE");

@@ -269,6 +269,7 @@ extern "C" int pyn_mesh_set(pyn_ctx* c, int dim, int nn, int64_t n_elem, int64_t
   PYN_TRY(dev_upload(&c->d_conn, conn, (size_t)n_elem * nn, c->stream));
   PYN_TRY(dev_upload(&c->d_xyz, xyz, (size_t)n_node * dim, c->stream));
   PYN_HIP(hipStreamSynchronize(c->stream));
+  c->mesh_affine = -1;
   PYN_TRY(pyn_lattice_detect(c, conn));
   // graph + matrices depend on the mesh
   (void)hipFree(c->d_rowptr);
@@ -348,6 +349,7 @@ extern "C" int pyn_elem_tables_set(pyn_ctx* c, int which, int ngp, const double*
         aff[248 + d * 3 + m] = sacc;
       }
     c->aff_standard = pyn_q1_affine_tables_standard(aff);
+    c->aff_rw_standard = pyn_q1_mixed_tables_standard(w, H, Hrs);
     PYN_TRY(dev_upload(&c->d_aff, aff, (size_t)(6 * 36 + 32 + 9), c->stream));
   }
   PYN_HIP(hipStreamSynchronize(c->stream));

@@ -98,7 +98,6 @@ struct PatchPlan {
 struct Lattice {
   bool valid = false;
   int nx = 0, ny = 0, npl = 0, p_own0 = 0, n_own = 0;
-  int all_affine = -1;         // every element a parallelepiped? (-1: not checked yet)
   bool std_shape = false;      // all planes owned, in id order (single rank)
   int std_ok = -1;             // closed-form row offsets verified against the graph (-1: not checked yet)
   int32_t* d_P = nullptr;      // [npl]
@@ -146,6 +145,8 @@ struct pyn_ctx {
   int32_t* d_conn = nullptr;
   double* d_xyz = nullptr;
   QuadTab quad[3];
+  int mesh_affine = -1;          // every element a parallelepiped? (-1: not checked yet; reset by pyn_mesh_set)
+  bool aff_rw_standard = false;  // ... and so is int N_a d N_b (affine Rw path)
   bool aff_standard = false;  // the uploaded tables are those of the trilinear hexahedron in closed form
   double* d_aff = nullptr;  // Q1-hex affine tables: [6][36] reference matrices + [4][8] non-affine monomial signs + [3][3] S
 
@@ -204,3 +205,4 @@ int pyn_sell_spmv(pyn_ctx* c, const DMat& A, const double* x, double* y, bool do
 void pyn_sell_drop_structure(pyn_ctx* c);
 int pyn_lattice_detect(pyn_ctx* c, const int32_t* conn_host);  // pyn_assemble_tiled.hip
 bool pyn_q1_affine_tables_standard(const double* aff);
+bool pyn_q1_mixed_tables_standard(const double* w, const double* H, const double* Hrs);
