@@ -1053,7 +1053,7 @@ __global__ void __launch_bounds__(KLE_THREADS, 2) assemble_q1_hex_kle_tiled_kern
       X[a][2] = q[2];
     }
     unsigned bcn = 0;  // bit 3*b + q = DOF (node b, comp q) imposed
-    if ((WHICH == 0 || WHICH == 3) && T.bcmask) {
+    if (WHICH == 0 && T.bcmask) {
 #pragma unroll
       for (int b = 0; b < 8; ++b)
 #pragma unroll
@@ -1067,54 +1067,10 @@ __global__ void __launch_bounds__(KLE_THREADS, 2) assemble_q1_hex_kle_tiled_kern
     const unsigned kmw[16] = {km4[0].x, km4[0].y, km4[0].z, km4[0].w, km4[1].x, km4[1].y, km4[1].z, km4[1].w,
                               km4[2].x, km4[2].y, km4[2].z, km4[2].w, km4[3].x, km4[3].y, km4[3].z, km4[3].w};
     // reduced (centroid) point
-    if (WHICH == 0 || WHICH == 3) {
+    if (WHICH == 0) {
       double Gr[3][8];
-      double cr;
+      const double cr = T.wr[0] * point_gradients(T.hcoor, T.hrsr, X, Gr);
       double L[36];
-      if (WHICH == 3) {
-        // every element a parallelepiped (checked once per mesh): one Jacobian serves the centroid gradients and
-        // the Laplacian block, whose reference matrices are compile-time integers (q1_aff_int)
-        double Ji[3][3];
-        const double det = jacobian_inverse(T.hcoor, X, Ji);
-        cr = T.wr[0] * det;
-        const double* __restrict__ hr = T.hrsr;
-#pragma unroll
-        for (int d = 0; d < 3; ++d)
-#pragma unroll
-          for (int a = 0; a < 8; ++a) Gr[d][a] = fma(Ji[d][2], hr[16 + a], fma(Ji[d][1], hr[8 + a], Ji[d][0] * hr[a]));
-        double D[3][3], M2[3][2];
-        {
-          constexpr int RS[6][2] = {{0, 0}, {1, 1}, {2, 2}, {0, 1}, {0, 2}, {1, 2}};
-#pragma unroll
-          for (int u = 0; u < 3; ++u) {
-            const int a0 = RS[u][0], a1 = RS[3 + u][0], b1 = RS[3 + u][1];
-            const double qd = det * (Ji[0][a0] * Ji[0][a0] + Ji[1][a0] * Ji[1][a0] + Ji[2][a0] * Ji[2][a0]) * (1.0 / 72.0);
-            const double qm = det * (Ji[0][a1] * Ji[0][b1] + Ji[1][a1] * Ji[1][b1] + Ji[2][a1] * Ji[2][b1]) * (1.0 / 72.0);
-            D[u][0] = 4.0 * qd;
-            D[u][1] = 8.0 * qd;
-            D[u][2] = 16.0 * qd;
-            M2[u][0] = 12.0 * qm;
-            M2[u][1] = 24.0 * qm;
-          }
-        }
-        int idx = 0;
-#pragma unroll
-        for (int a = 0; a < 8; ++a)
-#pragma unroll
-          for (int c2 = a; c2 < 8; ++c2, ++idx) {
-            double v = 0.0;
-#pragma unroll
-            for (int u = 0; u < 6; ++u) {
-              const int n = q1_aff_int(u, a, c2);
-              const int an = n < 0 ? -n : n;
-              if (an == 0) continue;
-              const double x = u < 3 ? D[u][an == 4 ? 0 : (an == 8 ? 1 : 2)] : M2[u - 3][an == 12 ? 0 : 1];
-              v = n > 0 ? v + x : v - x;
-            }
-            L[idx] = v;
-          }
-      } else {
-      cr = T.wr[0] * point_gradients(T.hcoor, T.hrsr, X, Gr);
 #pragma unroll
       for (int i = 0; i < 36; ++i) L[i] = 0.0;
       {
@@ -1129,7 +1085,6 @@ __global__ void __launch_bounds__(KLE_THREADS, 2) assemble_q1_hex_kle_tiled_kern
 #pragma nounroll
           for (int g = 0; g < 8; ++g) gauss_point(S, g, X, L);
         }
-      }
       }
       const double caw = cr * T.alpha_w, cad = cr * T.alpha_d;
 #pragma unroll
@@ -1160,54 +1115,7 @@ __global__ void __launch_bounds__(KLE_THREADS, 2) assemble_q1_hex_kle_tiled_kern
     } else {
       // Rw: passes over the derivative axis m (x the two halves of the row nodes, to keep one 4x8
       // block of T_m live): (p, kc) = the two other axes in both orders
-      if (WHICH == 2) {
-        // every element of the mesh is a parallelepiped (checked once per mesh): constant G, so
-        //   T_m[a][b] = detJ sum_d Ji[m][d] int N_a d_d N_b   (integrals = small integers / 72, q1_mix_int)
-        // and the whole 8x8 block of 3x3 entries comes straight from Ji -- no Gauss loop, no passes
-        double Ji[3][3];
-        const double det = jacobian_inverse(T.hcoor, X, Ji);
-        const double caw = T.wr[0] * det * T.alpha_w;
-        const double* __restrict__ hr = T.hrsr;
-        double D[3][3][3];   // [m][d][4|8|16] = detJ Ji[m][d] {4, 8, 16} / 72
-#pragma unroll
-        for (int m = 0; m < 3; ++m)
-#pragma unroll
-          for (int d = 0; d < 3; ++d) {
-            const double x = det * Ji[m][d] * (1.0 / 72.0);
-            D[m][d][0] = 4.0 * x;
-            D[m][d][1] = 8.0 * x;
-            D[m][d][2] = 16.0 * x;
-          }
-#pragma unroll
-        for (int a = 0; a < 8; ++a) {
-          const unsigned slot = (rsw[a >> 1] >> (16 * (a & 1))) & 0xFFFFu;
-          if (slot == 0xFFFFu) continue;
-          double* rowp = acc + (size_t)slot * rowsz;
-          double gra[3];     // alpha_w c G_r[m][a] at the centroid
-#pragma unroll
-          for (int m = 0; m < 3; ++m) gra[m] = caw * fma(Ji[m][2], hr[16 + a], fma(Ji[m][1], hr[8 + a], Ji[m][0] * hr[a]));
-#pragma unroll
-          for (int b = 0; b < 8; ++b) {
-            const unsigned k = (kmw[2 * a + (b >> 2)] >> (8 * (b & 3))) & 0xFFu;
-            const double hb = T.Hr[b];
-#pragma unroll
-            for (int m = 0; m < 3; ++m) {
-              double tv = 0.0;
-#pragma unroll
-              for (int d = 0; d < 3; ++d) {
-                const int n = q1_mix_int(d, a, b);
-                const int an = n < 0 ? -n : n;
-                const double x = D[m][d][an == 4 ? 0 : (an == 8 ? 1 : 2)];
-                tv = n > 0 ? tv + x : tv - x;
-              }
-              const double wv = tv - gra[m] * hb;
-              const int P1 = (m + 1) % 3, P2 = (m + 2) % 3;
-              atomicAdd(&rowp[(P2 * ml + k) * 3 + P1], wv);
-              atomicAdd(&rowp[(P1 * ml + k) * 3 + P2], -wv);
-            }
-          }
-        }
-      } else {
+      {
 #pragma nounroll
         for (int it = 0; it < 6; ++it) {  // a rolled loop keeps the passes from being interleaved (registers)
           switch (it) {
@@ -1243,9 +1151,9 @@ __global__ void __launch_bounds__(KLE_THREADS, 2) assemble_q1_hex_kle_tiled_kern
         const double v = src[idx];
         double va, vr;
         if (rowbc) {
-          const bool dg = (WHICH == 0 || WHICH == 3) && q == pp && T.colidx[lo + k] == T.p_rows[r_lo + slot];
+          const bool dg = (WHICH == 0) && q == pp && T.colidx[lo + k] == T.p_rows[r_lo + slot];
           va = vr = dg ? 1.0 : 0.0;
-        } else if ((WHICH == 0 || WHICH == 3) && ((cflag[slot * 3 + q] >> k) & 1u)) {
+        } else if (WHICH == 0 && ((cflag[slot * 3 + q] >> k) & 1u)) {
           va = 0.0;
           vr = -v;
         } else {
@@ -1253,7 +1161,246 @@ __global__ void __launch_bounds__(KLE_THREADS, 2) assemble_q1_hex_kle_tiled_kern
           vr = 0.0;
         }
         outA[gbase + idx] = va;
-        if ((WHICH == 0 || WHICH == 3) && outR) outR[gbase + idx] = vr;
+        if (WHICH == 0 && outR) outR[gbase + idx] = vr;
+      }
+    }
+  }
+}
+
+// ---- all-parallelepiped meshes (checked once per mesh on the device): closed-form element blocks, FOUR waves per
+// patch.  Wave w adds the node rows {2w, 2w+1} of every element (one element per lane, rounds of 64), so the
+// 576 LDS adds of an element are spread over four waves and a CU holds 12 waves instead of 6 -- the general
+// kernels run one wave per SIMD, which is what bounds them.  Every wave recomputes the (cheap) Jacobian.
+//   K : L_ab from the integer reference matrices (q1_aff_int), centroid gradients from Ji
+//   Rw: T_m[a][b] = detJ sum_d Ji[m][d] int N_a d_d N_b (q1_mix_int), no Gauss loop, no passes
+constexpr int KLE_AFF_THREADS = 256;
+
+template <int A0>
+__device__ __forceinline__ void kle_affine_k_rows(const KleArgs& T, const double (&Ji)[3][3], double det, const unsigned (&rsw)[4],
+                                                  const unsigned (&kmw)[16], unsigned bcn, double* acc, unsigned* cflag,
+                                                  int rowsz, int ml) {
+  const double cr = T.wr[0] * det;
+  const double caw = cr * T.alpha_w, cad = cr * T.alpha_d;
+  const double* __restrict__ hr = T.hrsr;
+  double Gr[3][8];
+#pragma unroll
+  for (int d = 0; d < 3; ++d)
+#pragma unroll
+    for (int a = 0; a < 8; ++a) Gr[d][a] = fma(Ji[d][2], hr[16 + a], fma(Ji[d][1], hr[8 + a], Ji[d][0] * hr[a]));
+  double D[3][3], M2[3][2];
+  {
+    constexpr int RS[6][2] = {{0, 0}, {1, 1}, {2, 2}, {0, 1}, {0, 2}, {1, 2}};
+#pragma unroll
+    for (int u = 0; u < 3; ++u) {
+      const int a0 = RS[u][0], a1 = RS[3 + u][0], b1 = RS[3 + u][1];
+      const double qd = det * (Ji[0][a0] * Ji[0][a0] + Ji[1][a0] * Ji[1][a0] + Ji[2][a0] * Ji[2][a0]) * (1.0 / 72.0);
+      const double qm = det * (Ji[0][a1] * Ji[0][b1] + Ji[1][a1] * Ji[1][b1] + Ji[2][a1] * Ji[2][b1]) * (1.0 / 72.0);
+      D[u][0] = 4.0 * qd;
+      D[u][1] = 8.0 * qd;
+      D[u][2] = 16.0 * qd;
+      M2[u][0] = 12.0 * qm;
+      M2[u][1] = 24.0 * qm;
+    }
+  }
+#pragma unroll
+  for (int h = 0; h < 2; ++h) {
+    const int a = A0 + h;
+    const unsigned slot = (rsw[a >> 1] >> (16 * (a & 1))) & 0xFFFFu;
+    if (slot == 0xFFFFu) continue;
+    double* rowp = acc + (size_t)slot * rowsz;
+#pragma unroll
+    for (int b = 0; b < 8; ++b) {
+      const unsigned k = (kmw[2 * a + (b >> 2)] >> (8 * (b & 3))) & 0xFFu;
+      double lab = 0.0;
+#pragma unroll
+      for (int u = 0; u < 6; ++u) {
+        const int n = q1_aff_int(u, a, b);
+        const int an = n < 0 ? -n : n;
+        if (an == 0) continue;
+        const double x = u < 3 ? D[u][an == 4 ? 0 : (an == 8 ? 1 : 2)] : M2[u - 3][an == 12 ? 0 : 1];
+        lab = n > 0 ? lab + x : lab - x;
+      }
+      const double s_ab = Gr[0][a] * Gr[0][b] + Gr[1][a] * Gr[1][b] + Gr[2][a] * Gr[2][b];
+      const double diag = lab + caw * s_ab;
+      if (bcn) {
+#pragma unroll
+        for (int q = 0; q < 3; ++q)
+          if ((bcn >> (3 * b + q)) & 1u) atomicOr(&cflag[slot * 3 + q], 1u << k);
+      }
+#pragma unroll
+      for (int pp = 0; pp < 3; ++pp)
+#pragma unroll
+        for (int q = 0; q < 3; ++q) {
+          double v = cad * Gr[pp][a] * Gr[q][b] - caw * Gr[q][a] * Gr[pp][b];
+          if (pp == q) v += diag;
+          atomicAdd(&rowp[(pp * ml + k) * 3 + q], v);
+        }
+    }
+  }
+}
+
+template <int A0>
+__device__ __forceinline__ void kle_affine_rw_rows(const KleArgs& T, const double (&Ji)[3][3], double det, const unsigned (&rsw)[4],
+                                                   const unsigned (&kmw)[16], double* acc, int rowsz, int ml) {
+  const double caw = T.wr[0] * det * T.alpha_w;
+  const double* __restrict__ hr = T.hrsr;
+  double D[3][3][3];   // [m][d][4|8|16] = detJ Ji[m][d] {4, 8, 16} / 72
+#pragma unroll
+  for (int m = 0; m < 3; ++m)
+#pragma unroll
+    for (int d = 0; d < 3; ++d) {
+      const double x = det * Ji[m][d] * (1.0 / 72.0);
+      D[m][d][0] = 4.0 * x;
+      D[m][d][1] = 8.0 * x;
+      D[m][d][2] = 16.0 * x;
+    }
+#pragma unroll
+  for (int h = 0; h < 2; ++h) {
+    const int a = A0 + h;
+    const unsigned slot = (rsw[a >> 1] >> (16 * (a & 1))) & 0xFFFFu;
+    if (slot == 0xFFFFu) continue;
+    double* rowp = acc + (size_t)slot * rowsz;
+    double gra[3];     // alpha_w c G_r[m][a] at the centroid
+#pragma unroll
+    for (int m = 0; m < 3; ++m) gra[m] = caw * fma(Ji[m][2], hr[16 + a], fma(Ji[m][1], hr[8 + a], Ji[m][0] * hr[a]));
+#pragma unroll
+    for (int b = 0; b < 8; ++b) {
+      const unsigned k = (kmw[2 * a + (b >> 2)] >> (8 * (b & 3))) & 0xFFu;
+      const double hb = T.Hr[b];
+#pragma unroll
+      for (int m = 0; m < 3; ++m) {
+        double tv = 0.0;
+#pragma unroll
+        for (int d = 0; d < 3; ++d) {
+          const int n = q1_mix_int(d, a, b);
+          const int an = n < 0 ? -n : n;
+          const double x = D[m][d][an == 4 ? 0 : (an == 8 ? 1 : 2)];
+          tv = n > 0 ? tv + x : tv - x;
+        }
+        // (curl w)_p = eps_{p m k} d_m w_k: +T_m at (row comp m+2, col comp m+1), -T_m at (m+1, m+2); the reduced
+        // term carries eps_{k m p}
+        const double wv = tv - gra[m] * hb;
+        const int P1 = (m + 1) % 3, P2 = (m + 2) % 3;
+        atomicAdd(&rowp[(P2 * ml + k) * 3 + P1], wv);
+        atomicAdd(&rowp[(P1 * ml + k) * 3 + P2], -wv);
+      }
+    }
+  }
+}
+
+template <bool RW>
+__global__ void __launch_bounds__(KLE_AFF_THREADS, 3) assemble_q1_hex_kle_affine_kernel(KleArgs T) {
+  extern __shared__ __align__(16) double acc[];  // [maxrows][3][maxlen][3]
+  const int p = blockIdx.x;
+  const int r_lo = T.p_rowptr[p];
+  const int nrows = T.p_rowptr[p + 1] - r_lo;
+  const int e_lo = T.p_eptr[p];
+  const int ne = T.p_eptr[p + 1] - e_lo;
+  const int ml = T.maxlen;
+  const int rowsz = 9 * ml;
+  int* rmeta = reinterpret_cast<int*>(acc + (size_t)T.maxrows * rowsz);
+  unsigned* cflag = reinterpret_cast<unsigned*>(rmeta + 2 * T.maxrows);
+  const int tid = threadIdx.x, lane = tid & 63, part = tid >> 6;
+
+  for (int i = tid; i < nrows * rowsz; i += KLE_AFF_THREADS) acc[i] = 0.0;
+  for (int i = tid; i < nrows * 3; i += KLE_AFF_THREADS) cflag[i] = 0u;
+  for (int sl = tid; sl < nrows; sl += KLE_AFF_THREADS) {
+    const int row = T.p_rows[r_lo + sl];
+    const int lo = T.rowptr[row];
+    const int len = T.rowptr[row + 1] - lo;
+    int rb = 0;
+    if (T.bcmask) rb = (T.bcmask[row * 3] ? 1 : 0) | (T.bcmask[row * 3 + 1] ? 2 : 0) | (T.bcmask[row * 3 + 2] ? 4 : 0);
+    rmeta[2 * sl] = lo;
+    rmeta[2 * sl + 1] = len | (rb << 16);
+  }
+  __syncthreads();
+
+  for (int base = 0; base < ne; base += 64) {
+    const int t = base + lane;
+    if (t >= ne) continue;
+    const int64_t pe = (int64_t)e_lo + t;
+    const int64_t e = T.p_elem[pe];
+    const int4 c0 = reinterpret_cast<const int4*>(T.conn)[e * 2];
+    const int4 c1 = reinterpret_cast<const int4*>(T.conn)[e * 2 + 1];
+    const int nd[8] = {c0.x, c0.y, c0.z, c0.w, c1.x, c1.y, c1.z, c1.w};
+    double X[8][3];
+#pragma unroll
+    for (int a = 0; a < 8; ++a) {
+      const double* q = T.xyz + (int64_t)nd[a] * 3;
+      X[a][0] = q[0];
+      X[a][1] = q[1];
+      X[a][2] = q[2];
+    }
+    unsigned bcn = 0;  // bit 3*b + q = DOF (node b, comp q) imposed
+    if (!RW && T.bcmask) {
+#pragma unroll
+      for (int b = 0; b < 8; ++b)
+#pragma unroll
+        for (int q = 0; q < 3; ++q) bcn |= (T.bcmask[(int64_t)nd[b] * 3 + q] ? 1u : 0u) << (3 * b + q);
+    }
+    const uint4 rs4 = T.rowslot4[pe];
+    const unsigned rsw[4] = {rs4.x, rs4.y, rs4.z, rs4.w};
+    // only this wave's two rows of the scatter map
+    const uint4 km = T.kmap4[(int64_t)part * T.npe + pe];
+    unsigned kmw[16];
+#pragma unroll
+    for (int j = 0; j < 16; ++j) kmw[j] = 0;
+    double Ji[3][3];
+    const double det = jacobian_inverse(T.hcoor, X, Ji);
+    switch (part) {   // wave-uniform
+      case 0:
+        kmw[0] = km.x, kmw[1] = km.y, kmw[2] = km.z, kmw[3] = km.w;
+        if (RW) kle_affine_rw_rows<0>(T, Ji, det, rsw, kmw, acc, rowsz, ml);
+        else kle_affine_k_rows<0>(T, Ji, det, rsw, kmw, bcn, acc, cflag, rowsz, ml);
+        break;
+      case 1:
+        kmw[4] = km.x, kmw[5] = km.y, kmw[6] = km.z, kmw[7] = km.w;
+        if (RW) kle_affine_rw_rows<2>(T, Ji, det, rsw, kmw, acc, rowsz, ml);
+        else kle_affine_k_rows<2>(T, Ji, det, rsw, kmw, bcn, acc, cflag, rowsz, ml);
+        break;
+      case 2:
+        kmw[8] = km.x, kmw[9] = km.y, kmw[10] = km.z, kmw[11] = km.w;
+        if (RW) kle_affine_rw_rows<4>(T, Ji, det, rsw, kmw, acc, rowsz, ml);
+        else kle_affine_k_rows<4>(T, Ji, det, rsw, kmw, bcn, acc, cflag, rowsz, ml);
+        break;
+      default:
+        kmw[12] = km.x, kmw[13] = km.y, kmw[14] = km.z, kmw[15] = km.w;
+        if (RW) kle_affine_rw_rows<6>(T, Ji, det, rsw, kmw, acc, rowsz, ml);
+        else kle_affine_k_rows<6>(T, Ji, det, rsw, kmw, bcn, acc, cflag, rowsz, ml);
+        break;
+    }
+  }
+  __syncthreads();
+
+  // ---- store: every scalar row (slot, p) = 3*len contiguous doubles, written once (as in the general kernel)
+  {
+    double* __restrict__ outA = T.K;
+    double* __restrict__ outR = T.Krhs;
+    constexpr int NW = KLE_AFF_THREADS / 64;
+    for (int sr = part; sr < nrows * 3; sr += NW) {
+      const int slot = sr / 3, pp = sr - slot * 3;
+      const int lo = rmeta[2 * slot];
+      const int m1 = rmeta[2 * slot + 1];
+      const int len = m1 & 0xFFFF;
+      const bool rowbc = (m1 >> (16 + pp)) & 1;
+      const int64_t gbase = ((int64_t)lo * 3 + (int64_t)pp * len) * 3;
+      const double* src = acc + (size_t)slot * rowsz + (size_t)pp * ml * 3;
+      for (int idx = lane; idx < len * 3; idx += 64) {
+        const int k = idx / 3, q = idx - k * 3;
+        const double v = src[idx];
+        double va, vr;
+        if (rowbc) {
+          const bool dg = !RW && q == pp && T.colidx[lo + k] == T.p_rows[r_lo + slot];
+          va = vr = dg ? 1.0 : 0.0;
+        } else if (!RW && ((cflag[slot * 3 + q] >> k) & 1u)) {
+          va = 0.0;
+          vr = -v;
+        } else {
+          va = v;
+          vr = 0.0;
+        }
+        outA[gbase + idx] = va;
+        if (!RW && outR) outR[gbase + idx] = vr;
       }
     }
   }
@@ -1402,9 +1549,9 @@ extern "C" int pyn_patch_plan_set_kind(pyn_ctx* c, int kind, int n_patch, const 
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     PYN_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(assemble_q1_hex_kle_tiled_kernel<1>),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    PYN_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(assemble_q1_hex_kle_tiled_kernel<2>),
+    PYN_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(assemble_q1_hex_kle_affine_kernel<false>),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    PYN_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(assemble_q1_hex_kle_tiled_kernel<3>),
+    PYN_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(assemble_q1_hex_kle_affine_kernel<true>),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   }
   return PYN_OK;
@@ -1473,7 +1620,7 @@ static int assemble_kle_tiled(pyn_ctx* c, double alpha_d, double alpha_w, double
     int all_aff = 0;
     if (T.aff && c->aff_standard) PYN_TRY(mesh_all_affine(c, &all_aff));
     if (all_aff)
-      assemble_q1_hex_kle_tiled_kernel<3><<<P.npatch, KLE_THREADS, lds, c->stream>>>(T);
+      assemble_q1_hex_kle_affine_kernel<false><<<P.npatch, KLE_AFF_THREADS, lds, c->stream>>>(T);
     else
       assemble_q1_hex_kle_tiled_kernel<0><<<P.npatch, KLE_THREADS, lds, c->stream>>>(T);
   }
@@ -1483,7 +1630,7 @@ static int assemble_kle_tiled(pyn_ctx* c, double alpha_d, double alpha_w, double
     int all_aff = 0;
     if (T.aff_rw) PYN_TRY(mesh_all_affine(c, &all_aff));
     if (all_aff)
-      assemble_q1_hex_kle_tiled_kernel<2><<<P.npatch, KLE_THREADS, lds, c->stream>>>(T);
+      assemble_q1_hex_kle_affine_kernel<true><<<P.npatch, KLE_AFF_THREADS, lds, c->stream>>>(T);
     else
       assemble_q1_hex_kle_tiled_kernel<1><<<P.npatch, KLE_THREADS, lds, c->stream>>>(T);
   }
