@@ -14,8 +14,9 @@ import sys
 __version__ = "0.1.0"
 
 _SUBPACKAGES = {
-    "elements": ("element", "utilities", "spectral"),
-    "domain": ("indices", "dmplex"),
+    "elements": ("element", "utilities", "spectral", "simplex"),
+    "domain": ("indices", "dmplex", "gmsh"),
+    "viewer": ("xml_generator", "paraviewer", "hdf5_writer"),
     "matrices": ("mat_generator", "mat_ns"),
     "solver": ("ksp_solver",),
     "common": ("timer", "nswalls", "options", "comm"),

@@ -112,10 +112,35 @@ class BaseProblem(object):
         self.dim_s = 3 if self.dim == 2 else 6
         self.ngl = kwargs['ngl'] if "ngl" in kwargs else domain['ngl']
 
-    def createMesh(self, saveMesh=True):
+    def createMesh(self, saveMesh=None):
+        """base_problem.py:117-125.  Unlike the reference, setUp() does not write `mesh.h5` into the working
+        directory unless asked to (`saveMesh=True`, or `save-output: true` in the yaml)."""
         self.dom.computeFullCoordinates(self.elemType)
+        self.viewer = None
+        if saveMesh is None:
+            saveMesh = bool(self.config.get("save-output", False))
+        if saveMesh:
+            self.getViewer().saveMesh(self.dom.fullCoordVec)
+            self._meshSaved = True
         if not self.comm.rank:
             self.logger.info("Mesh created")
+
+    def getViewer(self):
+        if getattr(self, "viewer", None) is None:
+            from pynama_amd.viewer.paraviewer import Paraviewer
+            self.viewer = Paraviewer(self.dim, self.comm, self.config.get("save-dir"))
+            self._meshSaved = False
+        return self.viewer
+
+    def saveStep(self, step, time, *extra):
+        """what the reference's converged-step callbacks write (base_problem.py:174-181, 201-202): the fields of
+        this step as /fields/<name> datasets + the XDMF time series"""
+        viewer = self.getViewer()
+        if not self._meshSaved:
+            viewer.saveMesh(self.dom.fullCoordVec)
+            self._meshSaved = True
+        viewer.saveData(step, time, self.vel, self.vort, *extra)
+        viewer.writeXmf(self.caseName)
 
     def setUpGeneral(self):
         self.setUpDomain()

@@ -890,6 +890,7 @@ struct KleArgs {
   const double *w, *H, *hrs, *hcoo;          // full rule
   const double *wr, *Hr, *hrsr, *hcoor;      // reduced rule (one point)
   const double* aff;
+  int ablate;    // diagnostics (PYNAMA_KLE_ABLATE): 1 = no element phase, 2 = element phase without the scatter map reads
   int aff_rw;    // the closed-form int N_a d N_b table was verified: affine elements skip the Gauss loop of Rw
   double alpha_d, alpha_w;
   double* K;     // WHICH 0: K     | WHICH 1: Rw
@@ -1315,7 +1316,7 @@ __global__ void __launch_bounds__(KLE_AFF_THREADS, 3) assemble_q1_hex_kle_affine
   }
   __syncthreads();
 
-  for (int base = 0; base < ne; base += 64) {
+  for (int base = 0; base < ne && T.ablate != 1; base += 64) {
     const int t = base + lane;
     if (t >= ne) continue;
     const int64_t pe = (int64_t)e_lo + t;
@@ -1611,6 +1612,10 @@ static int assemble_kle_tiled(pyn_ctx* c, double alpha_d, double alpha_w, double
   T.hcoor = c->quad[1].HrsCoo;
   T.aff = getenv("PYNAMA_NO_AFFINE") ? nullptr : c->d_aff;
   T.aff_rw = (T.aff && c->aff_rw_standard) ? 1 : 0;
+  {
+    const char* ab = getenv("PYNAMA_KLE_ABLATE");
+    T.ablate = ab ? atoi(ab) : 0;
+  }
   T.alpha_d = alpha_d;
   T.alpha_w = alpha_w;
   const size_t lds = kle_lds_bytes(P.maxrows, P.maxlen);

@@ -212,3 +212,24 @@ def test_gmsh_mesh_uniform_flow(tmp_path, nelem, upper):
     exactVel, exactVort = fem.generateExactVecs()
     fem.solveKLE(time=0.0, vort=exactVort)
     assert (exactVel - fem.vel).norm(norm_type=2) < 1e-10
+
+
+def test_save_step_writes_hdf5_and_xdmf(tmp_path):
+    """SURVEY.md 8 f4 (output half): the converged-step output of the reference (base_problem.py:174-181) from
+    device vectors: /fields/velocity, /fields/vorticity, mesh.h5 and the XDMF series"""
+    from pynama_amd.viewer import hdf5_writer
+    from cases.uniform import UniformFlow
+    with open(os.path.join(CASES, 'uniform.yaml')) as f:
+        cfg = yaml.load(f, Loader=yaml.Loader)
+    cfg["save-dir"] = str(tmp_path / "run")
+    fem = UniformFlow(cfg, case="uniform", nelem=[4, 3], ngl=3)
+    fem.setUp()
+    fem.setUpSolver()
+    exactVel, exactVort = fem.generateExactVecs()
+    fem.solveKLE(time=0.0, vort=exactVort)
+    fem.saveStep(3, 0.25)
+    d = cfg["save-dir"]
+    assert np.array_equal(hdf5_writer.read_dataset(os.path.join(d, "vec-data-00003.h5"), "/fields/velocity"), fem.vel.getArray())
+    assert np.array_equal(hdf5_writer.read_dataset(os.path.join(d, "vec-data-00003.h5"), "/fields/vorticity"), fem.vort.getArray())
+    assert np.array_equal(hdf5_writer.read_dataset(os.path.join(d, "mesh.h5"), "/fields/mesh"), fem.dom.fullCoordVec.getArray())
+    assert os.path.exists(os.path.join(d, f"{fem.caseName}.xmf"))
