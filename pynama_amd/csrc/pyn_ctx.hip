@@ -60,8 +60,11 @@ extern "C" int pyn_ctx_create(int device, pyn_ctx** out) {
   pyn_ctx* c = new pyn_ctx();
   c->device = device;
   PYN_HIP(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+  PYN_HIP(hipStreamCreateWithFlags(&c->comm_stream, hipStreamNonBlocking));
   PYN_HIP(hipEventCreate(&c->ev0));
   PYN_HIP(hipEventCreate(&c->ev1));
+  PYN_HIP(hipEventCreateWithFlags(&c->ev_vec, hipEventDisableTiming));
+  PYN_HIP(hipEventCreateWithFlags(&c->ev_halo, hipEventDisableTiming));
   PYN_HIP(hipMalloc((void**)&c->d_part, 8 * PYN_MAX_PARTIALS * sizeof(double)));
   PYN_HIP(hipMalloc((void**)&c->d_scal, 64 * sizeof(double)));
   PYN_HIP(hipMalloc((void**)&c->d_flag, 8 * sizeof(int)));
@@ -113,6 +116,9 @@ extern "C" int pyn_ctx_destroy(pyn_ctx* c) {
   for (auto e : c->prof_ev) (void)hipEventDestroy(e);
   (void)hipEventDestroy(c->ev0);
   (void)hipEventDestroy(c->ev1);
+  (void)hipEventDestroy(c->ev_vec);
+  (void)hipEventDestroy(c->ev_halo);
+  (void)hipStreamDestroy(c->comm_stream);
   (void)hipStreamDestroy(c->stream);
   delete c;
   return PYN_OK;
@@ -214,7 +220,9 @@ __global__ void pack_send_kernel(const double* __restrict__ x, const int32_t* __
   }
 }
 
-int pyn_halo_exchange(pyn_ctx* c, double* x, int bs) {
+int pyn_halo_exchange(pyn_ctx* c, double* x, int bs) { return pyn_halo_exchange_on(c, x, bs, c->stream); }
+
+int pyn_halo_exchange_on(pyn_ctx* c, double* x, int bs, hipStream_t st) {
   if (c->neigh.empty()) return PYN_OK;
   if (c->detached) return PYN_OK;  // ghost entries were written by the caller (pyn_vec_set_local_host)
   PYN_CHECK(c->comm, "halo exchange needs a communicator (pyn_comm_init with a unique id)");
@@ -222,14 +230,14 @@ int pyn_halo_exchange(pyn_ctx* c, double* x, int bs) {
   if (c->n_send) {
     int64_t tot = c->n_send * bs;
     int grid = (int)std::min<int64_t>((tot + 255) / 256, 1024);
-    pack_send_kernel<<<grid, 256, 0, c->stream>>>(x, c->d_send_idx, c->d_send_buf, c->n_send, bs);
+    pack_send_kernel<<<grid, 256, 0, st>>>(x, c->d_send_idx, c->d_send_buf, c->n_send, bs);
   }
   PYN_NCCL(ncclGroupStart());
   for (size_t k = 0; k < c->neigh.size(); ++k) {
     int64_t ns = c->send_ptr[k + 1] - c->send_ptr[k];
     int64_t nr = c->recv_ptr[k + 1] - c->recv_ptr[k];
-    if (ns) PYN_NCCL(ncclSend(c->d_send_buf + c->send_ptr[k] * bs, (size_t)ns * bs, ncclDouble, c->neigh[k], c->comm, c->stream));
-    if (nr) PYN_NCCL(ncclRecv(x + (c->n_owned + c->recv_ptr[k]) * bs, (size_t)nr * bs, ncclDouble, c->neigh[k], c->comm, c->stream));
+    if (ns) PYN_NCCL(ncclSend(c->d_send_buf + c->send_ptr[k] * bs, (size_t)ns * bs, ncclDouble, c->neigh[k], c->comm, st));
+    if (nr) PYN_NCCL(ncclRecv(x + (c->n_owned + c->recv_ptr[k]) * bs, (size_t)nr * bs, ncclDouble, c->neigh[k], c->comm, st));
   }
   PYN_NCCL(ncclGroupEnd());
   return PYN_OK;

@@ -110,6 +110,7 @@ struct SellShape {
   int64_t* ptr = nullptr;   // [ns+1] slice offsets
   int* w = nullptr;         // [ns] slice widths (entries per scalar row)
   int32_t* col = nullptr;   // explicit expanded columns (only when the dictionary does not apply)
+  int64_t int_begin = -1, int_end = -1;  // slices without ghost columns, when they are one contiguous range
 };
 
 struct DVec {
@@ -123,7 +124,9 @@ constexpr int PYN_MAX_PARTIALS = 2048;  // grid cap of every reducing kernel
 struct pyn_ctx {
   int device = 0;
   hipStream_t stream = nullptr;
+  hipStream_t comm_stream = nullptr;            // halo exchange overlapped with the interior SpMV rows
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
+  hipEvent_t ev_vec = nullptr, ev_halo = nullptr;  // vector ready for the exchange / ghosts have arrived
   double timers[PYN_T_COUNT] = {0};
 
   // communicator
@@ -194,6 +197,7 @@ inline int64_t n_local(const pyn_ctx* c) { return c->n_owned + c->n_ghost; }
 // ---- cross-TU helpers ---------------------------------------------------------------------
 int pyn_ensure_work(pyn_ctx* c, size_t bytes);
 int pyn_halo_exchange(pyn_ctx* c, double* x, int bs);  // fills ghost part of x (stream ordered)
+int pyn_halo_exchange_on(pyn_ctx* c, double* x, int bs, hipStream_t st);
 int pyn_check_mat(pyn_ctx* c, int id, const char* what);
 int pyn_check_vec(pyn_ctx* c, int id, const char* what);
 int pyn_reduce_host(pyn_ctx* c, int nslots, int nblocks, int op, double* out);  // partials -> host, allreduced
@@ -203,6 +207,9 @@ int pyn_sell_ensure(pyn_ctx* c, DMat& A);
 bool pyn_sell_supported(const DMat& A);
 int pyn_sell_spmv(pyn_ctx* c, const DMat& A, const double* x, double* y, bool dot, int* grid_out);
 void pyn_sell_drop_structure(pyn_ctx* c);
+const SellShape* pyn_sell_shape(pyn_ctx* c, const DMat& A);
+int pyn_sell_spmv_range(pyn_ctx* c, const DMat& A, const double* x, double* y, bool dot, int64_t s0, int64_t s1, int poff,
+                        int max_grid, hipStream_t st, int* grid_out);
 int pyn_lattice_detect(pyn_ctx* c, const int32_t* conn_host);  // pyn_assemble_tiled.hip
 bool pyn_q1_affine_tables_standard(const double* aff);
 bool pyn_q1_mixed_tables_standard(const double* w, const double* H, const double* Hrs);

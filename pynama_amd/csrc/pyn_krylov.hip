@@ -622,6 +622,9 @@ static int solve_cg_sr(pyn_ctx* c, DMat& A, const double* b, double* x, const py
   const int maxit = o.fixed_iters > 0 ? o.fixed_iters : o.maxit;
   const int check = o.fixed_iters > 0 ? 0 : 1;
   const bool multi = c->comm != nullptr;
+  const SellShape* S = sell ? pyn_sell_shape(c, A) : nullptr;
+  const bool overlap = multi && !c->neigh.empty() && !c->detached && S && S->int_begin >= 0 && !getenv("PYNAMA_NO_OVERLAP");
+  if (getenv("PYNAMA_OVERLAP_REQUIRE")) PYN_CHECK(overlap, "halo/SpMV overlap not engaged (tests)");
 
   cgsr_setup_kernel<<<1, 1, 0, s>>>(c->d_scal, c->d_flag, check ? o.rtol : 0.0, check ? o.atol : 0.0, o.dtol);
   cgsr_init_kernel<<<g, 256, 0, s>>>(b, dv, x, r, u, p, sv, n, o.norm_type, c->d_part);
@@ -638,14 +641,31 @@ static int solve_cg_sr(pyn_ctx* c, DMat& A, const double* b, double* x, const py
   while (!done && issued <= maxit) {
     const int todo = std::min(chunk, maxit + 1 - issued);
     for (int k = 0; k < todo; ++k) {
-      PYN_TRY(pyn_halo_exchange(c, u, A.bc));
       const bool prof = prof_n < prof_max;
-      if (prof) PYN_HIP(hipEventRecord(c->prof_ev[2 * prof_n], s));
       int gsp = gs;
-      if (sell)
-        PYN_TRY(pyn_sell_spmv(c, A, u, w, true, &gsp));
-      else
-        spmv_kernel<32, true><<<gs, 256, 0, s>>>(c->d_rowptr, c->d_colidx, A.val, u, w, rows, A.br, A.bc, c->d_flag, c->d_part);
+      if (overlap) {
+        // halo exchange of u on the communication stream while the rows without ghost columns are multiplied;
+        // the boundary rows follow once the ghosts have arrived.  u (owned part) is final here: record, let the
+        // communication stream wait for it.
+        PYN_HIP(hipEventRecord(c->ev_vec, s));
+        PYN_HIP(hipStreamWaitEvent(c->comm_stream, c->ev_vec, 0));
+        PYN_TRY(pyn_halo_exchange_on(c, u, A.bc, c->comm_stream));
+        PYN_HIP(hipEventRecord(c->ev_halo, c->comm_stream));
+        if (prof) PYN_HIP(hipEventRecord(c->prof_ev[2 * prof_n], s));
+        int g0 = 0, g1 = 0, g2 = 0;
+        PYN_TRY(pyn_sell_spmv_range(c, A, u, w, true, S->int_begin, S->int_end, 0, PYN_MAX_PARTIALS - 512, s, &g0));
+        PYN_HIP(hipStreamWaitEvent(s, c->ev_halo, 0));
+        PYN_TRY(pyn_sell_spmv_range(c, A, u, w, true, 0, S->int_begin, g0, 256, s, &g1));
+        PYN_TRY(pyn_sell_spmv_range(c, A, u, w, true, S->int_end, S->ns, g0 + g1, 256, s, &g2));
+        gsp = g0 + g1 + g2;
+      } else {
+        PYN_TRY(pyn_halo_exchange(c, u, A.bc));
+        if (prof) PYN_HIP(hipEventRecord(c->prof_ev[2 * prof_n], s));
+        if (sell)
+          PYN_TRY(pyn_sell_spmv(c, A, u, w, true, &gsp));
+        else
+          spmv_kernel<32, true><<<gs, 256, 0, s>>>(c->d_rowptr, c->d_colidx, A.val, u, w, rows, A.br, A.bc, c->d_flag, c->d_part);
+      }
       if (prof) PYN_HIP(hipEventRecord(c->prof_ev[2 * prof_n++ + 1], s));
       const int first = (issued + k) == 0;
       if (multi) {

@@ -105,13 +105,13 @@ template <bool DOT>
 __global__ void __launch_bounds__(256) sell_spmv_kernel(const int64_t* __restrict__ sptr, const int* __restrict__ sw,
                                                         const int32_t* __restrict__ scol, const double* __restrict__ sval,
                                                         const double* __restrict__ x, double* __restrict__ y, int64_t n_rows,
-                                                        int64_t n_slices, const int* __restrict__ flag, double* __restrict__ part) {
+                                                        int64_t n_slices, const int* __restrict__ flag, double* __restrict__ part, int64_t s_begin, int part_off) {
   if (flag && flag[0]) return;
   const int lane = threadIdx.x & 63;
   const int64_t w0 = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
   const int64_t nw = ((int64_t)gridDim.x * blockDim.x) >> 6;
   double dot = 0.0;
-  for (int64_t s = w0; s < n_slices; s += nw) {
+  for (int64_t s = s_begin + w0; s < n_slices; s += nw) {
     const int64_t base = sptr[s] + lane;
     const int wd = sw[s];
     const double* __restrict__ v = sval + base;
@@ -139,7 +139,7 @@ __global__ void __launch_bounds__(256) sell_spmv_kernel(const int64_t* __restric
     dot = wsum64(dot);
     if (lane == 0) smd[threadIdx.x >> 6] = dot;
     __syncthreads();
-    if (threadIdx.x == 0) part[blockIdx.x] = smd[0] + smd[1] + smd[2] + smd[3];
+    if (threadIdx.x == 0) part[part_off + blockIdx.x] = smd[0] + smd[1] + smd[2] + smd[3];
   }
 }
 
@@ -209,7 +209,7 @@ __global__ void __launch_bounds__(256) sellp_spmv_kernel(const int64_t* __restri
                                                          int npat, const double* __restrict__ sval,
                                                          const double* __restrict__ x, double* __restrict__ y, int64_t n_rows,
                                                          int64_t n_slices, const int* __restrict__ flag,
-                                                         double* __restrict__ part) {
+                                                         double* __restrict__ part, int64_t s_begin, int part_off) {
   extern __shared__ int32_t ltab[];  // [npat][PAT_W]
   __shared__ double smd[4];
   if (flag && flag[0]) return;
@@ -221,7 +221,7 @@ __global__ void __launch_bounds__(256) sellp_spmv_kernel(const int64_t* __restri
   const int64_t w0 = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
   const int64_t nw = ((int64_t)gridDim.x * blockDim.x) >> 6;
   double dot = 0.0;
-  for (int64_t s = w0; s < n_slices; s += nw) {
+  for (int64_t s = s_begin + w0; s < n_slices; s += nw) {
     const int64_t row = s * SH + lane;
     const int wd = sw[s];
     const double* __restrict__ v = sval + sptr[s] + lane;
@@ -247,7 +247,7 @@ __global__ void __launch_bounds__(256) sellp_spmv_kernel(const int64_t* __restri
     dot = wsum64(dot);
     if (lane == 0) smd[threadIdx.x >> 6] = dot;
     __syncthreads();
-    if (threadIdx.x == 0) part[blockIdx.x] = smd[0] + smd[1] + smd[2] + smd[3];
+    if (threadIdx.x == 0) part[part_off + blockIdx.x] = smd[0] + smd[1] + smd[2] + smd[3];
   }
 }
 
@@ -259,7 +259,7 @@ __global__ void __launch_bounds__(256) sellb_spmv_kernel(const int64_t* __restri
                                                          int npat, const int32_t* __restrict__ scol,
                                                          const double* __restrict__ sval, const double* __restrict__ x,
                                                          double* __restrict__ y, int64_t n_rows, int br, int64_t n_slices,
-                                                         const int* __restrict__ flag, double* __restrict__ part) {
+                                                         const int* __restrict__ flag, double* __restrict__ part, int64_t s_begin, int part_off) {
   extern __shared__ int32_t ltab[];  // [npat][PAT_W]
   __shared__ double smd[4];
   if (flag && flag[0]) return;
@@ -271,7 +271,7 @@ __global__ void __launch_bounds__(256) sellb_spmv_kernel(const int64_t* __restri
   const int64_t w0 = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
   const int64_t nw = ((int64_t)gridDim.x * blockDim.x) >> 6;
   double dot = 0.0;
-  for (int64_t s = w0; s < n_slices; s += nw) {
+  for (int64_t s = s_begin + w0; s < n_slices; s += nw) {
     const int64_t row = s * SH + lane;
     const bool live = row < n_rows;
     const int64_t node = live ? row / br : 0;
@@ -302,7 +302,7 @@ __global__ void __launch_bounds__(256) sellb_spmv_kernel(const int64_t* __restri
     dot = wsum64(dot);
     if (lane == 0) smd[threadIdx.x >> 6] = dot;
     __syncthreads();
-    if (threadIdx.x == 0) part[blockIdx.x] = smd[0] + smd[1] + smd[2] + smd[3];
+    if (threadIdx.x == 0) part[part_off + blockIdx.x] = smd[0] + smd[1] + smd[2] + smd[3];
   }
 }
 
@@ -361,6 +361,17 @@ static int build_pattern_dictionary(pyn_ctx* c, int maxw) {
 
 // (re)build the SELL image of a matrix; the structure (slice pointers, widths, explicit columns) is
 // shared by all matrices of the same block shape, the column-pattern dictionary by all of them
+// slice s needs ghost entries of x iff one of its nodes has a column >= n_owned (rows are sorted: the last one)
+__global__ void slice_ghost_flag_kernel(const int32_t* __restrict__ rowptr, const int32_t* __restrict__ colidx, int64_t n_owned,
+                                        int br, int64_t ns, int* __restrict__ flags) {
+  for (int64_t s = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; s < ns; s += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t r0 = s * SH, r1 = std::min<int64_t>(r0 + SH, n_owned * br) - 1;
+    int f = 0;
+    for (int64_t i = r0 / br; i <= r1 / br; ++i) f |= colidx[rowptr[i + 1] - 1] >= n_owned;
+    flags[s] = f;
+  }
+}
+
 int pyn_sell_ensure(pyn_ctx* c, DMat& A) {
   PYN_CHECK(pyn_sell_supported(A), "no SELL kernel for block shape %dx%d", A.br, A.bc);
   hipStream_t s = c->stream;
@@ -400,6 +411,26 @@ int pyn_sell_ensure(pyn_ctx* c, DMat& A) {
     PYN_HIP(hipMemcpyAsync(q.ptr, ptr.data(), (ns + 1) * sizeof(int64_t), hipMemcpyHostToDevice, s));
     PYN_HIP(hipStreamSynchronize(s));
     if (c->sell_npat == 0) PYN_HIP(hipMalloc((void**)&q.col, q.total * sizeof(int32_t)));  // explicit columns needed
+    if (c->n_ghost > 0) {
+      // interior slices (no ghost columns) can be multiplied while the halo exchange is in flight: usable when
+      // they form ONE contiguous range (z-slabs: everything between the first and the last node plane)
+      DevTmp tf;
+      PYN_HIP(tf.alloc(ns * sizeof(int)));
+      slice_ghost_flag_kernel<<<(int)std::min<int64_t>((ns + 255) / 256, 4096), 256, 0, s>>>(c->d_rowptr, c->d_colidx, c->n_owned, A.br,
+                                                                                         ns, tf.as<int>());
+      std::vector<int> fl((size_t)ns);
+      PYN_HIP(hipMemcpyAsync(fl.data(), tf.p, ns * sizeof(int), hipMemcpyDeviceToHost, s));
+      PYN_HIP(hipStreamSynchronize(s));
+      int64_t i0 = 0, i1 = ns;
+      while (i0 < ns && fl[i0]) ++i0;
+      while (i1 > i0 && fl[i1 - 1]) --i1;
+      bool contiguous = i1 > i0;
+      for (int64_t i = i0; i < i1 && contiguous; ++i) contiguous = !fl[i];
+      if (contiguous) {
+        q.int_begin = i0;
+        q.int_end = i1;
+      }
+    }
     c->sell_shapes.push_back(q);
     S = &c->sell_shapes.back();
     fresh = true;
@@ -430,59 +461,77 @@ int pyn_sell_ensure(pyn_ctx* c, DMat& A) {
 bool pyn_sell_supported(const DMat& A) { return A.bc == 1 || A.bc == 2 || A.bc == 3 || A.bc == 6; }
 
 template <int BC>
-static int launch_block(pyn_ctx* c, const SellShape& S, const DMat& A, const double* x, double* y, bool dot, int grid) {
+static int launch_block(pyn_ctx* c, const SellShape& S, const DMat& A, const double* x, double* y, bool dot, int grid,
+                        int64_t s0, int64_t s1, int poff, hipStream_t st) {
   const int64_t n = c->n_owned * A.br;
   const size_t lds = (size_t)(c->sell_npat + 1) * PAT_W * sizeof(int32_t);
   const bool pat = c->sell_npat > 0;
   if (pat && dot)
-    sellb_spmv_kernel<BC, true, true><<<grid, 256, lds, c->stream>>>(S.ptr, S.w, c->sell_pid, c->sell_tab, c->sell_npat, nullptr,
-                                                                     A.sell_val, x, y, n, A.br, S.ns, c->d_flag, c->d_part);
+    sellb_spmv_kernel<BC, true, true><<<grid, 256, lds, st>>>(S.ptr, S.w, c->sell_pid, c->sell_tab, c->sell_npat, nullptr,
+                                                                     A.sell_val, x, y, n, A.br, s1, c->d_flag, c->d_part, s0, poff);
   else if (pat)
-    sellb_spmv_kernel<BC, true, false><<<grid, 256, lds, c->stream>>>(S.ptr, S.w, c->sell_pid, c->sell_tab, c->sell_npat, nullptr,
-                                                                      A.sell_val, x, y, n, A.br, S.ns, nullptr, nullptr);
+    sellb_spmv_kernel<BC, true, false><<<grid, 256, lds, st>>>(S.ptr, S.w, c->sell_pid, c->sell_tab, c->sell_npat, nullptr,
+                                                                      A.sell_val, x, y, n, A.br, s1, nullptr, nullptr, s0, poff);
   else if (dot)
-    sellb_spmv_kernel<BC, false, true><<<grid, 256, 0, c->stream>>>(S.ptr, S.w, nullptr, nullptr, 0, S.col, A.sell_val, x, y, n,
-                                                                    A.br, S.ns, c->d_flag, c->d_part);
+    sellb_spmv_kernel<BC, false, true><<<grid, 256, 0, st>>>(S.ptr, S.w, nullptr, nullptr, 0, S.col, A.sell_val, x, y, n,
+                                                                    A.br, s1, c->d_flag, c->d_part, s0, poff);
   else
-    sellb_spmv_kernel<BC, false, false><<<grid, 256, 0, c->stream>>>(S.ptr, S.w, nullptr, nullptr, 0, S.col, A.sell_val, x, y, n,
-                                                                     A.br, S.ns, nullptr, nullptr);
+    sellb_spmv_kernel<BC, false, false><<<grid, 256, 0, st>>>(S.ptr, S.w, nullptr, nullptr, 0, S.col, A.sell_val, x, y, n,
+                                                                     A.br, s1, nullptr, nullptr, s0, poff);
   return PYN_OK;
 }
 
-int pyn_sell_spmv(pyn_ctx* c, const DMat& A, const double* x, double* y, bool dot, int* grid_out) {
-  const SellShape* S = nullptr;
+const SellShape* pyn_sell_shape(pyn_ctx* c, const DMat& A) {
   for (auto& q : c->sell_shapes)
-    if (q.br == A.br && q.bc == A.bc) S = &q;
+    if (q.br == A.br && q.bc == A.bc) return &q;
+  return nullptr;
+}
+
+// y = A x over the slices [s0, s1) on stream `st`; the fused dot partials go to d_part[poff .. poff + grid)
+int pyn_sell_spmv_range(pyn_ctx* c, const DMat& A, const double* x, double* y, bool dot, int64_t s0, int64_t s1, int poff,
+                        int max_grid, hipStream_t st, int* grid_out) {
+  const SellShape* S = pyn_sell_shape(c, A);
   PYN_CHECK(S && A.sell_valid, "pyn_sell_ensure first");
   PYN_CHECK(!dot || A.br == A.bc, "fused dot needs a square block shape");
-  const int64_t ns = S->ns;
-  const int grid = (int)std::max<int64_t>(1, std::min<int64_t>((ns + 3) / 4, PYN_MAX_PARTIALS));
+  PYN_CHECK(s0 >= 0 && s1 <= S->ns && s0 <= s1, "bad slice range");
+  if (s0 == s1) {
+    if (grid_out) *grid_out = 0;
+    return PYN_OK;
+  }
+  const int grid = (int)std::max<int64_t>(1, std::min<int64_t>((s1 - s0 + 3) / 4, max_grid));
+  PYN_CHECK(poff + grid <= PYN_MAX_PARTIALS, "partial buffer overflow");
   if (A.br == 1 && A.bc == 1) {  // scalar fast paths
     if (c->sell_npat > 0) {
       const size_t lds = (size_t)(c->sell_npat + 1) * PAT_W * sizeof(int32_t);
       if (dot)
-        sellp_spmv_kernel<true><<<grid, 256, lds, c->stream>>>(S->ptr, S->w, c->sell_pid, c->sell_tab, c->sell_npat, A.sell_val, x, y,
-                                                               c->n_owned, ns, c->d_flag, c->d_part);
+        sellp_spmv_kernel<true><<<grid, 256, lds, st>>>(S->ptr, S->w, c->sell_pid, c->sell_tab, c->sell_npat, A.sell_val, x, y,
+                                                        c->n_owned, s1, c->d_flag, c->d_part, s0, poff);
       else
-        sellp_spmv_kernel<false><<<grid, 256, lds, c->stream>>>(S->ptr, S->w, c->sell_pid, c->sell_tab, c->sell_npat, A.sell_val, x,
-                                                                y, c->n_owned, ns, nullptr, nullptr);
+        sellp_spmv_kernel<false><<<grid, 256, lds, st>>>(S->ptr, S->w, c->sell_pid, c->sell_tab, c->sell_npat, A.sell_val, x, y,
+                                                         c->n_owned, s1, nullptr, nullptr, s0, poff);
     } else if (dot) {
-      sell_spmv_kernel<true><<<grid, 256, 0, c->stream>>>(S->ptr, S->w, S->col, A.sell_val, x, y, c->n_owned, ns, c->d_flag, c->d_part);
+      sell_spmv_kernel<true><<<grid, 256, 0, st>>>(S->ptr, S->w, S->col, A.sell_val, x, y, c->n_owned, s1, c->d_flag, c->d_part, s0, poff);
     } else {
-      sell_spmv_kernel<false><<<grid, 256, 0, c->stream>>>(S->ptr, S->w, S->col, A.sell_val, x, y, c->n_owned, ns, nullptr, nullptr);
+      sell_spmv_kernel<false><<<grid, 256, 0, st>>>(S->ptr, S->w, S->col, A.sell_val, x, y, c->n_owned, s1, nullptr, nullptr, s0, poff);
     }
   } else if (A.bc == 1) {
-    PYN_TRY(launch_block<1>(c, *S, A, x, y, dot, grid));
+    PYN_TRY(launch_block<1>(c, *S, A, x, y, dot, grid, s0, s1, poff, st));
   } else if (A.bc == 2) {
-    PYN_TRY(launch_block<2>(c, *S, A, x, y, dot, grid));
+    PYN_TRY(launch_block<2>(c, *S, A, x, y, dot, grid, s0, s1, poff, st));
   } else if (A.bc == 3) {
-    PYN_TRY(launch_block<3>(c, *S, A, x, y, dot, grid));
+    PYN_TRY(launch_block<3>(c, *S, A, x, y, dot, grid, s0, s1, poff, st));
   } else {
-    PYN_TRY(launch_block<6>(c, *S, A, x, y, dot, grid));
+    PYN_TRY(launch_block<6>(c, *S, A, x, y, dot, grid, s0, s1, poff, st));
   }
   PYN_HIP(hipGetLastError());
   if (grid_out) *grid_out = grid;
   return PYN_OK;
+}
+
+int pyn_sell_spmv(pyn_ctx* c, const DMat& A, const double* x, double* y, bool dot, int* grid_out) {
+  const SellShape* S = pyn_sell_shape(c, A);
+  PYN_CHECK(S, "pyn_sell_ensure first");
+  return pyn_sell_spmv_range(c, A, x, y, dot, 0, S->ns, 0, PYN_MAX_PARTIALS, c->stream, grid_out);
 }
 
 void pyn_sell_drop_structure(pyn_ctx* c) {
