@@ -469,21 +469,41 @@ struct LatTile {
   static constexpr size_t BYTES = ACC * sizeof(double) + META_INTS * sizeof(int);
 };
 
-__device__ __forceinline__ int lat_plane(const LatArgs& T, int j) { return T.std_lat ? j * T.nx * T.ny : T.P[j]; }
-
-// CSR offset of row (x, y, z) of a standard lattice: rows in id order, len = cx cy cz with c = 3 minus the faces
-// the node sits on; sum_{x' < x} cx(x') = 3x - (x > 0), sum over a whole line = 3 nx - 2.
-__device__ __forceinline__ int lat_rowptr_std(const LatArgs& T, int x, int y, int z) {
-  const int sx = 3 * T.nx - 2, sy = 3 * T.ny - 2;
-  const int cy = 3 - (y == 0) - (y == T.ny - 1), cz = 3 - (z == 0) - (z == T.npl - 1);
-  return (3 * z - (z > 0)) * sy * sx + cz * ((3 * y - (y > 0)) * sx + cy * (3 * x - (x > 0)));
+// First node id of z-plane j.  Arithmetic form (std_lat): the owned planes carry the ids 0 .. n_owned-1 in z
+// order, the ghost planes below them follow, then the ghost planes above (the numbering of a rank's z-slab; on one
+// rank simply j*nx*ny).  pyn_lattice_detect verified that the uploaded numbering has this shape.
+__device__ __forceinline__ int lat_plane(const LatArgs& T, int j) {
+  if (!T.std_lat) return T.P[j];
+  const int pp = T.nx * T.ny, lo = T.p_own0, hi = T.p_own0 + T.n_own;
+  if (j < lo) return (T.n_own + j) * pp;
+  if (j >= hi) return (T.n_own + lo + (j - hi)) * pp;
+  return (j - lo) * pp;
 }
 
+// CSR offset of the row of owned node (x, y, owned plane zo): rows in id order, len = cx cy cz with c = 3 minus
+// the domain faces the node sits on (a slab interface is not a face: its ghost plane supplies the columns);
+// sum_{x' < x} cx(x') = 3x - (x > 0), sum over a whole line = 3 nx - 2.  Verified against the graph's rowptr.
+__device__ __forceinline__ int lat_rowptr_std(const LatArgs& T, int x, int y, int zo) {
+  const int sx = 3 * T.nx - 2, sy = 3 * T.ny - 2;
+  const bool bot = T.p_own0 == 0, top = T.p_own0 + T.n_own == T.npl;   // does the slab hold the domain's end planes?
+  const int cy = 3 - (y == 0) - (y == T.ny - 1), cz = 3 - (bot && zo == 0) - (top && zo == T.n_own - 1);
+  return (3 * zo - (bot && zo > 0)) * sy * sx + cz * ((3 * y - (y > 0)) * sx + cy * (3 * x - (x > 0)));
+}
+
+// z-order code of OWNED plane pl: the existing z-neighbours sorted by node id -- owned planes first (ascending),
+// then the ghost plane below, then the ghost plane above
 __device__ __forceinline__ int lat_zcode(const LatArgs& T, int pl) {
   if (!T.std_lat) return T.zord[pl];
-  if (pl == 0) return 2 | (1 << 2) | (2 << 4);
-  if (pl == T.npl - 1) return 2 | (0 << 2) | (1 << 4);
-  return 3 | (0 << 2) | (1 << 4) | (2 << 6);
+  const int lo = T.p_own0, hi = T.p_own0 + T.n_own;
+  const bool has_dn = pl > 0, has_up = pl < T.npl - 1;
+  const bool dn_ghost = has_dn && pl - 1 < lo, up_ghost = has_up && pl + 1 >= hi;
+  int code = 0, n = 0;
+  if (has_dn && !dn_ghost) code |= 0 << (2 + 2 * n++);
+  code |= 1 << (2 + 2 * n++);
+  if (has_up && !up_ghost) code |= 2 << (2 + 2 * n++);
+  if (dn_ghost) code |= 0 << (2 + 2 * n++);
+  if (up_ghost) code |= 2 << (2 + 2 * n++);
+  return code | n;
 }
 
 // Row offsets and Dirichlet flags of a tile, in two steps so that their HBM latency hides behind the element
@@ -825,8 +845,8 @@ __global__ void mesh_all_affine_kernel(const int32_t* __restrict__ conn, const d
 __global__ void lattice_rowptr_check_kernel(LatArgs T, const int32_t* __restrict__ rowptr, int64_t n_rows, int* flag) {
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n_rows) return;
-  const int x = (int)(i % T.nx), y = (int)((i / T.nx) % T.ny), z = (int)(i / ((int64_t)T.nx * T.ny));
-  if (rowptr[i] != lat_rowptr_std(T, x, y, z)) *flag = 0;
+  const int x = (int)(i % T.nx), y = (int)((i / T.nx) % T.ny), zo = (int)(i / ((int64_t)T.nx * T.ny));
+  if (rowptr[i] != lat_rowptr_std(T, x, y, zo)) *flag = 0;
 }
 
 // one tile per workgroup
@@ -1716,7 +1736,15 @@ int pyn_lattice_detect(pyn_ctx* c, const int32_t* conn) {
   L.npl = (int)npl;
   L.p_own0 = p0;
   L.n_own = n_own;
-  L.std_shape = p0 == 0 && n_own == (int)npl;   // single rank: P[j] = j*nx*ny follows from the checks above
+  // does the numbering have the arithmetic shape lat_plane / lat_zcode assume (one rank, or a rank's z-slab)?
+  L.std_shape = true;
+  for (int64_t j = 0; j < npl && L.std_shape; ++j) {
+    int64_t want;
+    if (j < p0) want = (n_own + j) * nxny;
+    else if (j >= p0 + n_own) want = (n_own + p0 + (j - p0 - n_own)) * nxny;
+    else want = (j - p0) * nxny;
+    L.std_shape = P[j] == want;
+  }
   L.valid = true;
   return PYN_OK;
 }
