@@ -279,7 +279,8 @@ class FreeSlip(BaseProblem):
     def buildKLEMats(self):
         """base_problem.py:499-552 as one fused device pass: quadrature of every cell
         (spectral.py:89-157), scatter with Dirichlet elimination, unit diagonal (:549)."""
-        self.mat.assembleKLE(self.elemType, alpha_d=1e3, alpha_w=1e2)
+        # like the reference (locK, locRw, _ = getElemKLEMatrices, :529), the free-slip problem does not fill Rd
+        self.mat.assembleKLE(self.elemType, alpha_d=1e3, alpha_w=1e2, with_rd=False)
         self.mat.setIndices2One(self.mat.globalIndicesDIR)
         self.mat.assembleAll()
         if not self.comm.rank:

@@ -516,7 +516,7 @@ struct LatMeta {
   int r[NRW];
 };
 
-template <int TX, int TY, int TZ, int NT>
+template <int TX, int TY, int TZ, int NT, int NDOF = 1>
 __device__ __forceinline__ void lat_meta_load(const LatArgs& T, int x0, int y0, int z0, int t, LatMeta<TX, TY, TZ, NT>& M) {
   using L = LatTile<TX, TY, TZ>;
   const int nx = T.nx, ny = T.ny;
@@ -526,7 +526,13 @@ __device__ __forceinline__ void lat_meta_load(const LatArgs& T, int x0, int y0, 
     const int qx = i % L::BX, qy = (i / L::BX) % L::BY, qz = i / (L::BX * L::BY);
     const int x = x0 - 1 + qx, y = y0 - 1 + qy, pl = T.p_own0 + z0 - 1 + qz;
     const bool ok = T.bcmask && i < L::NB && x >= 0 && x < nx && y >= 0 && y < ny && pl >= 0 && pl < T.npl;
-    M.f[j] = ok ? T.bcmask[lat_plane(T, pl) + y * nx + x] : 0;
+    unsigned char f = 0;   // bit q: DOF q of the node imposed
+    if (ok) {
+      const int64_t node = lat_plane(T, pl) + y * nx + x;
+#pragma unroll
+      for (int q = 0; q < NDOF; ++q) f |= (T.bcmask[node * NDOF + q] ? 1 : 0) << q;
+    }
+    M.f[j] = f;
   }
 #pragma unroll
   for (int j = 0; j < LatMeta<TX, TY, TZ, NT>::NRW; ++j) {
@@ -546,7 +552,7 @@ __device__ __forceinline__ int lat_meta_commit(const LatArgs& T, int z0, int t, 
 #pragma unroll
   for (int j = 0; j < LatMeta<TX, TY, TZ, NT>::NF; ++j)
     if (t + j * NT < L::NB) {
-      nbc[t + j * NT] = M.f[j] ? 1 : 0;
+      nbc[t + j * NT] = M.f[j];
       any |= M.f[j];
     }
 #pragma unroll
@@ -1427,6 +1433,218 @@ __global__ void __launch_bounds__(KLE_AFF_THREADS, 3) assemble_q1_hex_kle_affine
   }
 }
 
+// ---- plan-free KLE assembly on lattices of parallelepipeds: the scalar lattice kernel's scheme (index
+// arithmetic, stencil-ordered LDS rows, straight x-line copies for interior tiles) with the four-wave closed-form
+// element blocks of assemble_q1_hex_kle_affine_kernel.  LDS row of a node = [p][27 stencil slots][q] = exactly the
+// node's block-CSR row when it has all 27 neighbours.
+struct KleLatArgs {
+  LatArgs L;              // A = K or Rw, Arhs = Krhs (K only, may be null); bcmask per DOF (3 per node)
+  double alpha_d, alpha_w;
+  const double *wr, *hrsr, *Hr, *hcoor;   // reduced (centroid) rule
+};
+
+template <int TX, int TY, int TZ, bool RW, int A0>
+__device__ __forceinline__ void kle_lat_rows(const KleLatArgs& T, const double (&Ji)[3][3], double det, int lx, int ly, int lz,
+                                             int z0, double* acc) {
+  constexpr int CX[8] = {0, 0, 1, 1, 0, 1, 1, 0};
+  constexpr int CY[8] = {0, 1, 1, 0, 0, 0, 1, 1};
+  constexpr int CZ[8] = {0, 0, 0, 0, 1, 1, 1, 1};
+  const double cr = T.wr[0] * det;
+  const double caw = cr * T.alpha_w, cad = cr * T.alpha_d;
+  const double* __restrict__ hr = T.hrsr;
+  double Gr[3][8];
+#pragma unroll
+  for (int d = 0; d < 3; ++d)
+#pragma unroll
+    for (int a = 0; a < 8; ++a) Gr[d][a] = fma(Ji[d][2], hr[16 + a], fma(Ji[d][1], hr[8 + a], Ji[d][0] * hr[a]));
+  double D[3][3], M2[3][2], DM[3][3][3];
+  if (!RW) {
+    constexpr int RS[6][2] = {{0, 0}, {1, 1}, {2, 2}, {0, 1}, {0, 2}, {1, 2}};
+#pragma unroll
+    for (int u = 0; u < 3; ++u) {
+      const int a0 = RS[u][0], a1 = RS[3 + u][0], b1 = RS[3 + u][1];
+      const double qd = det * (Ji[0][a0] * Ji[0][a0] + Ji[1][a0] * Ji[1][a0] + Ji[2][a0] * Ji[2][a0]) * (1.0 / 72.0);
+      const double qm = det * (Ji[0][a1] * Ji[0][b1] + Ji[1][a1] * Ji[1][b1] + Ji[2][a1] * Ji[2][b1]) * (1.0 / 72.0);
+      D[u][0] = 4.0 * qd, D[u][1] = 8.0 * qd, D[u][2] = 16.0 * qd;
+      M2[u][0] = 12.0 * qm, M2[u][1] = 24.0 * qm;
+    }
+  } else {
+#pragma unroll
+    for (int m = 0; m < 3; ++m)
+#pragma unroll
+      for (int d = 0; d < 3; ++d) {
+        const double x = det * Ji[m][d] * (1.0 / 72.0);
+        DM[m][d][0] = 4.0 * x, DM[m][d][1] = 8.0 * x, DM[m][d][2] = 16.0 * x;
+      }
+  }
+#pragma unroll
+  for (int h = 0; h < 2; ++h) {
+    const int a = A0 + h;
+    const int rx = lx - 1 + CX[a], ry = ly - 1 + CY[a], rz = lz - 1 + CZ[a];
+    if (rx < 0 || rx >= TX || ry < 0 || ry >= TY || rz < 0 || rz >= TZ || z0 + rz >= T.L.n_own) continue;
+    double* rowp = acc + ((rz * TY + ry) * TX + rx) * 243;
+#pragma unroll
+    for (int b = 0; b < 8; ++b) {
+      const int kk = (CZ[b] - CZ[a] + 1) * 9 + (CY[b] - CY[a] + 1) * 3 + (CX[b] - CX[a] + 1);
+      if (!RW) {
+        double lab = 0.0;
+#pragma unroll
+        for (int u = 0; u < 6; ++u) {
+          const int n = q1_aff_int(u, a, b);
+          const int an = n < 0 ? -n : n;
+          if (an == 0) continue;
+          const double x = u < 3 ? D[u][an == 4 ? 0 : (an == 8 ? 1 : 2)] : M2[u - 3][an == 12 ? 0 : 1];
+          lab = n > 0 ? lab + x : lab - x;
+        }
+        const double s_ab = Gr[0][a] * Gr[0][b] + Gr[1][a] * Gr[1][b] + Gr[2][a] * Gr[2][b];
+        const double diag = lab + caw * s_ab;
+#pragma unroll
+        for (int pp = 0; pp < 3; ++pp)
+#pragma unroll
+          for (int q = 0; q < 3; ++q) {
+            double v = cad * Gr[pp][a] * Gr[q][b] - caw * Gr[q][a] * Gr[pp][b];
+            if (pp == q) v += diag;
+            atomicAdd(&rowp[(pp * 27 + kk) * 3 + q], v);
+          }
+      } else {
+        const double hb = T.Hr[b];
+#pragma unroll
+        for (int m = 0; m < 3; ++m) {
+          double tv = 0.0;
+#pragma unroll
+          for (int d = 0; d < 3; ++d) {
+            const int n = q1_mix_int(d, a, b);
+            const int an = n < 0 ? -n : n;
+            const double x = DM[m][d][an == 4 ? 0 : (an == 8 ? 1 : 2)];
+            tv = n > 0 ? tv + x : tv - x;
+          }
+          const double wv = tv - caw * Gr[m][a] * hb;
+          const int P1 = (m + 1) % 3, P2 = (m + 2) % 3;
+          atomicAdd(&rowp[(P2 * 27 + kk) * 3 + P1], wv);
+          atomicAdd(&rowp[(P1 * 27 + kk) * 3 + P2], -wv);
+        }
+      }
+    }
+  }
+}
+
+template <int TX, int TY, int TZ, bool RW>
+__global__ void __launch_bounds__(256, 3) assemble_q1_hex_kle_lattice_kernel(KleLatArgs T) {
+  using LT = LatTile<TX, TY, TZ>;
+  constexpr int ROW = 243, ACC = LT::NR * ROW;
+  extern __shared__ __align__(16) double lds[];
+  double* acc = lds;
+  int* rlo = reinterpret_cast<int*>(acc + ACC);
+  int* zrd = rlo + LT::NR;
+  unsigned char* nbc = reinterpret_cast<unsigned char*>(zrd + TZ);
+  const LatArgs& L = T.L;
+  const int tid = threadIdx.x, lane = tid & 63, part = tid >> 6;
+  const int b = blockIdx.x;
+  const int bx = b % L.ntx, by = (b / L.ntx) % L.nty, bz = b / (L.ntx * L.nty);
+  const int x0 = bx * TX, y0 = by * TY, z0 = bz * TZ;
+  const int nx = L.nx, ny = L.ny;
+  LatMeta<TX, TY, TZ, 256> meta;
+  lat_meta_load<TX, TY, TZ, 256, 3>(L, x0, y0, z0, tid, meta);
+  for (int i = tid; i < ACC; i += 256) acc[i] = 0.0;
+  __syncthreads();
+
+  const double* __restrict__ S = L.q.aff + 248;
+  for (int t = lane; t < LT::NE && L.ablate != 1; t += 64) {
+    const int lx = t % LT::EX, ly = (t / LT::EX) % LT::EY, lz = t / (LT::EX * LT::EY);
+    const int gx = x0 - 1 + lx, gy = y0 - 1 + ly, gl = L.p_own0 + z0 - 1 + lz;
+    if (gx < 0 || gx >= nx - 1 || gy < 0 || gy >= ny - 1 || gl < 0 || gl >= L.npl - 1) continue;
+    const int n00 = gy * nx + gx;
+    const double* q0 = L.xyz + (int64_t)(lat_plane(L, gl) + n00) * 3;
+    const double* qz = L.xyz + (int64_t)(lat_plane(L, gl + 1) + n00) * 3;
+    double E[3][3];
+#pragma unroll
+    for (int x = 0; x < 3; ++x) {
+      const double o = q0[x];
+      E[0][x] = q0[3 + x] - o;
+      E[1][x] = q0[3 * nx + x] - o;
+      E[2][x] = qz[x] - o;
+    }
+    double J[3][3];
+#pragma unroll
+    for (int d = 0; d < 3; ++d)
+#pragma unroll
+      for (int x = 0; x < 3; ++x) J[d][x] = fma(S[d * 3 + 2], E[2][x], fma(S[d * 3 + 1], E[1][x], S[d * 3] * E[0][x]));
+    const double c00 = J[1][1] * J[2][2] - J[1][2] * J[2][1];
+    const double c01 = J[1][2] * J[2][0] - J[1][0] * J[2][2];
+    const double c02 = J[1][0] * J[2][1] - J[1][1] * J[2][0];
+    const double det = J[0][0] * c00 + J[0][1] * c01 + J[0][2] * c02;
+    const double r = 1.0 / det;
+    double Ji[3][3];
+    Ji[0][0] = c00 * r;
+    Ji[0][1] = (J[0][2] * J[2][1] - J[0][1] * J[2][2]) * r;
+    Ji[0][2] = (J[0][1] * J[1][2] - J[0][2] * J[1][1]) * r;
+    Ji[1][0] = c01 * r;
+    Ji[1][1] = (J[0][0] * J[2][2] - J[0][2] * J[2][0]) * r;
+    Ji[1][2] = (J[0][2] * J[1][0] - J[0][0] * J[1][2]) * r;
+    Ji[2][0] = c02 * r;
+    Ji[2][1] = (J[0][1] * J[2][0] - J[0][0] * J[2][1]) * r;
+    Ji[2][2] = (J[0][0] * J[1][1] - J[0][1] * J[1][0]) * r;
+    switch (part) {   // wave-uniform: wave w adds the node rows {2w, 2w+1} of every element
+      case 0: kle_lat_rows<TX, TY, TZ, RW, 0>(T, Ji, det, lx, ly, lz, z0, acc); break;
+      case 1: kle_lat_rows<TX, TY, TZ, RW, 2>(T, Ji, det, lx, ly, lz, z0, acc); break;
+      case 2: kle_lat_rows<TX, TY, TZ, RW, 4>(T, Ji, det, lx, ly, lz, z0, acc); break;
+      default: kle_lat_rows<TX, TY, TZ, RW, 6>(T, Ji, det, lx, ly, lz, z0, acc); break;
+    }
+  }
+  const int anybc = __syncthreads_or(lat_meta_commit<TX, TY, TZ, 256>(L, z0, tid, meta, rlo, zrd, nbc));
+
+  double* __restrict__ outA = L.A;
+  double* __restrict__ outR = L.Arhs;
+  if (lat_tile_plain<TX, TY, TZ>(L, x0, y0, z0, zrd, anybc)) {
+    // interior tile: the TX node rows of an x-line are one contiguous run of TX*243 doubles here and in HBM
+    constexpr int LINE = TX * ROW, NL = TY * TZ;
+    for (int l = part; l < NL; l += 4) {
+      const int64_t base = (int64_t)rlo[l * TX] * 9;
+      for (int i = lane; i < LINE; i += 64) {
+        outA[base + i] = acc[l * LINE + i];
+        if (!RW && outR) outR[base + i] = 0.0;
+      }
+    }
+    return;
+  }
+  // boundary tile: one wave per scalar row (node row s, component p), CSR slot -> stencil position as in lat_store
+  for (int sr = part; sr < LT::NR * 3; sr += 4) {
+    const int s = sr / 3, pp = sr - s * 3;
+    const int rl = rlo[s];
+    if (rl < 0) continue;
+    const int rx = s % TX, ry = (s / TX) % TY, rz = s / (TX * TY);
+    const int x = x0 + rx, y = y0 + ry;
+    const int zi = zrd[rz];
+    const int cx = 3 - (x == 0) - (x == nx - 1), cy = 3 - (y == 0) - (y == ny - 1), cz = zi & 3;
+    const int cc = cx * cy, len = cc * cz;
+    const int bi = ((rz + 1) * LT::BY + ry + 1) * LT::BX + rx + 1;
+    const bool rowbc = (nbc[bi] >> pp) & 1;
+    const int64_t gbase = ((int64_t)rl * 3 + (int64_t)pp * len) * 3;
+    for (int idx = lane; idx < len * 3; idx += 64) {
+      const int k = idx / 3, q = idx - k * 3;
+      const int kz = (k >= cc) + (k >= 2 * cc);
+      const int rr = k - kz * cc;
+      const int ky = (rr >= cx) + (rr >= 2 * cx);
+      const int kx = rr - ky * cx;
+      const int dz = ((zi >> (2 + 2 * kz)) & 3) - 1;
+      const int dy = ky - (y != 0), dx = kx - (x != 0);
+      const double v = acc[s * ROW + (pp * 27 + (dz + 1) * 9 + (dy + 1) * 3 + (dx + 1)) * 3 + q];
+      double va, vr;
+      if (rowbc) {
+        va = vr = (!RW && q == pp && dx == 0 && dy == 0 && dz == 0) ? 1.0 : 0.0;
+      } else if (!RW && ((nbc[bi + (dz * LT::BY + dy) * LT::BX + dx] >> q) & 1)) {
+        va = 0.0;
+        vr = -v;
+      } else {
+        va = v;
+        vr = 0.0;
+      }
+      outA[gbase + idx] = va;
+      if (!RW && outR) outR[gbase + idx] = vr;
+    }
+  }
+}
+
 __global__ void colbc_kernel(const int32_t* __restrict__ colidx, const uint8_t* __restrict__ bcmask, int64_t nnz,
                              uint8_t* __restrict__ colbc) {
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < nnz; i += (int64_t)gridDim.x * blockDim.x)
@@ -1772,10 +1990,9 @@ static int launch_lattice(pyn_ctx* c, LatArgs& T, bool affine) {
   return PYN_OK;
 }
 
-static int assemble_lattice(pyn_ctx* c, double* A, double* Arhs, bool* handled) {
+// lattice descriptor -> kernel arguments (+ the one-off verification that index arithmetic may replace the loads)
+static int lat_fill_args(pyn_ctx* c, LatArgs& T, double* A, double* Arhs, int* mesh_aff) {
   Lattice& L = c->lat;
-  if (!L.valid || c->quad[0].ngp != 8) return PYN_OK;
-  LatArgs T;
   T.xyz = c->d_xyz;
   T.rowptr = c->d_rowptr;
   T.bcmask = c->d_bcmask;
@@ -1797,8 +2014,7 @@ static int assemble_lattice(pyn_ctx* c, double* A, double* Arhs, bool* handled) 
   T.Arhs = Arhs;
   const char* ab = getenv("PYNAMA_LATTICE_ABLATE");  // diagnostics: 1 = no element phase, 4 = no plain-tile store path
   T.ablate = ab ? atoi(ab) : 0;
-  int mesh_aff = 0;
-  PYN_TRY(mesh_all_affine(c, &mesh_aff));
+  PYN_TRY(mesh_all_affine(c, mesh_aff));
   if (L.std_ok < 0) {      // once per graph: may the index arithmetic replace P / zord / rowptr?
     L.std_ok = 0;
     if (L.std_shape && !getenv("PYNAMA_NO_STD_LATTICE")) {
@@ -1816,6 +2032,70 @@ static int assemble_lattice(pyn_ctx* c, double* A, double* Arhs, bool* handled) 
     }
   }
   T.std_lat = L.std_ok == 1;
+  return PYN_OK;
+}
+
+template <int TX, int TY, int TZ>
+static int launch_kle_lattice(pyn_ctx* c, KleLatArgs& T, double* K, double* Krhs, double* Rw) {
+  using LT = LatTile<TX, TY, TZ>;
+  T.L.ntx = (T.L.nx + TX - 1) / TX;
+  T.L.nty = (T.L.ny + TY - 1) / TY;
+  const int n_tiles = T.L.ntx * T.L.nty * ((T.L.n_own + TZ - 1) / TZ);
+  const size_t lds = (size_t)LT::NR * 243 * sizeof(double) + LT::META_INTS * sizeof(int);
+  static bool attr_done = false;
+  if (!attr_done) {
+    PYN_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(assemble_q1_hex_kle_lattice_kernel<TX, TY, TZ, false>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    PYN_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(assemble_q1_hex_kle_lattice_kernel<TX, TY, TZ, true>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    attr_done = true;
+  }
+  if (K) {
+    T.L.A = K;
+    T.L.Arhs = Krhs;
+    assemble_q1_hex_kle_lattice_kernel<TX, TY, TZ, false><<<n_tiles, 256, lds, c->stream>>>(T);
+  }
+  if (Rw) {
+    T.L.A = Rw;
+    T.L.Arhs = nullptr;
+    assemble_q1_hex_kle_lattice_kernel<TX, TY, TZ, true><<<n_tiles, 256, lds, c->stream>>>(T);
+  }
+  PYN_HIP(hipGetLastError());
+  return PYN_OK;
+}
+
+// KLE on lattices of parallelepipeds (the reference's box meshes): plan-free kernels
+static int assemble_kle_lattice(pyn_ctx* c, double alpha_d, double alpha_w, double* K, double* Krhs, double* Rw, bool* handled) {
+  if (!c->lat.valid || c->quad[0].ngp != 8 || c->quad[1].ngp != 1 || !c->aff_standard || !c->aff_rw_standard ||
+      getenv("PYNAMA_NO_AFFINE") || getenv("PYNAMA_NO_KLE_LATTICE"))
+    return PYN_OK;
+  KleLatArgs T;
+  int mesh_aff = 0;
+  PYN_TRY(lat_fill_args(c, T.L, nullptr, nullptr, &mesh_aff));
+  if (!mesh_aff) return PYN_OK;   // general geometry: the patch-plan kernels with quadrature
+  T.alpha_d = alpha_d;
+  T.alpha_w = alpha_w;
+  T.wr = c->quad[1].w;
+  T.hrsr = c->quad[1].Hrs;
+  T.Hr = c->quad[1].H;
+  T.hcoor = c->quad[1].HrsCoo;
+  const char* tl = getenv("PYNAMA_KLE_LATTICE_TILE");
+  switch (tl ? atoi(tl) : 0) {
+    case 1: PYN_TRY((launch_kle_lattice<6, 2, 2>(c, T, K, Krhs, Rw))); break;
+    case 2: PYN_TRY((launch_kle_lattice<3, 3, 2>(c, T, K, Krhs, Rw))); break;
+    case 3: PYN_TRY((launch_kle_lattice<4, 3, 3>(c, T, K, Krhs, Rw))); break;
+    default: PYN_TRY((launch_kle_lattice<3, 3, 3>(c, T, K, Krhs, Rw))); break;
+  }
+  *handled = true;
+  return PYN_OK;
+}
+
+static int assemble_lattice(pyn_ctx* c, double* A, double* Arhs, bool* handled) {
+  Lattice& L = c->lat;
+  if (!L.valid || c->quad[0].ngp != 8) return PYN_OK;
+  LatArgs T;
+  int mesh_aff = 0;
+  PYN_TRY(lat_fill_args(c, T, A, Arhs, &mesh_aff));
   const bool affine = mesh_aff == 1 && T.q.aff != nullptr && c->aff_standard;
   // measured at 10M DOFs: parallelepipeds are store-bound -> small tiles, 5 workgroups per CU;
   // the quadrature path is FP64-bound -> 7x7x7 tiles (least redundant integration that fits the LDS twice)
@@ -1839,14 +2119,33 @@ static int assemble_lattice(pyn_ctx* c, double* A, double* Arhs, bool* handled) 
 
 static int ensure_default_plan(pyn_ctx* c, int kind) {
   if (c->plan[kind].npatch || c->dim != 3 || c->nn != 8 || getenv("PYNAMA_NO_AUTO_PLAN")) return PYN_OK;
-  const int chunk = kind == 0 ? 343 : 27;
   const int64_t n = c->n_owned;
-  const int np = (int)((n + chunk - 1) / chunk);
-  std::vector<int32_t> ptr((size_t)np + 1), rows((size_t)n);
-  for (int p = 0; p <= np; ++p) ptr[p] = (int32_t)std::min<int64_t>((int64_t)p * chunk, n);
-  for (int64_t i = 0; i < n; ++i) rows[i] = (int32_t)i;
+  std::vector<int32_t> ptr, rows((size_t)n);
+  if (c->lat.valid) {
+    // structured topology: node tiles (7x7x7 for the scalar kernel, 3x3x3 for the 3x3-block kernels)
+    const int t = kind == 0 ? 7 : 3;
+    const Lattice& L = c->lat;
+    const int64_t nxny = (int64_t)L.nx * L.ny;
+    int64_t pos = 0;
+    ptr.push_back(0);
+    for (int z0 = 0; z0 < L.n_own; z0 += t)
+      for (int y0 = 0; y0 < L.ny; y0 += t)
+        for (int x0 = 0; x0 < L.nx; x0 += t) {
+          for (int z = z0; z < std::min(z0 + t, L.n_own); ++z)
+            for (int y = y0; y < std::min(y0 + t, L.ny); ++y)
+              for (int x = x0; x < std::min(x0 + t, L.nx); ++x) rows[pos++] = (int32_t)(z * nxny + (int64_t)y * L.nx + x);
+          ptr.push_back((int32_t)pos);
+        }
+  } else {
+    // any other numbering: consecutive-row chunks
+    const int chunk = kind == 0 ? 343 : 27;
+    const int np = (int)((n + chunk - 1) / chunk);
+    ptr.resize((size_t)np + 1);
+    for (int p = 0; p <= np; ++p) ptr[p] = (int32_t)std::min<int64_t>((int64_t)p * chunk, n);
+    for (int64_t i = 0; i < n; ++i) rows[i] = (int32_t)i;
+  }
   g_default_plan = true;
-  const int rc = pyn_patch_plan_set_kind(c, kind, np, ptr.data(), rows.data());
+  const int rc = pyn_patch_plan_set_kind(c, kind, (int)ptr.size() - 1, ptr.data(), rows.data());
   g_default_plan = false;
   return rc;
 }
@@ -1855,6 +2154,10 @@ int pyn_assemble_q1_tiled(pyn_ctx* c, int form, double alpha_d, double alpha_w, 
   *handled = false;
   if (form == PYN_FORM_LAPLACE && K && !Rw && !Rd && c->lat.valid && !c->plan[0].user) {
     PYN_TRY(assemble_lattice(c, K, Krhs, handled));
+    if (*handled) return PYN_OK;
+  }
+  if (form == PYN_FORM_KLE && K && !Rd && !c->plan[1].user) {
+    PYN_TRY(assemble_kle_lattice(c, alpha_d, alpha_w, K, Krhs, Rw, handled));
     if (*handled) return PYN_OK;
   }
   if (form == PYN_FORM_KLE && K && !Rd) PYN_TRY(ensure_default_plan(c, 1));

@@ -156,10 +156,7 @@ class Mat:
         for t in elem.deviceTables():
             self.ctx.tables_set(*t)
         self.ctx.bc_set(self.dim, self.dom.dirichletMaskLocal(self.dim))
-        if self.dim == 3 and elem.nnode == 8 and variant != 0 and not getattr(self, "_kle_plan", False):
-            # patch plan of the tiled (atomics-free) KLE kernels: 3x3x3 node tiles (fastest measured)
-            self.ctx.patch_plan_set(*self.dom.patchPlan((3, 3, 3)), kind=1)
-            self._kle_plan = True
+        # (the library picks the kernel: plan-free on lattices of parallelepipeds, 3x3x3-node patch plans otherwise)
         self.ctx.assemble_kle(alpha_d, alpha_w, self.K.id, self.Krhs.id, self.Rw.id,
                               self.Rd.id if with_rd else -1, variant)
 

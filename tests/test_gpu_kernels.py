@@ -801,3 +801,99 @@ def test_rccl_overlapped_halo_in_cg(lib):
         gn = r @ u; delta = w @ u
         beta = gn / gamma; alpha = gn / (delta - beta * gn / alpha); gamma = gn
     assert rel_err(out["overlap"][1], x) < 1e-9
+
+
+# ---- plan-free KLE kernels on lattices of parallelepipeds ------------------------------------------
+@pytest.mark.parametrize("tile", [0, 1, 2, 3])
+@pytest.mark.parametrize("kind", ["uniform", "sheared", "partial_bc", "nobc", "interior_bc"])
+def test_assemble_kle_lattice_kernel(lib, tile, kind):
+    """box meshes of parallelepipeds are assembled by the plan-free KLE kernels (K, Krhs, Rw): every tile shape,
+    ragged domain sizes, full / per-component / no / interior Dirichlet masks, K without Krhs.  All equal the
+    oracle (whose blocks come from the reference-pinned formulas)."""
+    import os
+    import scipy.sparse as sps
+    mesh = fo.box_mesh([7, 5, 8], [0, 0, 0], [1.0, 0.9, 1.1], 2)
+    if kind == "sheared":
+        M = np.array([[1.0, 0.3, -0.2], [0.1, 0.9, 0.25], [-0.15, 0.2, 1.1]])
+        mesh.xyz = mesh.xyz @ M.T + np.array([0.5, -1.0, 2.0])
+    mask = np.zeros((mesh.n_node, 3), np.uint8)
+    if kind in ("uniform", "sheared"):
+        mask[mesh.boundary] = 1
+    elif kind == "partial_bc":                       # only the normal component on each border
+        for name, (d, _) in {"back": (2, 0), "front": (2, 1), "down": (1, 0), "up": (1, 1), "right": (0, 1), "left": (0, 0)}.items():
+            mask[mesh.borders[name], d] = 1
+    elif kind == "interior_bc":
+        rng = np.random.default_rng(3)
+        mask[rng.choice(mesh.n_node, size=mesh.n_node // 6, replace=False), rng.integers(0, 3, size=mesh.n_node // 6)] = 1
+    os.environ["PYNAMA_KLE_LATTICE_TILE"] = str(tile)
+    try:
+        from pynama_amd.elements.spectral import Spectral
+        ctx = lib.Context(0)
+        ctx.mesh_set(3, mesh.conn, mesh.xyz)
+        for t in Spectral(2, 3).deviceTables():
+            ctx.tables_set(*t)
+        if kind != "nobc":
+            ctx.bc_set(3, mask)
+        ctx.csr_symbolic()
+        assert ctx.mesh_topology()[0] == "lattice"
+        K, Krhs, Rw = ctx.mat_create(3, 3), ctx.mat_create(3, 3), ctx.mat_create(3, 3)
+        ctx.assemble_kle(1e3, 1e2, K, Krhs, Rw, -1)
+        K2 = ctx.mat_create(3, 3)
+        ctx.assemble_kle(1e3, 1e2, K2, -1, -1, -1)
+        tb = fo.Tables(2, 3)
+        Ke, Rwe, _ = fo.elem_kle_matrices(tb, mesh.corners())
+        vdof = fo.dof_indices(mesh.conn, 3)
+        is_bc = mask.ravel().astype(bool)
+        n3 = mesh.n_node * 3
+        rfree, cbc = ~is_bc[vdof], is_bc[vdof]
+        R = np.broadcast_to(vdof[:, :, None], Ke.shape)
+        C = np.broadcast_to(vdof[:, None, :], Ke.shape)
+        mff = rfree[:, :, None] & rfree[:, None, :]
+        mfb = rfree[:, :, None] & cbc[:, None, :]
+        ident = sps.coo_matrix((np.ones(is_bc.sum()), (np.nonzero(is_bc)[0], np.nonzero(is_bc)[0])), shape=(n3, n3)).tocsr()
+        Kref = (sps.coo_matrix((Ke[mff], (R[mff], C[mff])), shape=(n3, n3)).tocsr() + ident).tocsr()
+        Krref = (sps.coo_matrix((-Ke[mfb], (R[mfb], C[mfb])), shape=(n3, n3)).tocsr() + ident).tocsr()
+        mrow = np.broadcast_to(rfree[:, :, None], Rwe.shape)
+        Rwref = sps.coo_matrix((Rwe[mrow], (R[mrow], C[mrow])), shape=(n3, n3)).tocsr()
+        assert sp_rel_err(mat_to_scipy(ctx, K, 3, 3), Kref) < FP_TOL
+        assert sp_rel_err(mat_to_scipy(ctx, K2, 3, 3), Kref) < FP_TOL
+        assert sp_rel_err(mat_to_scipy(ctx, Krhs, 3, 3), Krref) < FP_TOL
+        assert sp_rel_err(mat_to_scipy(ctx, Rw, 3, 3), Rwref) < FP_TOL
+        # and the patch-plan kernels (explicit plan) give the same matrices
+        ctx.patch_plan_set(*tile_plan(mesh, (3, 3, 3)), kind=1)
+        K3, Rw3 = ctx.mat_create(3, 3), ctx.mat_create(3, 3)
+        ctx.assemble_kle(1e3, 1e2, K3, -1, Rw3, -1)
+        assert sp_rel_err(mat_to_scipy(ctx, K3, 3, 3), Kref) < FP_TOL
+        assert sp_rel_err(mat_to_scipy(ctx, Rw3, 3, 3), Rwref) < FP_TOL
+        ctx.close()
+    finally:
+        del os.environ["PYNAMA_KLE_LATTICE_TILE"]
+
+
+@pytest.mark.parametrize("size", [2, 3])
+def test_kle_lattice_kernel_on_rank_slabs(lib, size):
+    from pynama_amd.common.comm import Comm
+    from pynama_amd.domain.dmplex import DMPlexDom
+    from pynama_amd.elements.spectral import Spectral
+    nelem = [5, 4, 9]
+    glob = fo.box_mesh(nelem, [0, 0, 0], [1, 1, 1], 2)
+    ref = fo.assemble_kle_freeslip(glob, fo.Tables(2, 3))
+    for r in range(size):
+        dom = DMPlexDom(boxMesh={'nelem': nelem, 'lower': [0, 0, 0], 'upper': [1, 1, 1]}, comm=Comm(r, size))
+        dom.setFemIndexing(2)
+        ctx = lib.Context(0)
+        ctx.comm_init(r, size, None)
+        ctx.halo_set(*dom._halo_plan())
+        ctx.mesh_set(3, dom.conn, dom.xyz)
+        for t in Spectral(2, 3).deviceTables():
+            ctx.tables_set(*t)
+        ctx.bc_set(3, np.repeat(dom.boundaryMaskLocal()[:, None], 3, axis=1))
+        ctx.csr_symbolic()
+        K, Kr, Rw = ctx.mat_create(3, 3), ctx.mat_create(3, 3), ctx.mat_create(3, 3)
+        ctx.assemble_kle(1e3, 1e2, K, Kr, Rw, -1)
+        cols = dom._local2global(np.arange(dom.nLocal))
+        rows3 = (np.arange(dom.rStart, dom.rEnd)[:, None] * 3 + np.arange(3)).ravel()
+        cols3 = (cols[:, None] * 3 + np.arange(3)).ravel()
+        for mid, name in ((K, "K"), (Kr, "Krhs"), (Rw, "Rw")):
+            assert sp_rel_err(mat_to_scipy(ctx, mid, 3, 3), ref[name][rows3][:, cols3]) < FP_TOL, name
+        ctx.close()

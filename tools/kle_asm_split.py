@@ -14,8 +14,10 @@ for t in Spectral(2, 3).deviceTables():
 bm = dom.boundaryMaskLocal()
 ctx.bc_set(3, np.repeat(bm[:, None], 3, axis=1))
 ctx.csr_symbolic()
-tile = tuple(int(v) for v in os.environ.get("PYNAMA_KLE_TILE", "3,3,3").split(","))
-ctx.patch_plan_set(*dom.patchPlan(tile), kind=1)
+tile = os.environ.get("PYNAMA_KLE_TILE")       # explicit patch plan -> patch-plan kernels; default: the library's choice
+if tile:
+    tile = tuple(int(v) for v in tile.split(","))
+    ctx.patch_plan_set(*dom.patchPlan(tile), kind=1)
 K, Krhs, Rw = ctx.mat_create(3, 3), ctx.mat_create(3, 3), ctx.mat_create(3, 3)
 for name, args in (("K only", (K, -1, -1)), ("K+Krhs", (K, Krhs, -1)), ("K+Krhs+Rw", (K, Krhs, Rw))):
     for _ in range(2):

@@ -25,8 +25,8 @@ t0 = time.time()
 ctx.csr_symbolic()
 print("symbolic ms", ctx.timers()["symbolic_ms"])
 K, Krhs, Rw = ctx.mat_create(3, 3), ctx.mat_create(3, 3), ctx.mat_create(3, 3)
-if os.environ.get("PYNAMA_VARIANT", "1") == "1":
-    tile = tuple(int(v) for v in os.environ.get("PYNAMA_KLE_TILE", "3,3,3").split(","))
+if os.environ.get("PYNAMA_KLE_TILE"):       # explicit patch plan -> patch-plan kernels; default: the library's choice
+    tile = tuple(int(v) for v in os.environ["PYNAMA_KLE_TILE"].split(","))
     ctx.patch_plan_set(*dom.patchPlan(tile), kind=1)
 for _ in range(2):
     ctx.assemble_kle(1e3, 1e2, K, Krhs, Rw, -1, variant=int(os.environ.get('PYNAMA_VARIANT', '1')))
