@@ -706,17 +706,83 @@ static int solve_cg_sr(pyn_ctx* c, DMat& A, const double* b, double* x, const py
   return PYN_OK;
 }
 
-// Left-preconditioned restarted GMRES(m), modified Gram-Schmidt, Givens rotations on the host.
+
+// ---- fused classical Gram-Schmidt for GMRES: all k+1 projections in ONE pass over the basis -----------------
+// h[j] = V_j . w for j < k1 (partials per block, chunks of 8 vectors so the accumulators stay in registers)
+constexpr int MD_GRID = 512;
+__global__ void __launch_bounds__(256) multi_dot_kernel(const double* __restrict__ V, int64_t ld, int k1,
+                                                        const double* __restrict__ w, int64_t n, double* __restrict__ part) {
+  __shared__ double sm[4];
+  for (int c0 = 0; c0 < k1; c0 += 8) {
+    double acc[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) acc[j] = 0.0;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+      const double wi = w[i];
+#pragma unroll
+      for (int j = 0; j < 8; ++j)
+        if (c0 + j < k1) acc[j] = fma(V[(int64_t)(c0 + j) * ld + i], wi, acc[j]);
+    }
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      if (c0 + j >= k1) break;
+      const double v = wsum(acc[j]);
+      __syncthreads();
+      if ((threadIdx.x & 63) == 0) sm[threadIdx.x >> 6] = v;
+      __syncthreads();
+      if (threadIdx.x == 0) part[(int64_t)(c0 + j) * MD_GRID + blockIdx.x] = sm[0] + sm[1] + sm[2] + sm[3];
+    }
+  }
+}
+
+__global__ void __launch_bounds__(256) multi_finish_kernel(const double* __restrict__ part, int nblocks, double* __restrict__ out) {
+  __shared__ double sm[4];
+  double acc = 0.0;
+  for (int i = threadIdx.x; i < nblocks; i += 256) acc += part[(int64_t)blockIdx.x * MD_GRID + i];
+  acc = wsum(acc);
+  if ((threadIdx.x & 63) == 0) sm[threadIdx.x >> 6] = acc;
+  __syncthreads();
+  if (threadIdx.x == 0) out[blockIdx.x] = sm[0] + sm[1] + sm[2] + sm[3];
+}
+
+// w -= sum_j h[j] V_j  (h on the device: no host round trip between the projection and the update)
+__global__ void __launch_bounds__(256) multi_axpy_kernel(double* __restrict__ w, const double* __restrict__ V, int64_t ld, int k1,
+                                                         const double* __restrict__ h, int64_t n) {
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+    double acc = w[i];
+    for (int j = 0; j < k1; ++j) acc = fma(-h[j], V[(int64_t)j * ld + i], acc);
+    w[i] = acc;
+  }
+}
+
+// v *= 1/sqrt(hn[0]) (hn = v.v on the device); nothing if the norm vanished (happy breakdown)
+__global__ void __launch_bounds__(256) scale_rsqrt_kernel(double* __restrict__ v, const double* __restrict__ hn, int64_t n) {
+  const double q = hn[0];
+  if (!(q > 0.0)) return;
+  const double r = 1.0 / sqrt(q);
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) v[i] *= r;
+}
+
+// Left-preconditioned restarted GMRES(m), Givens rotations on the host.  Orthogonalisation: classical
+// Gram-Schmidt with one refinement pass (two fused projection + update sweeps, ONE host synchronisation per
+// iteration; as stable as modified Gram-Schmidt) -- PETSc's KSPGMRES default is the classical variant too.
+// PYNAMA_GMRES_MGS=1 selects the step-by-step modified Gram-Schmidt (k+2 synchronisations per iteration).
 static int solve_gmres(pyn_ctx* c, const DMat& A, const double* b, double* x, const pyn_solve_opts& o, pyn_solve_info* info) {
   const int64_t n = c->n_owned * A.br;
   const int64_t nl = n_local(c) * A.br;
   const int m = std::max(1, o.restart);
-  size_t need = (size_t)((int64_t)(m + 1) * nl + 2 * nl + n) * sizeof(double);
+  const int mh = m + 2;                                  // h1[m+1], then (offset mh) h2[m+1], then (2 mh) the norm
+  size_t need = (size_t)((int64_t)(m + 1) * nl + 2 * nl + n + (int64_t)(m + 1) * MD_GRID + 3 * mh) * sizeof(double);
   PYN_TRY(pyn_ensure_work(c, need));
   double* V = c->d_work;            // (m+1) x nl
   double* w = V + (int64_t)(m + 1) * nl;  // nl (needs ghost space as SpMV input? no: output) -> n used
   double* t = w + nl;               // nl  (SpMV input with ghosts)
   double* dinv = t + nl;
+  double* mpart = dinv + n;         // (m+1) x MD_GRID partial sums of the fused projections
+  double* dh = mpart + (int64_t)(m + 1) * MD_GRID;       // device copy of the projection coefficients
+  std::vector<double> hh_host((size_t)3 * mh);
+  const bool mgs = getenv("PYNAMA_GMRES_MGS") != nullptr;
+  const int mdg = (int)std::max<int64_t>(1, std::min<int64_t>((n + 255) / 256, MD_GRID));
   const bool jac = o.pc == PYN_PC_JACOBI;
   if (jac) PYN_TRY(pyn_extract_diag_inv(c, A, dinv, true));
   const double* dv = jac ? dinv : nullptr;
@@ -757,17 +823,35 @@ static int solve_gmres(pyn_ctx* c, const DMat& A, const double* b, double* x, co
       PYN_TRY(pyn_halo_exchange(c, vk, A.bc));
       PYN_TRY(pyn_spmv_raw(c, A, vk, w));
       wmul_kernel<<<g, 256, 0, s>>>(vn, dv, w, n);
-      for (int j = 0; j <= k; ++j) {
-        double h = 0;
-        PYN_TRY(dev_dot(c, vn, V + (int64_t)j * nl, n, &h));
-        H[(size_t)j * m + k] = h;
-        waxpby_kernel<<<g, 256, 0, s>>>(vn, 1.0, vn, -h, V + (int64_t)j * nl, n);
-      }
       double hh = 0;
-      PYN_TRY(dev_dot(c, vn, vn, n, &hh));
-      hh = sqrt(hh);
+      if (mgs) {
+        for (int j = 0; j <= k; ++j) {
+          double h = 0;
+          PYN_TRY(dev_dot(c, vn, V + (int64_t)j * nl, n, &h));
+          H[(size_t)j * m + k] = h;
+          waxpby_kernel<<<g, 256, 0, s>>>(vn, 1.0, vn, -h, V + (int64_t)j * nl, n);
+        }
+        PYN_TRY(dev_dot(c, vn, vn, n, &hh));
+        hh = sqrt(hh);
+        if (hh > 0) waxpby_kernel<<<g, 256, 0, s>>>(vn, 1.0 / hh, vn, 0.0, vn, n);
+      } else {
+        const int k1 = k + 1;
+        for (int pass = 0; pass < 2; ++pass) {          // projection + update, then once more (refinement)
+          multi_dot_kernel<<<mdg, 256, 0, s>>>(V, nl, k1, vn, n, mpart);
+          multi_finish_kernel<<<k1, 256, 0, s>>>(mpart, mdg, dh + pass * mh);
+          if (c->comm) PYN_NCCL(ncclAllReduce(dh + pass * mh, dh + pass * mh, k1, ncclDouble, ncclSum, c->comm, s));
+          multi_axpy_kernel<<<g, 256, 0, s>>>(vn, V, nl, k1, dh + pass * mh, n);
+        }
+        multi_dot_kernel<<<mdg, 256, 0, s>>>(vn, nl, 1, vn, n, mpart);
+        multi_finish_kernel<<<1, 256, 0, s>>>(mpart, mdg, dh + 2 * mh);
+        if (c->comm) PYN_NCCL(ncclAllReduce(dh + 2 * mh, dh + 2 * mh, 1, ncclDouble, ncclSum, c->comm, s));
+        scale_rsqrt_kernel<<<g, 256, 0, s>>>(vn, dh + 2 * mh, n);
+        PYN_HIP(hipMemcpyAsync(hh_host.data(), dh, 3 * mh * sizeof(double), hipMemcpyDeviceToHost, s));
+        PYN_HIP(hipStreamSynchronize(s));
+        for (int j = 0; j <= k; ++j) H[(size_t)j * m + k] = hh_host[j] + hh_host[mh + j];
+        hh = sqrt(std::max(0.0, hh_host[2 * mh]));
+      }
       H[(size_t)(k + 1) * m + k] = hh;
-      if (hh > 0) waxpby_kernel<<<g, 256, 0, s>>>(vn, 1.0 / hh, vn, 0.0, vn, n);
       for (int j = 0; j < k; ++j) {
         double a = cs[j] * H[(size_t)j * m + k] + sn[j] * H[(size_t)(j + 1) * m + k];
         H[(size_t)(j + 1) * m + k] = -sn[j] * H[(size_t)j * m + k] + cs[j] * H[(size_t)(j + 1) * m + k];
