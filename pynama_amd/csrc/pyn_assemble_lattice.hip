@@ -1,0 +1,865 @@
+// Plan-free assembly kernels for Q1 hexahedral meshes with STRUCTURED topology (scalar Laplacian and the KLE blocks),
+// the lattice detection of pyn_mesh_set and their launchers.  See DESIGN.md 4/5.
+#include "pyn_internal.h"
+#include "pyn_q1_hex.h"
+
+namespace {
+
+// =================================================================================================
+// Plan-free variant for meshes with STRUCTURED topology (box meshes: the reference's primary mesh,
+// DMPlexDom.createBoxMesh, src/domain/dmplex.py:8-21; a rank's z-slab of one included).  Same scheme
+// as the patch kernel -- a workgroup owns a TX x TY x TZ tile of rows, integrates every element touching
+// it (one per lane), accumulates in LDS, writes each CSR row once -- but every index comes from integer
+// arithmetic on the lattice descriptor instead of from HBM: no element list, no row-slot / scatter-map
+// stream (84 B per patch-element in the plan), no dependent load chains in front of the stores.
+// LDS accumulators use a fixed 27-point stencil layout acc[row][(dz+1)*9 + (dy+1)*3 + (dx+1)], so the
+// LDS address of pair (a, b) is row_slot(a)*27 + a compile-time constant; the store phase maps CSR slot
+// k of a row (columns sorted by node id: z-plane order from `zord`, then y, then x, clipped at the
+// domain faces) back to the stencil position.
+struct LatArgs {
+  const double* xyz;
+  const int32_t* rowptr;
+  const uint8_t* bcmask;   // per node, may be null
+  const int32_t* P;        // [npl] first node id of every z-plane
+  const int32_t* zord;     // [npl]
+  int nx, ny, npl, p_own0, n_own;
+  int ntx, nty;            // tiles per direction
+  int std_lat;             // P[j] == j*nx*ny, all planes owned, standard z order: plane bases, z codes AND row offsets
+                           // come from arithmetic (no index loads at all)
+  int ablate;              // diagnostics (PYNAMA_LATTICE_ABLATE): 1 no element phase, 2 no LDS adds, 3 no coordinate loads
+  TileArgs q;              // quadrature tables (w, hrs, hcoo, aff) -- only those fields are used
+  double* A;
+  double* Arhs;
+};
+
+template <int TX, int TY, int TZ>
+struct LatTile {
+  static constexpr int NR = TX * TY * TZ, EX = TX + 1, EY = TY + 1, EZ = TZ + 1, NE = EX * EY * EZ;
+  static constexpr int BX = TX + 2, BY = TY + 2, BZ = TZ + 2, NB = BX * BY * BZ;
+  static constexpr int ACC = NR * 27;                                  // doubles
+  static constexpr int META_INTS = NR + TZ + (NB + 3) / 4;             // rlo[NR], zrd[TZ], nbc[NB] bytes
+  static constexpr size_t BYTES = ACC * sizeof(double) + META_INTS * sizeof(int);
+};
+
+// First node id of z-plane j.  Arithmetic form (std_lat): the owned planes carry the ids 0 .. n_owned-1 in z
+// order, the ghost planes below them follow, then the ghost planes above (the numbering of a rank's z-slab; on one
+// rank simply j*nx*ny).  pyn_lattice_detect verified that the uploaded numbering has this shape.
+__device__ __forceinline__ int lat_plane(const LatArgs& T, int j) {
+  if (!T.std_lat) return T.P[j];
+  const int pp = T.nx * T.ny, lo = T.p_own0, hi = T.p_own0 + T.n_own;
+  if (j < lo) return (T.n_own + j) * pp;
+  if (j >= hi) return (T.n_own + lo + (j - hi)) * pp;
+  return (j - lo) * pp;
+}
+
+// CSR offset of the row of owned node (x, y, owned plane zo): rows in id order, len = cx cy cz with c = 3 minus
+// the domain faces the node sits on (a slab interface is not a face: its ghost plane supplies the columns);
+// sum_{x' < x} cx(x') = 3x - (x > 0), sum over a whole line = 3 nx - 2.  Verified against the graph's rowptr.
+__device__ __forceinline__ int lat_rowptr_std(const LatArgs& T, int x, int y, int zo) {
+  const int sx = 3 * T.nx - 2, sy = 3 * T.ny - 2;
+  const bool bot = T.p_own0 == 0, top = T.p_own0 + T.n_own == T.npl;   // does the slab hold the domain's end planes?
+  const int cy = 3 - (y == 0) - (y == T.ny - 1), cz = 3 - (bot && zo == 0) - (top && zo == T.n_own - 1);
+  return (3 * zo - (bot && zo > 0)) * sy * sx + cz * ((3 * y - (y > 0)) * sx + cy * (3 * x - (x > 0)));
+}
+
+// z-order code of OWNED plane pl: the existing z-neighbours sorted by node id -- owned planes first (ascending),
+// then the ghost plane below, then the ghost plane above
+__device__ __forceinline__ int lat_zcode(const LatArgs& T, int pl) {
+  if (!T.std_lat) return T.zord[pl];
+  const int lo = T.p_own0, hi = T.p_own0 + T.n_own;
+  const bool has_dn = pl > 0, has_up = pl < T.npl - 1;
+  const bool dn_ghost = has_dn && pl - 1 < lo, up_ghost = has_up && pl + 1 >= hi;
+  int code = 0, n = 0;
+  if (has_dn && !dn_ghost) code |= 0 << (2 + 2 * n++);
+  code |= 1 << (2 + 2 * n++);
+  if (has_up && !up_ghost) code |= 2 << (2 + 2 * n++);
+  if (dn_ghost) code |= 0 << (2 + 2 * n++);
+  if (up_ghost) code |= 2 << (2 + 2 * n++);
+  return code | n;
+}
+
+// Row offsets and Dirichlet flags of a tile, in two steps so that their HBM latency hides behind the element
+// phase: lat_meta_load issues the loads into registers before it, lat_meta_commit writes them to LDS after it.
+template <int TX, int TY, int TZ, int NT>
+struct LatMeta {
+  using L = LatTile<TX, TY, TZ>;
+  static constexpr int NF = (L::NB + NT - 1) / NT, NRW = (L::NR + NT - 1) / NT;
+  unsigned char f[NF];
+  int r[NRW];
+};
+
+template <int TX, int TY, int TZ, int NT, int NDOF = 1>
+__device__ __forceinline__ void lat_meta_load(const LatArgs& T, int x0, int y0, int z0, int t, LatMeta<TX, TY, TZ, NT>& M) {
+  using L = LatTile<TX, TY, TZ>;
+  const int nx = T.nx, ny = T.ny;
+#pragma unroll
+  for (int j = 0; j < LatMeta<TX, TY, TZ, NT>::NF; ++j) {
+    const int i = t + j * NT;
+    const int qx = i % L::BX, qy = (i / L::BX) % L::BY, qz = i / (L::BX * L::BY);
+    const int x = x0 - 1 + qx, y = y0 - 1 + qy, pl = T.p_own0 + z0 - 1 + qz;
+    const bool ok = T.bcmask && i < L::NB && x >= 0 && x < nx && y >= 0 && y < ny && pl >= 0 && pl < T.npl;
+    unsigned char f = 0;   // bit q: DOF q of the node imposed
+    if (ok) {
+      const int64_t node = lat_plane(T, pl) + y * nx + x;
+#pragma unroll
+      for (int q = 0; q < NDOF; ++q) f |= (T.bcmask[node * NDOF + q] ? 1 : 0) << q;
+    }
+    M.f[j] = f;
+  }
+#pragma unroll
+  for (int j = 0; j < LatMeta<TX, TY, TZ, NT>::NRW; ++j) {
+    const int s = t + j * NT;
+    const int rx = s % TX, ry = (s / TX) % TY, rz = s / (TX * TY);
+    const int x = x0 + rx, y = y0 + ry, zo = z0 + rz;
+    const bool ok = s < L::NR && x < nx && y < ny && zo < T.n_own;
+    M.r[j] = !ok ? -1 : (T.std_lat ? lat_rowptr_std(T, x, y, zo) : T.rowptr[T.P[T.p_own0 + zo] + y * nx + x]);
+  }
+}
+
+template <int TX, int TY, int TZ, int NT>
+__device__ __forceinline__ int lat_meta_commit(const LatArgs& T, int z0, int t, const LatMeta<TX, TY, TZ, NT>& M, int* rlo, int* zrd,
+                                               unsigned char* nbc) {
+  using L = LatTile<TX, TY, TZ>;
+  int any = 0;
+#pragma unroll
+  for (int j = 0; j < LatMeta<TX, TY, TZ, NT>::NF; ++j)
+    if (t + j * NT < L::NB) {
+      nbc[t + j * NT] = M.f[j];
+      any |= M.f[j];
+    }
+#pragma unroll
+  for (int j = 0; j < LatMeta<TX, TY, TZ, NT>::NRW; ++j)
+    if (t + j * NT < L::NR) rlo[t + j * NT] = M.r[j];
+  if (t < TZ) zrd[t] = (z0 + t < T.n_own) ? lat_zcode(T, T.p_own0 + z0 + t) : 0;
+  return any;
+}
+
+// integrate every element touching the tile (one per lane) and add the rows the tile owns into acc
+template <int TX, int TY, int TZ>
+__device__ __forceinline__ void lat_integrate(const LatArgs& T, int x0, int y0, int z0, double* acc, int t0, int nt) {
+  using LT = LatTile<TX, TY, TZ>;
+  const int nx = T.nx, ny = T.ny;
+  // corner offsets (dx, dy, dz) in the reference's closure order
+  constexpr int CX[8] = {0, 0, 1, 1, 0, 1, 1, 0};
+  constexpr int CY[8] = {0, 1, 1, 0, 0, 0, 1, 1};
+  constexpr int CZ[8] = {0, 0, 0, 0, 1, 1, 1, 1};
+  for (int t = t0; t < LT::NE; t += nt) {
+    const int lx = t % LT::EX, ly = (t / LT::EX) % LT::EY, lz = t / (LT::EX * LT::EY);
+    const int gx = x0 - 1 + lx, gy = y0 - 1 + ly, gl = T.p_own0 + z0 - 1 + lz;
+    if (gx < 0 || gx >= nx - 1 || gy < 0 || gy >= ny - 1 || gl < 0 || gl >= T.npl - 1) continue;
+    const int n00 = gy * nx + gx;
+    const int pb = lat_plane(T, gl) + n00, pt = lat_plane(T, gl + 1) + n00;
+    double X[8][3];
+#pragma unroll
+    for (int a = 0; a < 8; ++a) {
+      const int node = (CZ[a] ? pt : pb) + CY[a] * nx + CX[a];
+      const double* q = T.xyz + (int64_t)node * 3;
+      X[a][0] = q[0];
+      X[a][1] = q[1];
+      X[a][2] = q[2];
+    }
+    double L[36];
+    if (T.q.aff && __all(element_is_affine(T.q, X) ? 1 : 0)) {
+      affine_laplace(T.q, X, L);
+    } else {
+#pragma unroll
+      for (int i = 0; i < 36; ++i) L[i] = 0.0;
+#pragma nounroll
+      for (int g = 0; g < 8; ++g) gauss_point(T.q, g, X, L);
+    }
+#pragma unroll
+    for (int a = 0; a < 8; ++a) {
+      const int rx = lx - 1 + CX[a], ry = ly - 1 + CY[a], rz = lz - 1 + CZ[a];
+      // the row exists in x, y (the element does); in z it must be one of this tile's OWNED planes
+      if (rx < 0 || rx >= TX || ry < 0 || ry >= TY || rz < 0 || rz >= TZ || z0 + rz >= T.n_own) continue;
+      double* row = acc + ((rz * TY + ry) * TX + rx) * 27;
+#pragma unroll
+      for (int c = 0; c < 8; ++c) {
+        const int kk = (CZ[c] - CZ[a] + 1) * 9 + (CY[c] - CY[a] + 1) * 3 + (CX[c] - CX[a] + 1);
+        atomicAdd(&row[kk], L[tri(a, c)]);
+      }
+    }
+  }
+}
+
+// write every row of the tile once (half a wave per row, UNROLL rows in flight): A gets the free columns,
+// Arhs the imposed ones (negated), imposed rows become identity rows (mat_generator.py:113-118).
+// ZERO: clear each accumulator after reading it (the buffer is reused by the next tile).
+template <int TX, int TY, int TZ>
+__device__ __forceinline__ void lat_store(const LatArgs& T, int x0, int y0, const double* acc, const int* rlo, const int* zrd,
+                                          const unsigned char* nbc, int t, int nt) {
+  using LT = LatTile<TX, TY, TZ>;
+  const int nx = T.nx, ny = T.ny;
+  double* __restrict__ outA = T.A;
+  double* __restrict__ outR = T.Arhs;
+  const int half = t >> 5, k = t & 31;
+  const int NH = nt >> 5;
+  constexpr int UNROLL = 4;
+  // branch-free per row: the LDS reads of the UNROLL rows are independent of each other, so they overlap
+  for (int s0 = half; s0 < LT::NR; s0 += NH * UNROLL) {
+    int lo[UNROLL], ai[UNROLL], bi[UNROLL], bo[UNROLL];
+    bool diag[UNROLL];
+#pragma unroll
+    for (int u = 0; u < UNROLL; ++u) {
+      const int s = min(s0 + u * NH, LT::NR - 1);
+      const int rl = rlo[s];
+      const int rx = s % TX, ry = (s / TX) % TY, rz = s / (TX * TY);
+      const int x = x0 + rx, y = y0 + ry;
+      const int zi = zrd[rz];
+      const int cx = 3 - (x == 0) - (x == nx - 1), cy = 3 - (y == 0) - (y == ny - 1), cz = zi & 3;
+      const int cc = cx * cy;
+      const bool act = (s0 + u * NH < LT::NR) && rl >= 0 && k < cc * cz;
+      const int kz = (k >= cc) + (k >= 2 * cc);
+      const int r = k - kz * cc;
+      const int ky = (r >= cx) + (r >= 2 * cx);
+      const int kx = r - ky * cx;
+      const int dz = act ? ((zi >> (2 + 2 * kz)) & 3) - 1 : 0;
+      const int dy = act ? ky - (y != 0) : 0, dx = act ? kx - (x != 0) : 0;
+      ai[u] = s * 27 + (dz + 1) * 9 + (dy + 1) * 3 + (dx + 1);
+      bi[u] = ((rz + 1) * LT::BY + ry + 1) * LT::BX + rx + 1;
+      bo[u] = bi[u] + (dz * LT::BY + dy) * LT::BX + dx;
+      diag[u] = dx == 0 && dy == 0 && dz == 0;
+      lo[u] = act ? rl + k : -1;
+    }
+    double v[UNROLL];
+    unsigned char fr[UNROLL], fc[UNROLL];
+#pragma unroll
+    for (int u = 0; u < UNROLL; ++u) {
+      v[u] = acc[ai[u]];
+      fr[u] = nbc[bi[u]];
+      fc[u] = nbc[bo[u]];
+    }
+#pragma unroll
+    for (int u = 0; u < UNROLL; ++u) {
+      const double va = fr[u] ? (diag[u] ? 1.0 : 0.0) : (fc[u] ? 0.0 : v[u]);
+      const double vr = fr[u] ? (diag[u] ? 1.0 : 0.0) : (fc[u] ? -v[u] : 0.0);
+      if (lo[u] >= 0) {
+        outA[lo[u]] = va;
+        if (outR) outR[lo[u]] = vr;
+      }
+    }
+  }
+}
+
+// Store phase of a "plain" tile -- no row on a domain face, the three z-neighbour planes in ascending id order,
+// no imposed node in the node box: CSR slot k of a row IS stencil position k, and the TX rows of an x-line are
+// one contiguous run of TX*27 doubles both in LDS and in the CSR value array.  Straight coalesced copy.
+constexpr int ZCODE_STD = 3 | (0 << 2) | (1 << 4) | (2 << 6);
+template <int TX, int TY, int TZ>
+__device__ __forceinline__ void lat_store_plain(const LatArgs& T, const double* acc, const int* rlo, int t, int nt) {
+  constexpr int LINE = TX * 27, NL = TY * TZ, PER = (LINE + 63) / 64;
+  double* __restrict__ outA = T.A;
+  double* __restrict__ outR = T.Arhs;
+  const int w = t >> 6, lane = t & 63, nw = nt >> 6;
+  for (int l = w; l < NL; l += nw) {
+    const int base = rlo[l * TX];
+    double v[PER];
+#pragma unroll
+    for (int j = 0; j < PER; ++j) {
+      const int i = lane + 64 * j;
+      v[j] = (i < LINE) ? acc[l * LINE + i] : 0.0;
+    }
+#pragma unroll
+    for (int j = 0; j < PER; ++j) {
+      const int i = lane + 64 * j;
+      if (i < LINE) {
+        outA[base + i] = v[j];
+        if (outR) outR[base + i] = 0.0;
+      }
+    }
+  }
+}
+
+template <int TX, int TY, int TZ>
+__device__ __forceinline__ bool lat_tile_plain(const LatArgs& T, int x0, int y0, int z0, const int* zrd, int anybc) {
+  bool plain = !anybc && x0 >= 1 && x0 + TX <= T.nx - 1 && y0 >= 1 && y0 + TY <= T.ny - 1 && z0 + TZ <= T.n_own;
+  for (int j = 0; j < TZ; ++j) plain = plain && zrd[j] == ZCODE_STD;
+  return plain;
+}
+
+// Lean integration for meshes whose elements are ALL parallelepipeds (every box mesh the reference creates,
+// src/domain/dmplex.py:8-21): four corner loads instead of eight, J = S.E from the three edge vectors
+// (S[d][m] = sum_c hcoo[d][c] C_m[c], a table constant), L_ab = detJ sum_{r<=s} Q_rs T_rs[ab]; no quadrature
+// loop, no affinity test: ~110 VGPRs instead of ~170, i.e. 4 instead of 2-3 waves per SIMD to hide the gather
+// and store latencies.
+template <int TX, int TY, int TZ>
+__device__ __forceinline__ void lat_integrate_affine(const LatArgs& T, int x0, int y0, int z0, double* acc, int t0, int nt) {
+  using LT = LatTile<TX, TY, TZ>;
+  const int nx = T.nx, ny = T.ny;
+  const double* __restrict__ S = T.q.aff + 248;
+  constexpr int CX[8] = {0, 0, 1, 1, 0, 1, 1, 0};
+  constexpr int CY[8] = {0, 1, 1, 0, 0, 0, 1, 1};
+  constexpr int CZ[8] = {0, 0, 0, 0, 1, 1, 1, 1};
+  for (int t = t0; t < LT::NE; t += nt) {
+    const int lx = t % LT::EX, ly = (t / LT::EX) % LT::EY, lz = t / (LT::EX * LT::EY);
+    const int gx = x0 - 1 + lx, gy = y0 - 1 + ly, gl = T.p_own0 + z0 - 1 + lz;
+    if (gx < 0 || gx >= nx - 1 || gy < 0 || gy >= ny - 1 || gl < 0 || gl >= T.npl - 1) continue;
+    const int n00 = gy * nx + gx;
+    const double* q0 = T.xyz + (int64_t)(lat_plane(T, gl) + n00) * 3;
+    const double* qz = T.xyz + (int64_t)(lat_plane(T, gl + 1) + n00) * 3;
+    double E[3][3];  // edge vectors along the lattice x, y, z directions
+#pragma unroll
+    for (int x = 0; x < 3; ++x) {
+      const double o = q0[x];
+      E[0][x] = q0[3 + x] - o;
+      E[1][x] = q0[3 * nx + x] - o;
+      E[2][x] = qz[x] - o;
+    }
+    double J[3][3];
+#pragma unroll
+    for (int d = 0; d < 3; ++d)
+#pragma unroll
+      for (int x = 0; x < 3; ++x) J[d][x] = fma(S[d * 3 + 2], E[2][x], fma(S[d * 3 + 1], E[1][x], S[d * 3] * E[0][x]));
+    const double c00 = J[1][1] * J[2][2] - J[1][2] * J[2][1];
+    const double c01 = J[1][2] * J[2][0] - J[1][0] * J[2][2];
+    const double c02 = J[1][0] * J[2][1] - J[1][1] * J[2][0];
+    const double det = J[0][0] * c00 + J[0][1] * c01 + J[0][2] * c02;
+    const double r = 1.0 / det;
+    double Ji[3][3];
+    Ji[0][0] = c00 * r;
+    Ji[0][1] = (J[0][2] * J[2][1] - J[0][1] * J[2][2]) * r;
+    Ji[0][2] = (J[0][1] * J[1][2] - J[0][2] * J[1][1]) * r;
+    Ji[1][0] = c01 * r;
+    Ji[1][1] = (J[0][0] * J[2][2] - J[0][2] * J[2][0]) * r;
+    Ji[1][2] = (J[0][2] * J[1][0] - J[0][0] * J[1][2]) * r;
+    Ji[2][0] = c02 * r;
+    Ji[2][1] = (J[0][1] * J[2][0] - J[0][0] * J[2][1]) * r;
+    Ji[2][2] = (J[0][0] * J[1][1] - J[0][1] * J[1][0]) * r;
+    double Q[6];
+    {
+      constexpr int RS[6][2] = {{0, 0}, {1, 1}, {2, 2}, {0, 1}, {0, 2}, {1, 2}};
+#pragma unroll
+      for (int u = 0; u < 6; ++u) {
+        const int a = RS[u][0], b = RS[u][1];
+        Q[u] = det * (Ji[0][a] * Ji[0][b] + Ji[1][a] * Ji[1][b] + Ji[2][a] * Ji[2][b]);
+      }
+    }
+    // 72 T_rs[ab] are small integers for the trilinear element (q1_aff_int): 15 products, then signed sums --
+    // no table traffic at all inside the loop
+    double L[36];
+    {
+      double D[3][3], M[3][2];
+#pragma unroll
+      for (int u = 0; u < 3; ++u) {
+        const double qd = Q[u] * (1.0 / 72.0), qm = Q[3 + u] * (1.0 / 72.0);
+        D[u][0] = 4.0 * qd;
+        D[u][1] = 8.0 * qd;
+        D[u][2] = 16.0 * qd;
+        M[u][0] = 12.0 * qm;
+        M[u][1] = 24.0 * qm;
+      }
+      int idx = 0;
+#pragma unroll
+      for (int a = 0; a < 8; ++a)
+#pragma unroll
+        for (int c = a; c < 8; ++c, ++idx) {
+          double v = 0.0;
+#pragma unroll
+          for (int u = 0; u < 6; ++u) {
+            const int n = q1_aff_int(u, a, c);
+            const int an = n < 0 ? -n : n;
+            if (an == 0) continue;
+            const double x = u < 3 ? D[u][an == 4 ? 0 : (an == 8 ? 1 : 2)] : M[u - 3][an == 12 ? 0 : 1];
+            v = n > 0 ? v + x : v - x;
+          }
+          L[idx] = v;
+        }
+    }
+#pragma unroll
+    for (int a = 0; a < 8; ++a) {
+      const int rx = lx - 1 + CX[a], ry = ly - 1 + CY[a], rz = lz - 1 + CZ[a];
+      if (rx < 0 || rx >= TX || ry < 0 || ry >= TY || rz < 0 || rz >= TZ || z0 + rz >= T.n_own) continue;
+      double* row = acc + ((rz * TY + ry) * TX + rx) * 27;
+#pragma unroll
+      for (int c = 0; c < 8; ++c) {
+        const int kk = (CZ[c] - CZ[a] + 1) * 9 + (CY[c] - CY[a] + 1) * 3 + (CX[c] - CX[a] + 1);
+        atomicAdd(&row[kk], L[tri(a, c)]);
+      }
+    }
+  }
+}
+
+// one-off check behind std_lat: the closed-form row offsets equal the symbolic phase's rowptr
+__global__ void lattice_rowptr_check_kernel(LatArgs T, const int32_t* __restrict__ rowptr, int64_t n_rows, int* flag) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n_rows) return;
+  const int x = (int)(i % T.nx), y = (int)((i / T.nx) % T.ny), zo = (int)(i / ((int64_t)T.nx * T.ny));
+  if (rowptr[i] != lat_rowptr_std(T, x, y, zo)) *flag = 0;
+}
+
+// one tile per workgroup
+template <int TX, int TY, int TZ, bool AFF>
+__global__ void __launch_bounds__(TILE_THREADS, AFF ? 3 : 2) assemble_q1_hex_lattice_kernel(LatArgs T) {
+  using LT = LatTile<TX, TY, TZ>;
+  extern __shared__ __align__(16) double lds[];
+  double* acc = lds;
+  int* rlo = reinterpret_cast<int*>(acc + LT::ACC);
+  int* zrd = rlo + LT::NR;
+  unsigned char* nbc = reinterpret_cast<unsigned char*>(zrd + TZ);
+  const int tid = threadIdx.x;
+  const int b = blockIdx.x;
+  const int bx = b % T.ntx, by = (b / T.ntx) % T.nty, bz = b / (T.ntx * T.nty);
+  const int x0 = bx * TX, y0 = by * TY, z0 = bz * TZ;
+  LatMeta<TX, TY, TZ, TILE_THREADS> meta;
+  lat_meta_load<TX, TY, TZ, TILE_THREADS>(T, x0, y0, z0, tid, meta);   // in flight during the element phase
+  for (int i = tid; i < LT::ACC; i += TILE_THREADS) acc[i] = 0.0;
+  __syncthreads();
+  if (T.ablate != 1) {
+    if (AFF)
+      lat_integrate_affine<TX, TY, TZ>(T, x0, y0, z0, acc, tid, TILE_THREADS);
+    else
+      lat_integrate<TX, TY, TZ>(T, x0, y0, z0, acc, tid, TILE_THREADS);
+  }
+  const int anybc = __syncthreads_or(lat_meta_commit<TX, TY, TZ, TILE_THREADS>(T, z0, tid, meta, rlo, zrd, nbc));
+  if (lat_tile_plain<TX, TY, TZ>(T, x0, y0, z0, zrd, anybc) && T.ablate != 4)
+    lat_store_plain<TX, TY, TZ>(T, acc, rlo, tid, TILE_THREADS);
+  else
+    lat_store<TX, TY, TZ>(T, x0, y0, acc, rlo, zrd, nbc, tid, TILE_THREADS);
+}
+
+// ---- plan-free KLE assembly on lattices of parallelepipeds: the scalar lattice kernel's scheme (index
+// arithmetic, stencil-ordered LDS rows, straight x-line copies for interior tiles) with the four-wave closed-form
+// element blocks of assemble_q1_hex_kle_affine_kernel.  LDS row of a node = [p][27 stencil slots][q] = exactly the
+// node's block-CSR row when it has all 27 neighbours.
+struct KleLatArgs {
+  LatArgs L;              // A = K or Rw, Arhs = Krhs (K only, may be null); bcmask per DOF (3 per node)
+  double alpha_d, alpha_w;
+  const double *wr, *hrsr, *Hr, *hcoor;   // reduced (centroid) rule
+};
+
+template <int TX, int TY, int TZ, bool RW, int A0>
+__device__ __forceinline__ void kle_lat_rows(const KleLatArgs& T, const double (&Ji)[3][3], double det, int lx, int ly, int lz,
+                                             int z0, double* acc) {
+  constexpr int CX[8] = {0, 0, 1, 1, 0, 1, 1, 0};
+  constexpr int CY[8] = {0, 1, 1, 0, 0, 0, 1, 1};
+  constexpr int CZ[8] = {0, 0, 0, 0, 1, 1, 1, 1};
+  const double cr = T.wr[0] * det;
+  const double caw = cr * T.alpha_w, cad = cr * T.alpha_d;
+  const double* __restrict__ hr = T.hrsr;
+  double Gr[3][8];
+#pragma unroll
+  for (int d = 0; d < 3; ++d)
+#pragma unroll
+    for (int a = 0; a < 8; ++a) Gr[d][a] = fma(Ji[d][2], hr[16 + a], fma(Ji[d][1], hr[8 + a], Ji[d][0] * hr[a]));
+  double D[3][3], M2[3][2], DM[3][3][3];
+  if (!RW) {
+    constexpr int RS[6][2] = {{0, 0}, {1, 1}, {2, 2}, {0, 1}, {0, 2}, {1, 2}};
+#pragma unroll
+    for (int u = 0; u < 3; ++u) {
+      const int a0 = RS[u][0], a1 = RS[3 + u][0], b1 = RS[3 + u][1];
+      const double qd = det * (Ji[0][a0] * Ji[0][a0] + Ji[1][a0] * Ji[1][a0] + Ji[2][a0] * Ji[2][a0]) * (1.0 / 72.0);
+      const double qm = det * (Ji[0][a1] * Ji[0][b1] + Ji[1][a1] * Ji[1][b1] + Ji[2][a1] * Ji[2][b1]) * (1.0 / 72.0);
+      D[u][0] = 4.0 * qd, D[u][1] = 8.0 * qd, D[u][2] = 16.0 * qd;
+      M2[u][0] = 12.0 * qm, M2[u][1] = 24.0 * qm;
+    }
+  } else {
+#pragma unroll
+    for (int m = 0; m < 3; ++m)
+#pragma unroll
+      for (int d = 0; d < 3; ++d) {
+        const double x = det * Ji[m][d] * (1.0 / 72.0);
+        DM[m][d][0] = 4.0 * x, DM[m][d][1] = 8.0 * x, DM[m][d][2] = 16.0 * x;
+      }
+  }
+#pragma unroll
+  for (int h = 0; h < 2; ++h) {
+    const int a = A0 + h;
+    const int rx = lx - 1 + CX[a], ry = ly - 1 + CY[a], rz = lz - 1 + CZ[a];
+    if (rx < 0 || rx >= TX || ry < 0 || ry >= TY || rz < 0 || rz >= TZ || z0 + rz >= T.L.n_own) continue;
+    double* rowp = acc + ((rz * TY + ry) * TX + rx) * 243;
+#pragma unroll
+    for (int b = 0; b < 8; ++b) {
+      const int kk = (CZ[b] - CZ[a] + 1) * 9 + (CY[b] - CY[a] + 1) * 3 + (CX[b] - CX[a] + 1);
+      if (!RW) {
+        double lab = 0.0;
+#pragma unroll
+        for (int u = 0; u < 6; ++u) {
+          const int n = q1_aff_int(u, a, b);
+          const int an = n < 0 ? -n : n;
+          if (an == 0) continue;
+          const double x = u < 3 ? D[u][an == 4 ? 0 : (an == 8 ? 1 : 2)] : M2[u - 3][an == 12 ? 0 : 1];
+          lab = n > 0 ? lab + x : lab - x;
+        }
+        const double s_ab = Gr[0][a] * Gr[0][b] + Gr[1][a] * Gr[1][b] + Gr[2][a] * Gr[2][b];
+        const double diag = lab + caw * s_ab;
+#pragma unroll
+        for (int pp = 0; pp < 3; ++pp)
+#pragma unroll
+          for (int q = 0; q < 3; ++q) {
+            double v = cad * Gr[pp][a] * Gr[q][b] - caw * Gr[q][a] * Gr[pp][b];
+            if (pp == q) v += diag;
+            atomicAdd(&rowp[(pp * 27 + kk) * 3 + q], v);
+          }
+      } else {
+        const double hb = T.Hr[b];
+#pragma unroll
+        for (int m = 0; m < 3; ++m) {
+          double tv = 0.0;
+#pragma unroll
+          for (int d = 0; d < 3; ++d) {
+            const int n = q1_mix_int(d, a, b);
+            const int an = n < 0 ? -n : n;
+            const double x = DM[m][d][an == 4 ? 0 : (an == 8 ? 1 : 2)];
+            tv = n > 0 ? tv + x : tv - x;
+          }
+          const double wv = tv - caw * Gr[m][a] * hb;
+          const int P1 = (m + 1) % 3, P2 = (m + 2) % 3;
+          atomicAdd(&rowp[(P2 * 27 + kk) * 3 + P1], wv);
+          atomicAdd(&rowp[(P1 * 27 + kk) * 3 + P2], -wv);
+        }
+      }
+    }
+  }
+}
+
+template <int TX, int TY, int TZ, bool RW>
+__global__ void __launch_bounds__(256, 3) assemble_q1_hex_kle_lattice_kernel(KleLatArgs T) {
+  using LT = LatTile<TX, TY, TZ>;
+  constexpr int ROW = 243, ACC = LT::NR * ROW;
+  extern __shared__ __align__(16) double lds[];
+  double* acc = lds;
+  int* rlo = reinterpret_cast<int*>(acc + ACC);
+  int* zrd = rlo + LT::NR;
+  unsigned char* nbc = reinterpret_cast<unsigned char*>(zrd + TZ);
+  const LatArgs& L = T.L;
+  const int tid = threadIdx.x, lane = tid & 63, part = tid >> 6;
+  const int b = blockIdx.x;
+  const int bx = b % L.ntx, by = (b / L.ntx) % L.nty, bz = b / (L.ntx * L.nty);
+  const int x0 = bx * TX, y0 = by * TY, z0 = bz * TZ;
+  const int nx = L.nx, ny = L.ny;
+  LatMeta<TX, TY, TZ, 256> meta;
+  lat_meta_load<TX, TY, TZ, 256, 3>(L, x0, y0, z0, tid, meta);
+  for (int i = tid; i < ACC; i += 256) acc[i] = 0.0;
+  __syncthreads();
+
+  const double* __restrict__ S = L.q.aff + 248;
+  for (int t = lane; t < LT::NE && L.ablate != 1; t += 64) {
+    const int lx = t % LT::EX, ly = (t / LT::EX) % LT::EY, lz = t / (LT::EX * LT::EY);
+    const int gx = x0 - 1 + lx, gy = y0 - 1 + ly, gl = L.p_own0 + z0 - 1 + lz;
+    if (gx < 0 || gx >= nx - 1 || gy < 0 || gy >= ny - 1 || gl < 0 || gl >= L.npl - 1) continue;
+    const int n00 = gy * nx + gx;
+    const double* q0 = L.xyz + (int64_t)(lat_plane(L, gl) + n00) * 3;
+    const double* qz = L.xyz + (int64_t)(lat_plane(L, gl + 1) + n00) * 3;
+    double E[3][3];
+#pragma unroll
+    for (int x = 0; x < 3; ++x) {
+      const double o = q0[x];
+      E[0][x] = q0[3 + x] - o;
+      E[1][x] = q0[3 * nx + x] - o;
+      E[2][x] = qz[x] - o;
+    }
+    double J[3][3];
+#pragma unroll
+    for (int d = 0; d < 3; ++d)
+#pragma unroll
+      for (int x = 0; x < 3; ++x) J[d][x] = fma(S[d * 3 + 2], E[2][x], fma(S[d * 3 + 1], E[1][x], S[d * 3] * E[0][x]));
+    const double c00 = J[1][1] * J[2][2] - J[1][2] * J[2][1];
+    const double c01 = J[1][2] * J[2][0] - J[1][0] * J[2][2];
+    const double c02 = J[1][0] * J[2][1] - J[1][1] * J[2][0];
+    const double det = J[0][0] * c00 + J[0][1] * c01 + J[0][2] * c02;
+    const double r = 1.0 / det;
+    double Ji[3][3];
+    Ji[0][0] = c00 * r;
+    Ji[0][1] = (J[0][2] * J[2][1] - J[0][1] * J[2][2]) * r;
+    Ji[0][2] = (J[0][1] * J[1][2] - J[0][2] * J[1][1]) * r;
+    Ji[1][0] = c01 * r;
+    Ji[1][1] = (J[0][0] * J[2][2] - J[0][2] * J[2][0]) * r;
+    Ji[1][2] = (J[0][2] * J[1][0] - J[0][0] * J[1][2]) * r;
+    Ji[2][0] = c02 * r;
+    Ji[2][1] = (J[0][1] * J[2][0] - J[0][0] * J[2][1]) * r;
+    Ji[2][2] = (J[0][0] * J[1][1] - J[0][1] * J[1][0]) * r;
+    switch (part) {   // wave-uniform: wave w adds the node rows {2w, 2w+1} of every element
+      case 0: kle_lat_rows<TX, TY, TZ, RW, 0>(T, Ji, det, lx, ly, lz, z0, acc); break;
+      case 1: kle_lat_rows<TX, TY, TZ, RW, 2>(T, Ji, det, lx, ly, lz, z0, acc); break;
+      case 2: kle_lat_rows<TX, TY, TZ, RW, 4>(T, Ji, det, lx, ly, lz, z0, acc); break;
+      default: kle_lat_rows<TX, TY, TZ, RW, 6>(T, Ji, det, lx, ly, lz, z0, acc); break;
+    }
+  }
+  const int anybc = __syncthreads_or(lat_meta_commit<TX, TY, TZ, 256>(L, z0, tid, meta, rlo, zrd, nbc));
+
+  double* __restrict__ outA = L.A;
+  double* __restrict__ outR = L.Arhs;
+  if (lat_tile_plain<TX, TY, TZ>(L, x0, y0, z0, zrd, anybc)) {
+    // interior tile: the TX node rows of an x-line are one contiguous run of TX*243 doubles here and in HBM
+    constexpr int LINE = TX * ROW, NL = TY * TZ;
+    for (int l = part; l < NL; l += 4) {
+      const int64_t base = (int64_t)rlo[l * TX] * 9;
+      for (int i = lane; i < LINE; i += 64) {
+        outA[base + i] = acc[l * LINE + i];
+        if (!RW && outR) outR[base + i] = 0.0;
+      }
+    }
+    return;
+  }
+  // boundary tile: one wave per scalar row (node row s, component p), CSR slot -> stencil position as in lat_store
+  for (int sr = part; sr < LT::NR * 3; sr += 4) {
+    const int s = sr / 3, pp = sr - s * 3;
+    const int rl = rlo[s];
+    if (rl < 0) continue;
+    const int rx = s % TX, ry = (s / TX) % TY, rz = s / (TX * TY);
+    const int x = x0 + rx, y = y0 + ry;
+    const int zi = zrd[rz];
+    const int cx = 3 - (x == 0) - (x == nx - 1), cy = 3 - (y == 0) - (y == ny - 1), cz = zi & 3;
+    const int cc = cx * cy, len = cc * cz;
+    const int bi = ((rz + 1) * LT::BY + ry + 1) * LT::BX + rx + 1;
+    const bool rowbc = (nbc[bi] >> pp) & 1;
+    const int64_t gbase = ((int64_t)rl * 3 + (int64_t)pp * len) * 3;
+    for (int idx = lane; idx < len * 3; idx += 64) {
+      const int k = idx / 3, q = idx - k * 3;
+      const int kz = (k >= cc) + (k >= 2 * cc);
+      const int rr = k - kz * cc;
+      const int ky = (rr >= cx) + (rr >= 2 * cx);
+      const int kx = rr - ky * cx;
+      const int dz = ((zi >> (2 + 2 * kz)) & 3) - 1;
+      const int dy = ky - (y != 0), dx = kx - (x != 0);
+      const double v = acc[s * ROW + (pp * 27 + (dz + 1) * 9 + (dy + 1) * 3 + (dx + 1)) * 3 + q];
+      double va, vr;
+      if (rowbc) {
+        va = vr = (!RW && q == pp && dx == 0 && dy == 0 && dz == 0) ? 1.0 : 0.0;
+      } else if (!RW && ((nbc[bi + (dz * LT::BY + dy) * LT::BX + dx] >> q) & 1)) {
+        va = 0.0;
+        vr = -v;
+      } else {
+        va = v;
+        vr = 0.0;
+      }
+      outA[gbase + idx] = va;
+      if (!RW && outR) outR[gbase + idx] = vr;
+    }
+  }
+}
+
+}  // namespace
+
+// ---- structured topology: detection (host, once per pyn_mesh_set) and launch -------------------------
+int pyn_lattice_detect(pyn_ctx* c, const int32_t* conn) {
+  Lattice& L = c->lat;
+  (void)hipFree(L.d_P);
+  (void)hipFree(L.d_zord);
+  L = Lattice();
+  if (c->dim != 3 || c->nn != 8 || c->n_elem < 1 || getenv("PYNAMA_NO_LATTICE")) return PYN_OK;
+  const int64_t ne = c->n_elem;
+  const int64_t nx = (int64_t)conn[1] - conn[0];
+  if (nx < 2 || conn[3] != conn[0] + 1) return PYN_OK;
+  const int64_t ex = nx - 1;
+  if (ne % ex) return PYN_OK;
+  // rows of elements per layer: the first element row that does not continue the bottom plane of layer 0
+  int64_t ey = 0;
+  for (int64_t j = 0; j * ex < ne; ++j) {
+    if (conn[j * ex * 8] != conn[0] + j * nx) break;
+    ey = j + 1;
+  }
+  if (ey < 1 || (ne / ex) % ey) return PYN_OK;
+  const int64_t ny = ey + 1, ezl = ne / (ex * ey), npl = ezl + 1, nxny = nx * ny;
+  if (nxny * npl != c->n_node || nxny > INT32_MAX / 2) return PYN_OK;
+  std::vector<int32_t> P((size_t)npl);
+  for (int64_t l = 0; l < ezl; ++l) {
+    const int32_t* e0 = conn + l * ex * ey * 8;
+    P[l] = e0[0];
+    if (l + 1 == ezl) P[l + 1] = e0[4];
+    if (l > 0 && P[l] != conn[(l - 1) * ex * ey * 8 + 4]) return PYN_OK;
+  }
+  for (int64_t l = 0; l < ezl; ++l)
+    for (int64_t iy = 0; iy < ey; ++iy)
+      for (int64_t ix = 0; ix < ex; ++ix) {
+        const int32_t* q = conn + ((l * ey + iy) * ex + ix) * 8;
+        const int32_t lo = (int32_t)(P[l] + iy * nx + ix), hi = (int32_t)(P[l + 1] + iy * nx + ix);
+        if (q[0] != lo || q[1] != lo + nx || q[2] != lo + nx + 1 || q[3] != lo + 1 || q[4] != hi || q[5] != hi + 1 ||
+            q[6] != hi + nx + 1 || q[7] != hi + nx)
+          return PYN_OK;
+      }
+  // planes are disjoint blocks of nx*ny ids; the owned ones are consecutive in z and carry ids 0..n_owned-1
+  std::vector<int32_t> sorted(P);
+  std::sort(sorted.begin(), sorted.end());
+  for (int64_t j = 0; j < npl; ++j)
+    if (sorted[j] != j * nxny) return PYN_OK;
+  if (c->n_owned % nxny) return PYN_OK;
+  const int n_own = (int)(c->n_owned / nxny);
+  int p0 = -1;
+  for (int64_t j = 0; j < npl; ++j)
+    if (P[j] == 0) p0 = (int)j;
+  if (p0 < 0 || p0 + n_own > npl) return PYN_OK;
+  for (int j = 0; j < n_own; ++j)
+    if (P[p0 + j] != (int64_t)j * nxny) return PYN_OK;
+  std::vector<int32_t> zord((size_t)npl);
+  for (int64_t j = 0; j < npl; ++j) {
+    int dz[3], n = 0;
+    for (int d = -1; d <= 1; ++d)
+      if (j + d >= 0 && j + d < npl) dz[n++] = d;
+    std::sort(dz, dz + n, [&](int a, int b2) { return P[j + a] < P[j + b2]; });
+    int code = n;
+    for (int i = 0; i < n; ++i) code |= (dz[i] + 1) << (2 + 2 * i);
+    zord[j] = code;
+  }
+  PYN_HIP(hipMalloc((void**)&L.d_P, npl * sizeof(int32_t)));
+  PYN_HIP(hipMalloc((void**)&L.d_zord, npl * sizeof(int32_t)));
+  PYN_HIP(hipMemcpy(L.d_P, P.data(), npl * sizeof(int32_t), hipMemcpyHostToDevice));
+  PYN_HIP(hipMemcpy(L.d_zord, zord.data(), npl * sizeof(int32_t), hipMemcpyHostToDevice));
+  L.nx = (int)nx;
+  L.ny = (int)ny;
+  L.npl = (int)npl;
+  L.p_own0 = p0;
+  L.n_own = n_own;
+  // does the numbering have the arithmetic shape lat_plane / lat_zcode assume (one rank, or a rank's z-slab)?
+  L.std_shape = true;
+  for (int64_t j = 0; j < npl && L.std_shape; ++j) {
+    int64_t want;
+    if (j < p0) want = (n_own + j) * nxny;
+    else if (j >= p0 + n_own) want = (n_own + p0 + (j - p0 - n_own)) * nxny;
+    else want = (j - p0) * nxny;
+    L.std_shape = P[j] == want;
+  }
+  L.valid = true;
+  return PYN_OK;
+}
+
+template <int TX, int TY, int TZ>
+static int launch_lattice(pyn_ctx* c, LatArgs& T, bool affine) {
+  using LT = LatTile<TX, TY, TZ>;
+  T.ntx = (T.nx + TX - 1) / TX;
+  T.nty = (T.ny + TY - 1) / TY;
+  const int ntz = (T.n_own + TZ - 1) / TZ;
+  const int n_tiles = T.ntx * T.nty * ntz;
+  static bool attr_done = false;
+  if (!attr_done) {
+    PYN_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(assemble_q1_hex_lattice_kernel<TX, TY, TZ, false>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)LT::BYTES));
+    PYN_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(assemble_q1_hex_lattice_kernel<TX, TY, TZ, true>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)LT::BYTES));
+    attr_done = true;
+  }
+  if (affine)
+    assemble_q1_hex_lattice_kernel<TX, TY, TZ, true><<<n_tiles, TILE_THREADS, LT::BYTES, c->stream>>>(T);
+  else
+    assemble_q1_hex_lattice_kernel<TX, TY, TZ, false><<<n_tiles, TILE_THREADS, LT::BYTES, c->stream>>>(T);
+  PYN_HIP(hipGetLastError());
+  return PYN_OK;
+}
+
+// lattice descriptor -> kernel arguments (+ the one-off verification that index arithmetic may replace the loads)
+static int lat_fill_args(pyn_ctx* c, LatArgs& T, double* A, double* Arhs, int* mesh_aff) {
+  Lattice& L = c->lat;
+  T.xyz = c->d_xyz;
+  T.rowptr = c->d_rowptr;
+  T.bcmask = c->d_bcmask;
+  T.P = L.d_P;
+  T.zord = L.d_zord;
+  T.nx = L.nx;
+  T.ny = L.ny;
+  T.npl = L.npl;
+  T.p_own0 = L.p_own0;
+  T.n_own = L.n_own;
+  T.ntx = T.nty = 0;
+  T.std_lat = 0;
+  T.q = TileArgs();
+  T.q.w = c->quad[0].w;
+  T.q.hrs = c->quad[0].Hrs;
+  T.q.hcoo = c->quad[0].HrsCoo;
+  T.q.aff = getenv("PYNAMA_NO_AFFINE") ? nullptr : c->d_aff;
+  T.A = A;
+  T.Arhs = Arhs;
+  const char* ab = getenv("PYNAMA_LATTICE_ABLATE");  // diagnostics: 1 = no element phase, 4 = no plain-tile store path
+  T.ablate = ab ? atoi(ab) : 0;
+  PYN_TRY(pyn_mesh_all_affine(c, mesh_aff));
+  if (L.std_ok < 0) {      // once per graph: may the index arithmetic replace P / zord / rowptr?
+    L.std_ok = 0;
+    if (L.std_shape && !getenv("PYNAMA_NO_STD_LATTICE")) {
+      DevTmp flag;
+      PYN_HIP(flag.alloc(sizeof(int)));
+      const int one = 1;
+      PYN_HIP(hipMemcpyAsync(flag.p, &one, sizeof(int), hipMemcpyHostToDevice, c->stream));
+      LatArgs Tc = T;
+      Tc.std_lat = 1;
+      lattice_rowptr_check_kernel<<<(int)((c->n_owned + 255) / 256), 256, 0, c->stream>>>(Tc, c->d_rowptr, c->n_owned, flag.as<int>());
+      int h = 0;
+      PYN_HIP(hipMemcpyAsync(&h, flag.p, sizeof(int), hipMemcpyDeviceToHost, c->stream));
+      PYN_HIP(hipStreamSynchronize(c->stream));
+      L.std_ok = h;
+    }
+  }
+  T.std_lat = L.std_ok == 1;
+  return PYN_OK;
+}
+
+template <int TX, int TY, int TZ>
+static int launch_kle_lattice(pyn_ctx* c, KleLatArgs& T, double* K, double* Krhs, double* Rw) {
+  using LT = LatTile<TX, TY, TZ>;
+  T.L.ntx = (T.L.nx + TX - 1) / TX;
+  T.L.nty = (T.L.ny + TY - 1) / TY;
+  const int n_tiles = T.L.ntx * T.L.nty * ((T.L.n_own + TZ - 1) / TZ);
+  const size_t lds = (size_t)LT::NR * 243 * sizeof(double) + LT::META_INTS * sizeof(int);
+  static bool attr_done = false;
+  if (!attr_done) {
+    PYN_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(assemble_q1_hex_kle_lattice_kernel<TX, TY, TZ, false>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    PYN_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(assemble_q1_hex_kle_lattice_kernel<TX, TY, TZ, true>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    attr_done = true;
+  }
+  if (K) {
+    T.L.A = K;
+    T.L.Arhs = Krhs;
+    assemble_q1_hex_kle_lattice_kernel<TX, TY, TZ, false><<<n_tiles, 256, lds, c->stream>>>(T);
+  }
+  if (Rw) {
+    T.L.A = Rw;
+    T.L.Arhs = nullptr;
+    assemble_q1_hex_kle_lattice_kernel<TX, TY, TZ, true><<<n_tiles, 256, lds, c->stream>>>(T);
+  }
+  PYN_HIP(hipGetLastError());
+  return PYN_OK;
+}
+
+// KLE on lattices of parallelepipeds (the reference's box meshes): plan-free kernels
+int pyn_assemble_kle_lattice(pyn_ctx* c, double alpha_d, double alpha_w, double* K, double* Krhs, double* Rw, bool* handled) {
+  if (!c->lat.valid || c->quad[0].ngp != 8 || c->quad[1].ngp != 1 || !c->aff_standard || !c->aff_rw_standard ||
+      getenv("PYNAMA_NO_AFFINE") || getenv("PYNAMA_NO_KLE_LATTICE"))
+    return PYN_OK;
+  KleLatArgs T;
+  int mesh_aff = 0;
+  PYN_TRY(lat_fill_args(c, T.L, nullptr, nullptr, &mesh_aff));
+  if (!mesh_aff) return PYN_OK;   // general geometry: the patch-plan kernels with quadrature
+  T.alpha_d = alpha_d;
+  T.alpha_w = alpha_w;
+  T.wr = c->quad[1].w;
+  T.hrsr = c->quad[1].Hrs;
+  T.Hr = c->quad[1].H;
+  T.hcoor = c->quad[1].HrsCoo;
+  const char* tl = getenv("PYNAMA_KLE_LATTICE_TILE");
+  switch (tl ? atoi(tl) : 0) {
+    case 1: PYN_TRY((launch_kle_lattice<6, 2, 2>(c, T, K, Krhs, Rw))); break;
+    case 2: PYN_TRY((launch_kle_lattice<3, 3, 2>(c, T, K, Krhs, Rw))); break;
+    case 3: PYN_TRY((launch_kle_lattice<4, 3, 3>(c, T, K, Krhs, Rw))); break;
+    default: PYN_TRY((launch_kle_lattice<3, 3, 3>(c, T, K, Krhs, Rw))); break;
+  }
+  *handled = true;
+  return PYN_OK;
+}
+
+int pyn_assemble_lattice(pyn_ctx* c, double* A, double* Arhs, bool* handled) {
+  Lattice& L = c->lat;
+  if (!L.valid || c->quad[0].ngp != 8) return PYN_OK;
+  LatArgs T;
+  int mesh_aff = 0;
+  PYN_TRY(lat_fill_args(c, T, A, Arhs, &mesh_aff));
+  const bool affine = mesh_aff == 1 && T.q.aff != nullptr && c->aff_standard;
+  // measured at 10M DOFs: parallelepipeds are store-bound -> small tiles, 5 workgroups per CU;
+  // the quadrature path is FP64-bound -> 7x7x7 tiles (least redundant integration that fits the LDS twice)
+  const char* tl = getenv("PYNAMA_LATTICE_TILE");
+  const int sel = tl ? atoi(tl) : (affine ? 0 : 1);
+  switch (sel) {
+    case 1: PYN_TRY((launch_lattice<7, 7, 7>(c, T, affine))); break;
+    case 2: PYN_TRY((launch_lattice<6, 6, 6>(c, T, affine))); break;
+    case 3: PYN_TRY((launch_lattice<8, 6, 6>(c, T, affine))); break;
+    case 4: PYN_TRY((launch_lattice<7, 6, 6>(c, T, affine))); break;
+    case 5: PYN_TRY((launch_lattice<6, 6, 4>(c, T, affine))); break;
+    case 6: PYN_TRY((launch_lattice<6, 5, 5>(c, T, affine))); break;
+    case 7: PYN_TRY((launch_lattice<7, 4, 4>(c, T, affine))); break;
+    case 8: PYN_TRY((launch_lattice<14, 3, 3>(c, T, affine))); break;
+    case 9: PYN_TRY((launch_lattice<7, 5, 5>(c, T, affine))); break;
+    default: PYN_TRY((launch_lattice<7, 5, 4>(c, T, affine))); break;
+  }
+  *handled = true;
+  return PYN_OK;
+}
+

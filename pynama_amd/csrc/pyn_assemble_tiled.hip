@@ -17,12 +17,12 @@
 #include <hipcub/hipcub.hpp>
 
 #include "pyn_internal.h"
+#include "pyn_q1_hex.h"
 
 namespace {
 
 constexpr int KLE_MAX_ROWS = 36;      // 4*3*3 node tiles: 36 rows * 27 cols * 9 * 8 B = 70 KB of LDS
 constexpr int PATCH_MAX_ROWS = 352;   // 7*7*7 = 343 rows -> 74 KB of LDS accumulators at 27 cols
-constexpr int TILE_THREADS = 256;
 
 __device__ inline int find_slot_t(const int32_t* __restrict__ colidx, int lo, int len, int col) {
   int l = 0, h = len;
@@ -121,158 +121,6 @@ __global__ void plan_fill_kernel(const unsigned long long* __restrict__ keys, in
 }
 
 // ---- the numeric kernel -------------------------------------------------------------------------
-struct TileArgs {
-  const int32_t* conn;
-  const double* xyz;
-  const int32_t* rowptr;
-  const int32_t* colidx;
-  const uint8_t* bcmask;  // per node (scalar forms), may be null
-  const uint8_t* colbc;   // per CSR entry: column node imposed (null iff bcmask null)
-  const int32_t* p_rowptr;
-  const int32_t* p_rows;
-  const int32_t* p_eptr;
-  const int32_t* p_elem;
-  const uint4* rowslot4;
-  const uint4* kmap4;
-  int64_t npe;
-  int n_patch;
-  int maxlen;           // max CSR row length (27)
-  int maxrows;          // max rows per patch (LDS layout)
-  const double* w;      // full rule [8]
-  const double* hrs;    // [8][3][8]  reference gradients of the nodal basis at the Gauss points
-  const double* hcoo;   // [8][3][8]  reference gradients of the geometry (corner) basis
-  const double* aff;    // [6][36] affine reference matrices + [4][8] monomial signs (null: shortcut off)
-  double* A;            // values for free columns
-  double* Arhs;         // -values for imposed columns (may be null)
-};
-
-// One Gauss point: J = hcoo.X, Ji = J^-1, c = w detJ, G = Ji.hrs, L += c G^T G (upper triangle).
-__device__ __forceinline__ void gauss_point(const TileArgs& T, const int G, const double (&X)[8][3], double (&L)[36]) {
-  const double* __restrict__ hc = T.hcoo + G * 24;
-  const double* __restrict__ hr = T.hrs + G * 24;
-  double J[3][3];
-#pragma unroll
-  for (int d = 0; d < 3; ++d)
-#pragma unroll
-    for (int x = 0; x < 3; ++x) {
-      double s = 0.0;
-#pragma unroll
-      for (int c = 0; c < 8; ++c) s = fma(hc[d * 8 + c], X[c][x], s);
-      J[d][x] = s;
-    }
-  const double c00 = J[1][1] * J[2][2] - J[1][2] * J[2][1];
-  const double c01 = J[1][2] * J[2][0] - J[1][0] * J[2][2];
-  const double c02 = J[1][0] * J[2][1] - J[1][1] * J[2][0];
-  const double det = J[0][0] * c00 + J[0][1] * c01 + J[0][2] * c02;
-  const double r = 1.0 / det;
-  double Ji[3][3];
-  Ji[0][0] = c00 * r;
-  Ji[0][1] = (J[0][2] * J[2][1] - J[0][1] * J[2][2]) * r;
-  Ji[0][2] = (J[0][1] * J[1][2] - J[0][2] * J[1][1]) * r;
-  Ji[1][0] = c01 * r;
-  Ji[1][1] = (J[0][0] * J[2][2] - J[0][2] * J[2][0]) * r;
-  Ji[1][2] = (J[0][2] * J[1][0] - J[0][0] * J[1][2]) * r;
-  Ji[2][0] = c02 * r;
-  Ji[2][1] = (J[0][1] * J[2][0] - J[0][0] * J[2][1]) * r;
-  Ji[2][2] = (J[0][0] * J[1][1] - J[0][1] * J[1][0]) * r;
-  const double cw = T.w[G] * det;
-  double Gm[3][8];
-#pragma unroll
-  for (int d = 0; d < 3; ++d)
-#pragma unroll
-    for (int a = 0; a < 8; ++a) {
-      double s = Ji[d][0] * hr[a];
-      s = fma(Ji[d][1], hr[8 + a], s);
-      s = fma(Ji[d][2], hr[16 + a], s);
-      Gm[d][a] = s;
-    }
-  int idx = 0;
-#pragma unroll
-  for (int a = 0; a < 8; ++a) {
-    const double g0 = cw * Gm[0][a], g1 = cw * Gm[1][a], g2 = cw * Gm[2][a];
-#pragma unroll
-    for (int b = a; b < 8; ++b) {
-      double s = L[idx];
-      s = fma(g0, Gm[0][b], s);
-      s = fma(g1, Gm[1][b], s);
-      s = fma(g2, Gm[2][b], s);
-      L[idx++] = s;
-    }
-  }
-}
-
-// Affine shortcut: for a parallelepiped J is constant and the 2x2x2 rule integrates the (quadratic)
-// integrand exactly, so L_ab = detJ * sum_{r<=s} Q_rs T_rs[ab] with Q = J^-T J^-1 -- ~350 instead of
-// ~2500 FP64 operations.  `affine` is decided per element from the non-affine trilinear modes.
-__device__ __forceinline__ bool element_is_affine(const TileArgs& T, const double (&X)[8][3]) {
-  const double* __restrict__ sg = T.aff + 216;
-  double na = 0.0, h2 = 0.0;
-#pragma unroll
-  for (int m = 0; m < 4; ++m)
-#pragma unroll
-    for (int x = 0; x < 3; ++x) {
-      double c = 0.0;
-#pragma unroll
-      for (int a = 0; a < 8; ++a) c = fma(sg[m * 8 + a], X[a][x], c);
-      na = fma(c, c, na);
-    }
-#pragma unroll
-  for (int x = 0; x < 3; ++x) {  // squared edge scale: (x_6 - x_0) carries all three affine modes
-    const double d = X[6][x] - X[0][x];
-    h2 = fma(d, d, h2);
-  }
-  return na <= 1e-25 * h2;  // non-affine modes below ~3e-13 of the element size: coordinate round-off
-}
-
-__device__ __forceinline__ void affine_laplace(const TileArgs& T, const double (&X)[8][3], double (&L)[36]) {
-  const double* __restrict__ hc = T.hcoo;  // any Gauss point: J is constant
-  double J[3][3];
-#pragma unroll
-  for (int d = 0; d < 3; ++d)
-#pragma unroll
-    for (int x = 0; x < 3; ++x) {
-      double s = 0.0;
-#pragma unroll
-      for (int c = 0; c < 8; ++c) s = fma(hc[d * 8 + c], X[c][x], s);
-      J[d][x] = s;
-    }
-  const double c00 = J[1][1] * J[2][2] - J[1][2] * J[2][1];
-  const double c01 = J[1][2] * J[2][0] - J[1][0] * J[2][2];
-  const double c02 = J[1][0] * J[2][1] - J[1][1] * J[2][0];
-  const double det = J[0][0] * c00 + J[0][1] * c01 + J[0][2] * c02;
-  const double r = 1.0 / det;
-  double Ji[3][3];  // Ji[x][d]: physical axis x, reference axis d   (G = Ji . hr)
-  Ji[0][0] = c00 * r;
-  Ji[0][1] = (J[0][2] * J[2][1] - J[0][1] * J[2][2]) * r;
-  Ji[0][2] = (J[0][1] * J[1][2] - J[0][2] * J[1][1]) * r;
-  Ji[1][0] = c01 * r;
-  Ji[1][1] = (J[0][0] * J[2][2] - J[0][2] * J[2][0]) * r;
-  Ji[1][2] = (J[0][2] * J[1][0] - J[0][0] * J[1][2]) * r;
-  Ji[2][0] = c02 * r;
-  Ji[2][1] = (J[0][1] * J[2][0] - J[0][0] * J[2][1]) * r;
-  Ji[2][2] = (J[0][0] * J[1][1] - J[0][1] * J[1][0]) * r;
-  double Q[6];
-  const int RS[6][2] = {{0, 0}, {1, 1}, {2, 2}, {0, 1}, {0, 2}, {1, 2}};
-#pragma unroll
-  for (int t = 0; t < 6; ++t) {
-    const int a = RS[t][0], b = RS[t][1];
-    Q[t] = det * (Ji[0][a] * Ji[0][b] + Ji[1][a] * Ji[1][b] + Ji[2][a] * Ji[2][b]);
-  }
-  const double* __restrict__ Tm = T.aff;
-#pragma unroll
-  for (int i = 0; i < 36; ++i) {
-    double s = Q[0] * Tm[i];
-#pragma unroll
-    for (int t = 1; t < 6; ++t) s = fma(Q[t], Tm[t * 36 + i], s);
-    L[i] = s;
-  }
-}
-
-__device__ inline int tri(int a, int b) {  // index of (min,max) in the packed upper triangle of 8x8
-  int i = a < b ? a : b, j = a < b ? b : a;
-  return i * 8 - (i * (i - 1)) / 2 + (j - i);
-}
-
 template <int ABLATE>
 __global__ void __launch_bounds__(TILE_THREADS, 2) assemble_q1_hex_tiled_kernel(TileArgs T) {
   extern __shared__ __align__(16) double acc[];  // [maxrows][maxlen] accumulators, then per-row meta
@@ -434,458 +282,6 @@ __global__ void __launch_bounds__(TILE_THREADS, 2) assemble_q1_hex_tiled_kernel(
 
 
 // =================================================================================================
-// Plan-free variant for meshes with STRUCTURED topology (box meshes: the reference's primary mesh,
-// DMPlexDom.createBoxMesh, src/domain/dmplex.py:8-21; a rank's z-slab of one included).  Same scheme
-// as the patch kernel -- a workgroup owns a TX x TY x TZ tile of rows, integrates every element touching
-// it (one per lane), accumulates in LDS, writes each CSR row once -- but every index comes from integer
-// arithmetic on the lattice descriptor instead of from HBM: no element list, no row-slot / scatter-map
-// stream (84 B per patch-element in the plan), no dependent load chains in front of the stores.
-// LDS accumulators use a fixed 27-point stencil layout acc[row][(dz+1)*9 + (dy+1)*3 + (dx+1)], so the
-// LDS address of pair (a, b) is row_slot(a)*27 + a compile-time constant; the store phase maps CSR slot
-// k of a row (columns sorted by node id: z-plane order from `zord`, then y, then x, clipped at the
-// domain faces) back to the stencil position.
-struct LatArgs {
-  const double* xyz;
-  const int32_t* rowptr;
-  const uint8_t* bcmask;   // per node, may be null
-  const int32_t* P;        // [npl] first node id of every z-plane
-  const int32_t* zord;     // [npl]
-  int nx, ny, npl, p_own0, n_own;
-  int ntx, nty;            // tiles per direction
-  int std_lat;             // P[j] == j*nx*ny, all planes owned, standard z order: plane bases, z codes AND row offsets
-                           // come from arithmetic (no index loads at all)
-  int ablate;              // diagnostics (PYNAMA_LATTICE_ABLATE): 1 no element phase, 2 no LDS adds, 3 no coordinate loads
-  TileArgs q;              // quadrature tables (w, hrs, hcoo, aff) -- only those fields are used
-  double* A;
-  double* Arhs;
-};
-
-template <int TX, int TY, int TZ>
-struct LatTile {
-  static constexpr int NR = TX * TY * TZ, EX = TX + 1, EY = TY + 1, EZ = TZ + 1, NE = EX * EY * EZ;
-  static constexpr int BX = TX + 2, BY = TY + 2, BZ = TZ + 2, NB = BX * BY * BZ;
-  static constexpr int ACC = NR * 27;                                  // doubles
-  static constexpr int META_INTS = NR + TZ + (NB + 3) / 4;             // rlo[NR], zrd[TZ], nbc[NB] bytes
-  static constexpr size_t BYTES = ACC * sizeof(double) + META_INTS * sizeof(int);
-};
-
-// First node id of z-plane j.  Arithmetic form (std_lat): the owned planes carry the ids 0 .. n_owned-1 in z
-// order, the ghost planes below them follow, then the ghost planes above (the numbering of a rank's z-slab; on one
-// rank simply j*nx*ny).  pyn_lattice_detect verified that the uploaded numbering has this shape.
-__device__ __forceinline__ int lat_plane(const LatArgs& T, int j) {
-  if (!T.std_lat) return T.P[j];
-  const int pp = T.nx * T.ny, lo = T.p_own0, hi = T.p_own0 + T.n_own;
-  if (j < lo) return (T.n_own + j) * pp;
-  if (j >= hi) return (T.n_own + lo + (j - hi)) * pp;
-  return (j - lo) * pp;
-}
-
-// CSR offset of the row of owned node (x, y, owned plane zo): rows in id order, len = cx cy cz with c = 3 minus
-// the domain faces the node sits on (a slab interface is not a face: its ghost plane supplies the columns);
-// sum_{x' < x} cx(x') = 3x - (x > 0), sum over a whole line = 3 nx - 2.  Verified against the graph's rowptr.
-__device__ __forceinline__ int lat_rowptr_std(const LatArgs& T, int x, int y, int zo) {
-  const int sx = 3 * T.nx - 2, sy = 3 * T.ny - 2;
-  const bool bot = T.p_own0 == 0, top = T.p_own0 + T.n_own == T.npl;   // does the slab hold the domain's end planes?
-  const int cy = 3 - (y == 0) - (y == T.ny - 1), cz = 3 - (bot && zo == 0) - (top && zo == T.n_own - 1);
-  return (3 * zo - (bot && zo > 0)) * sy * sx + cz * ((3 * y - (y > 0)) * sx + cy * (3 * x - (x > 0)));
-}
-
-// z-order code of OWNED plane pl: the existing z-neighbours sorted by node id -- owned planes first (ascending),
-// then the ghost plane below, then the ghost plane above
-__device__ __forceinline__ int lat_zcode(const LatArgs& T, int pl) {
-  if (!T.std_lat) return T.zord[pl];
-  const int lo = T.p_own0, hi = T.p_own0 + T.n_own;
-  const bool has_dn = pl > 0, has_up = pl < T.npl - 1;
-  const bool dn_ghost = has_dn && pl - 1 < lo, up_ghost = has_up && pl + 1 >= hi;
-  int code = 0, n = 0;
-  if (has_dn && !dn_ghost) code |= 0 << (2 + 2 * n++);
-  code |= 1 << (2 + 2 * n++);
-  if (has_up && !up_ghost) code |= 2 << (2 + 2 * n++);
-  if (dn_ghost) code |= 0 << (2 + 2 * n++);
-  if (up_ghost) code |= 2 << (2 + 2 * n++);
-  return code | n;
-}
-
-// Row offsets and Dirichlet flags of a tile, in two steps so that their HBM latency hides behind the element
-// phase: lat_meta_load issues the loads into registers before it, lat_meta_commit writes them to LDS after it.
-template <int TX, int TY, int TZ, int NT>
-struct LatMeta {
-  using L = LatTile<TX, TY, TZ>;
-  static constexpr int NF = (L::NB + NT - 1) / NT, NRW = (L::NR + NT - 1) / NT;
-  unsigned char f[NF];
-  int r[NRW];
-};
-
-template <int TX, int TY, int TZ, int NT, int NDOF = 1>
-__device__ __forceinline__ void lat_meta_load(const LatArgs& T, int x0, int y0, int z0, int t, LatMeta<TX, TY, TZ, NT>& M) {
-  using L = LatTile<TX, TY, TZ>;
-  const int nx = T.nx, ny = T.ny;
-#pragma unroll
-  for (int j = 0; j < LatMeta<TX, TY, TZ, NT>::NF; ++j) {
-    const int i = t + j * NT;
-    const int qx = i % L::BX, qy = (i / L::BX) % L::BY, qz = i / (L::BX * L::BY);
-    const int x = x0 - 1 + qx, y = y0 - 1 + qy, pl = T.p_own0 + z0 - 1 + qz;
-    const bool ok = T.bcmask && i < L::NB && x >= 0 && x < nx && y >= 0 && y < ny && pl >= 0 && pl < T.npl;
-    unsigned char f = 0;   // bit q: DOF q of the node imposed
-    if (ok) {
-      const int64_t node = lat_plane(T, pl) + y * nx + x;
-#pragma unroll
-      for (int q = 0; q < NDOF; ++q) f |= (T.bcmask[node * NDOF + q] ? 1 : 0) << q;
-    }
-    M.f[j] = f;
-  }
-#pragma unroll
-  for (int j = 0; j < LatMeta<TX, TY, TZ, NT>::NRW; ++j) {
-    const int s = t + j * NT;
-    const int rx = s % TX, ry = (s / TX) % TY, rz = s / (TX * TY);
-    const int x = x0 + rx, y = y0 + ry, zo = z0 + rz;
-    const bool ok = s < L::NR && x < nx && y < ny && zo < T.n_own;
-    M.r[j] = !ok ? -1 : (T.std_lat ? lat_rowptr_std(T, x, y, zo) : T.rowptr[T.P[T.p_own0 + zo] + y * nx + x]);
-  }
-}
-
-template <int TX, int TY, int TZ, int NT>
-__device__ __forceinline__ int lat_meta_commit(const LatArgs& T, int z0, int t, const LatMeta<TX, TY, TZ, NT>& M, int* rlo, int* zrd,
-                                               unsigned char* nbc) {
-  using L = LatTile<TX, TY, TZ>;
-  int any = 0;
-#pragma unroll
-  for (int j = 0; j < LatMeta<TX, TY, TZ, NT>::NF; ++j)
-    if (t + j * NT < L::NB) {
-      nbc[t + j * NT] = M.f[j];
-      any |= M.f[j];
-    }
-#pragma unroll
-  for (int j = 0; j < LatMeta<TX, TY, TZ, NT>::NRW; ++j)
-    if (t + j * NT < L::NR) rlo[t + j * NT] = M.r[j];
-  if (t < TZ) zrd[t] = (z0 + t < T.n_own) ? lat_zcode(T, T.p_own0 + z0 + t) : 0;
-  return any;
-}
-
-// integrate every element touching the tile (one per lane) and add the rows the tile owns into acc
-template <int TX, int TY, int TZ>
-__device__ __forceinline__ void lat_integrate(const LatArgs& T, int x0, int y0, int z0, double* acc, int t0, int nt) {
-  using LT = LatTile<TX, TY, TZ>;
-  const int nx = T.nx, ny = T.ny;
-  // corner offsets (dx, dy, dz) in the reference's closure order
-  constexpr int CX[8] = {0, 0, 1, 1, 0, 1, 1, 0};
-  constexpr int CY[8] = {0, 1, 1, 0, 0, 0, 1, 1};
-  constexpr int CZ[8] = {0, 0, 0, 0, 1, 1, 1, 1};
-  for (int t = t0; t < LT::NE; t += nt) {
-    const int lx = t % LT::EX, ly = (t / LT::EX) % LT::EY, lz = t / (LT::EX * LT::EY);
-    const int gx = x0 - 1 + lx, gy = y0 - 1 + ly, gl = T.p_own0 + z0 - 1 + lz;
-    if (gx < 0 || gx >= nx - 1 || gy < 0 || gy >= ny - 1 || gl < 0 || gl >= T.npl - 1) continue;
-    const int n00 = gy * nx + gx;
-    const int pb = lat_plane(T, gl) + n00, pt = lat_plane(T, gl + 1) + n00;
-    double X[8][3];
-#pragma unroll
-    for (int a = 0; a < 8; ++a) {
-      const int node = (CZ[a] ? pt : pb) + CY[a] * nx + CX[a];
-      const double* q = T.xyz + (int64_t)node * 3;
-      X[a][0] = q[0];
-      X[a][1] = q[1];
-      X[a][2] = q[2];
-    }
-    double L[36];
-    if (T.q.aff && __all(element_is_affine(T.q, X) ? 1 : 0)) {
-      affine_laplace(T.q, X, L);
-    } else {
-#pragma unroll
-      for (int i = 0; i < 36; ++i) L[i] = 0.0;
-#pragma nounroll
-      for (int g = 0; g < 8; ++g) gauss_point(T.q, g, X, L);
-    }
-#pragma unroll
-    for (int a = 0; a < 8; ++a) {
-      const int rx = lx - 1 + CX[a], ry = ly - 1 + CY[a], rz = lz - 1 + CZ[a];
-      // the row exists in x, y (the element does); in z it must be one of this tile's OWNED planes
-      if (rx < 0 || rx >= TX || ry < 0 || ry >= TY || rz < 0 || rz >= TZ || z0 + rz >= T.n_own) continue;
-      double* row = acc + ((rz * TY + ry) * TX + rx) * 27;
-#pragma unroll
-      for (int c = 0; c < 8; ++c) {
-        const int kk = (CZ[c] - CZ[a] + 1) * 9 + (CY[c] - CY[a] + 1) * 3 + (CX[c] - CX[a] + 1);
-        atomicAdd(&row[kk], L[tri(a, c)]);
-      }
-    }
-  }
-}
-
-// write every row of the tile once (half a wave per row, UNROLL rows in flight): A gets the free columns,
-// Arhs the imposed ones (negated), imposed rows become identity rows (mat_generator.py:113-118).
-// ZERO: clear each accumulator after reading it (the buffer is reused by the next tile).
-template <int TX, int TY, int TZ>
-__device__ __forceinline__ void lat_store(const LatArgs& T, int x0, int y0, const double* acc, const int* rlo, const int* zrd,
-                                          const unsigned char* nbc, int t, int nt) {
-  using LT = LatTile<TX, TY, TZ>;
-  const int nx = T.nx, ny = T.ny;
-  double* __restrict__ outA = T.A;
-  double* __restrict__ outR = T.Arhs;
-  const int half = t >> 5, k = t & 31;
-  const int NH = nt >> 5;
-  constexpr int UNROLL = 4;
-  // branch-free per row: the LDS reads of the UNROLL rows are independent of each other, so they overlap
-  for (int s0 = half; s0 < LT::NR; s0 += NH * UNROLL) {
-    int lo[UNROLL], ai[UNROLL], bi[UNROLL], bo[UNROLL];
-    bool diag[UNROLL];
-#pragma unroll
-    for (int u = 0; u < UNROLL; ++u) {
-      const int s = min(s0 + u * NH, LT::NR - 1);
-      const int rl = rlo[s];
-      const int rx = s % TX, ry = (s / TX) % TY, rz = s / (TX * TY);
-      const int x = x0 + rx, y = y0 + ry;
-      const int zi = zrd[rz];
-      const int cx = 3 - (x == 0) - (x == nx - 1), cy = 3 - (y == 0) - (y == ny - 1), cz = zi & 3;
-      const int cc = cx * cy;
-      const bool act = (s0 + u * NH < LT::NR) && rl >= 0 && k < cc * cz;
-      const int kz = (k >= cc) + (k >= 2 * cc);
-      const int r = k - kz * cc;
-      const int ky = (r >= cx) + (r >= 2 * cx);
-      const int kx = r - ky * cx;
-      const int dz = act ? ((zi >> (2 + 2 * kz)) & 3) - 1 : 0;
-      const int dy = act ? ky - (y != 0) : 0, dx = act ? kx - (x != 0) : 0;
-      ai[u] = s * 27 + (dz + 1) * 9 + (dy + 1) * 3 + (dx + 1);
-      bi[u] = ((rz + 1) * LT::BY + ry + 1) * LT::BX + rx + 1;
-      bo[u] = bi[u] + (dz * LT::BY + dy) * LT::BX + dx;
-      diag[u] = dx == 0 && dy == 0 && dz == 0;
-      lo[u] = act ? rl + k : -1;
-    }
-    double v[UNROLL];
-    unsigned char fr[UNROLL], fc[UNROLL];
-#pragma unroll
-    for (int u = 0; u < UNROLL; ++u) {
-      v[u] = acc[ai[u]];
-      fr[u] = nbc[bi[u]];
-      fc[u] = nbc[bo[u]];
-    }
-#pragma unroll
-    for (int u = 0; u < UNROLL; ++u) {
-      const double va = fr[u] ? (diag[u] ? 1.0 : 0.0) : (fc[u] ? 0.0 : v[u]);
-      const double vr = fr[u] ? (diag[u] ? 1.0 : 0.0) : (fc[u] ? -v[u] : 0.0);
-      if (lo[u] >= 0) {
-        outA[lo[u]] = va;
-        if (outR) outR[lo[u]] = vr;
-      }
-    }
-  }
-}
-
-// Store phase of a "plain" tile -- no row on a domain face, the three z-neighbour planes in ascending id order,
-// no imposed node in the node box: CSR slot k of a row IS stencil position k, and the TX rows of an x-line are
-// one contiguous run of TX*27 doubles both in LDS and in the CSR value array.  Straight coalesced copy.
-constexpr int ZCODE_STD = 3 | (0 << 2) | (1 << 4) | (2 << 6);
-template <int TX, int TY, int TZ>
-__device__ __forceinline__ void lat_store_plain(const LatArgs& T, const double* acc, const int* rlo, int t, int nt) {
-  constexpr int LINE = TX * 27, NL = TY * TZ, PER = (LINE + 63) / 64;
-  double* __restrict__ outA = T.A;
-  double* __restrict__ outR = T.Arhs;
-  const int w = t >> 6, lane = t & 63, nw = nt >> 6;
-  for (int l = w; l < NL; l += nw) {
-    const int base = rlo[l * TX];
-    double v[PER];
-#pragma unroll
-    for (int j = 0; j < PER; ++j) {
-      const int i = lane + 64 * j;
-      v[j] = (i < LINE) ? acc[l * LINE + i] : 0.0;
-    }
-#pragma unroll
-    for (int j = 0; j < PER; ++j) {
-      const int i = lane + 64 * j;
-      if (i < LINE) {
-        outA[base + i] = v[j];
-        if (outR) outR[base + i] = 0.0;
-      }
-    }
-  }
-}
-
-template <int TX, int TY, int TZ>
-__device__ __forceinline__ bool lat_tile_plain(const LatArgs& T, int x0, int y0, int z0, const int* zrd, int anybc) {
-  bool plain = !anybc && x0 >= 1 && x0 + TX <= T.nx - 1 && y0 >= 1 && y0 + TY <= T.ny - 1 && z0 + TZ <= T.n_own;
-  for (int j = 0; j < TZ; ++j) plain = plain && zrd[j] == ZCODE_STD;
-  return plain;
-}
-
-// 72 * T_rs[a][b] of the trilinear hexahedron in the reference's corner order, in closed form from the corner
-// signs s_d(a) (tensor product of the 1-D integrals  int N_i N_j = (3 + s_i s_j)/6,  int N_i' N_j' = s_i s_j/2,
-// int N_i' N_j = s_i/2):  rr: s_r(a)s_r(b)(3+s_p s_p)(3+s_q s_q);  rs: 3(3+s_u s_u)(s_r(a)s_s(b)+s_s(a)s_r(b)).
-// pyn_elem_tables_set checks the uploaded tables against it (lat_aff_standard) before the lean path is used.
-__host__ __device__ constexpr int q1_aff_int(int t, int a, int b) {
-  constexpr int SG[3][8] = {{-1, -1, 1, 1, -1, 1, 1, -1}, {-1, 1, 1, -1, -1, -1, 1, 1}, {-1, -1, -1, -1, 1, 1, 1, 1}};
-  constexpr int RS[6][2] = {{0, 0}, {1, 1}, {2, 2}, {0, 1}, {0, 2}, {1, 2}};
-  const int r = RS[t][0], s2 = RS[t][1];
-  if (r == s2) {
-    const int p = (r + 1) % 3, q = (r + 2) % 3;
-    return SG[r][a] * SG[r][b] * (3 + SG[p][a] * SG[p][b]) * (3 + SG[q][a] * SG[q][b]);
-  }
-  const int u = 3 - r - s2;
-  return 3 * (3 + SG[u][a] * SG[u][b]) * (SG[r][a] * SG[s2][b] + SG[s2][a] * SG[r][b]);
-}
-
-// 72 * int N_a d_d N_b over the reference cube = s_d(b) (3 + s_e(a)s_e(b)) (3 + s_f(a)s_f(b)), e, f the other axes
-// (pyn_elem_tables_set checks sum_g w_g H_g[a] Hrs_g[d][b] against it before the affine Rw path is used)
-__host__ __device__ constexpr int q1_mix_int(int d, int a, int b) {
-  constexpr int SG[3][8] = {{-1, -1, 1, 1, -1, 1, 1, -1}, {-1, 1, 1, -1, -1, -1, 1, 1}, {-1, -1, -1, -1, 1, 1, 1, 1}};
-  const int e = (d + 1) % 3, f = (d + 2) % 3;
-  return SG[d][b] * (3 + SG[e][a] * SG[e][b]) * (3 + SG[f][a] * SG[f][b]);
-}
-
-// Lean integration for meshes whose elements are ALL parallelepipeds (every box mesh the reference creates,
-// src/domain/dmplex.py:8-21): four corner loads instead of eight, J = S.E from the three edge vectors
-// (S[d][m] = sum_c hcoo[d][c] C_m[c], a table constant), L_ab = detJ sum_{r<=s} Q_rs T_rs[ab]; no quadrature
-// loop, no affinity test: ~110 VGPRs instead of ~170, i.e. 4 instead of 2-3 waves per SIMD to hide the gather
-// and store latencies.
-template <int TX, int TY, int TZ>
-__device__ __forceinline__ void lat_integrate_affine(const LatArgs& T, int x0, int y0, int z0, double* acc, int t0, int nt) {
-  using LT = LatTile<TX, TY, TZ>;
-  const int nx = T.nx, ny = T.ny;
-  const double* __restrict__ S = T.q.aff + 248;
-  constexpr int CX[8] = {0, 0, 1, 1, 0, 1, 1, 0};
-  constexpr int CY[8] = {0, 1, 1, 0, 0, 0, 1, 1};
-  constexpr int CZ[8] = {0, 0, 0, 0, 1, 1, 1, 1};
-  for (int t = t0; t < LT::NE; t += nt) {
-    const int lx = t % LT::EX, ly = (t / LT::EX) % LT::EY, lz = t / (LT::EX * LT::EY);
-    const int gx = x0 - 1 + lx, gy = y0 - 1 + ly, gl = T.p_own0 + z0 - 1 + lz;
-    if (gx < 0 || gx >= nx - 1 || gy < 0 || gy >= ny - 1 || gl < 0 || gl >= T.npl - 1) continue;
-    const int n00 = gy * nx + gx;
-    const double* q0 = T.xyz + (int64_t)(lat_plane(T, gl) + n00) * 3;
-    const double* qz = T.xyz + (int64_t)(lat_plane(T, gl + 1) + n00) * 3;
-    double E[3][3];  // edge vectors along the lattice x, y, z directions
-#pragma unroll
-    for (int x = 0; x < 3; ++x) {
-      const double o = q0[x];
-      E[0][x] = q0[3 + x] - o;
-      E[1][x] = q0[3 * nx + x] - o;
-      E[2][x] = qz[x] - o;
-    }
-    double J[3][3];
-#pragma unroll
-    for (int d = 0; d < 3; ++d)
-#pragma unroll
-      for (int x = 0; x < 3; ++x) J[d][x] = fma(S[d * 3 + 2], E[2][x], fma(S[d * 3 + 1], E[1][x], S[d * 3] * E[0][x]));
-    const double c00 = J[1][1] * J[2][2] - J[1][2] * J[2][1];
-    const double c01 = J[1][2] * J[2][0] - J[1][0] * J[2][2];
-    const double c02 = J[1][0] * J[2][1] - J[1][1] * J[2][0];
-    const double det = J[0][0] * c00 + J[0][1] * c01 + J[0][2] * c02;
-    const double r = 1.0 / det;
-    double Ji[3][3];
-    Ji[0][0] = c00 * r;
-    Ji[0][1] = (J[0][2] * J[2][1] - J[0][1] * J[2][2]) * r;
-    Ji[0][2] = (J[0][1] * J[1][2] - J[0][2] * J[1][1]) * r;
-    Ji[1][0] = c01 * r;
-    Ji[1][1] = (J[0][0] * J[2][2] - J[0][2] * J[2][0]) * r;
-    Ji[1][2] = (J[0][2] * J[1][0] - J[0][0] * J[1][2]) * r;
-    Ji[2][0] = c02 * r;
-    Ji[2][1] = (J[0][1] * J[2][0] - J[0][0] * J[2][1]) * r;
-    Ji[2][2] = (J[0][0] * J[1][1] - J[0][1] * J[1][0]) * r;
-    double Q[6];
-    {
-      constexpr int RS[6][2] = {{0, 0}, {1, 1}, {2, 2}, {0, 1}, {0, 2}, {1, 2}};
-#pragma unroll
-      for (int u = 0; u < 6; ++u) {
-        const int a = RS[u][0], b = RS[u][1];
-        Q[u] = det * (Ji[0][a] * Ji[0][b] + Ji[1][a] * Ji[1][b] + Ji[2][a] * Ji[2][b]);
-      }
-    }
-    // 72 T_rs[ab] are small integers for the trilinear element (q1_aff_int): 15 products, then signed sums --
-    // no table traffic at all inside the loop
-    double L[36];
-    {
-      double D[3][3], M[3][2];
-#pragma unroll
-      for (int u = 0; u < 3; ++u) {
-        const double qd = Q[u] * (1.0 / 72.0), qm = Q[3 + u] * (1.0 / 72.0);
-        D[u][0] = 4.0 * qd;
-        D[u][1] = 8.0 * qd;
-        D[u][2] = 16.0 * qd;
-        M[u][0] = 12.0 * qm;
-        M[u][1] = 24.0 * qm;
-      }
-      int idx = 0;
-#pragma unroll
-      for (int a = 0; a < 8; ++a)
-#pragma unroll
-        for (int c = a; c < 8; ++c, ++idx) {
-          double v = 0.0;
-#pragma unroll
-          for (int u = 0; u < 6; ++u) {
-            const int n = q1_aff_int(u, a, c);
-            const int an = n < 0 ? -n : n;
-            if (an == 0) continue;
-            const double x = u < 3 ? D[u][an == 4 ? 0 : (an == 8 ? 1 : 2)] : M[u - 3][an == 12 ? 0 : 1];
-            v = n > 0 ? v + x : v - x;
-          }
-          L[idx] = v;
-        }
-    }
-#pragma unroll
-    for (int a = 0; a < 8; ++a) {
-      const int rx = lx - 1 + CX[a], ry = ly - 1 + CY[a], rz = lz - 1 + CZ[a];
-      if (rx < 0 || rx >= TX || ry < 0 || ry >= TY || rz < 0 || rz >= TZ || z0 + rz >= T.n_own) continue;
-      double* row = acc + ((rz * TY + ry) * TX + rx) * 27;
-#pragma unroll
-      for (int c = 0; c < 8; ++c) {
-        const int kk = (CZ[c] - CZ[a] + 1) * 9 + (CY[c] - CY[a] + 1) * 3 + (CX[c] - CX[a] + 1);
-        atomicAdd(&row[kk], L[tri(a, c)]);
-      }
-    }
-  }
-}
-
-// one-off check for any Q1 hex mesh (connectivity-driven): is every element a parallelepiped?
-__global__ void mesh_all_affine_kernel(const int32_t* __restrict__ conn, const double* __restrict__ xyz, int64_t n_elem,
-                                       TileArgs q, int* flag) {
-  const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (e >= n_elem) return;
-  double X[8][3];
-#pragma unroll
-  for (int a = 0; a < 8; ++a) {
-    const double* p = xyz + (int64_t)conn[e * 8 + a] * 3;
-    X[a][0] = p[0];
-    X[a][1] = p[1];
-    X[a][2] = p[2];
-  }
-  if (!element_is_affine(q, X)) *flag = 0;
-}
-
-// one-off check behind std_lat: the closed-form row offsets equal the symbolic phase's rowptr
-__global__ void lattice_rowptr_check_kernel(LatArgs T, const int32_t* __restrict__ rowptr, int64_t n_rows, int* flag) {
-  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n_rows) return;
-  const int x = (int)(i % T.nx), y = (int)((i / T.nx) % T.ny), zo = (int)(i / ((int64_t)T.nx * T.ny));
-  if (rowptr[i] != lat_rowptr_std(T, x, y, zo)) *flag = 0;
-}
-
-// one tile per workgroup
-template <int TX, int TY, int TZ, bool AFF>
-__global__ void __launch_bounds__(TILE_THREADS, AFF ? 3 : 2) assemble_q1_hex_lattice_kernel(LatArgs T) {
-  using LT = LatTile<TX, TY, TZ>;
-  extern __shared__ __align__(16) double lds[];
-  double* acc = lds;
-  int* rlo = reinterpret_cast<int*>(acc + LT::ACC);
-  int* zrd = rlo + LT::NR;
-  unsigned char* nbc = reinterpret_cast<unsigned char*>(zrd + TZ);
-  const int tid = threadIdx.x;
-  const int b = blockIdx.x;
-  const int bx = b % T.ntx, by = (b / T.ntx) % T.nty, bz = b / (T.ntx * T.nty);
-  const int x0 = bx * TX, y0 = by * TY, z0 = bz * TZ;
-  LatMeta<TX, TY, TZ, TILE_THREADS> meta;
-  lat_meta_load<TX, TY, TZ, TILE_THREADS>(T, x0, y0, z0, tid, meta);   // in flight during the element phase
-  for (int i = tid; i < LT::ACC; i += TILE_THREADS) acc[i] = 0.0;
-  __syncthreads();
-  if (T.ablate != 1) {
-    if (AFF)
-      lat_integrate_affine<TX, TY, TZ>(T, x0, y0, z0, acc, tid, TILE_THREADS);
-    else
-      lat_integrate<TX, TY, TZ>(T, x0, y0, z0, acc, tid, TILE_THREADS);
-  }
-  const int anybc = __syncthreads_or(lat_meta_commit<TX, TY, TZ, TILE_THREADS>(T, z0, tid, meta, rlo, zrd, nbc));
-  if (lat_tile_plain<TX, TY, TZ>(T, x0, y0, z0, zrd, anybc) && T.ablate != 4)
-    lat_store_plain<TX, TY, TZ>(T, acc, rlo, tid, TILE_THREADS);
-  else
-    lat_store<TX, TY, TZ>(T, x0, y0, acc, rlo, zrd, nbc, tid, TILE_THREADS);
-}
-
-// =================================================================================================
 // Tiled KLE assembly (3 DOF per node): K, Krhs (WHICH = 0) and Rw (WHICH = 1) of
 // FreeSlip.buildKLEMats (src/cases/base_problem.py:499-552) without HBM atomics.
 //
@@ -924,75 +320,6 @@ struct KleArgs {
 };
 
 constexpr int KLE_THREADS = 128;
-
-// geometry at one point of a rule: Ji = (hc . X)^-1, returns detJ; G[d][a] = sum_r Ji[d][r] hr[r][a]
-__device__ __forceinline__ double point_gradients(const double* __restrict__ hc, const double* __restrict__ hr,
-                                                  const double (&X)[8][3], double (&G)[3][8]) {
-  double J[3][3];
-#pragma unroll
-  for (int d = 0; d < 3; ++d)
-#pragma unroll
-    for (int x = 0; x < 3; ++x) {
-      double s = 0.0;
-#pragma unroll
-      for (int c = 0; c < 8; ++c) s = fma(hc[d * 8 + c], X[c][x], s);
-      J[d][x] = s;
-    }
-  const double c00 = J[1][1] * J[2][2] - J[1][2] * J[2][1];
-  const double c01 = J[1][2] * J[2][0] - J[1][0] * J[2][2];
-  const double c02 = J[1][0] * J[2][1] - J[1][1] * J[2][0];
-  const double det = J[0][0] * c00 + J[0][1] * c01 + J[0][2] * c02;
-  const double r = 1.0 / det;
-  double Ji[3][3];
-  Ji[0][0] = c00 * r;
-  Ji[0][1] = (J[0][2] * J[2][1] - J[0][1] * J[2][2]) * r;
-  Ji[0][2] = (J[0][1] * J[1][2] - J[0][2] * J[1][1]) * r;
-  Ji[1][0] = c01 * r;
-  Ji[1][1] = (J[0][0] * J[2][2] - J[0][2] * J[2][0]) * r;
-  Ji[1][2] = (J[0][2] * J[1][0] - J[0][0] * J[1][2]) * r;
-  Ji[2][0] = c02 * r;
-  Ji[2][1] = (J[0][1] * J[2][0] - J[0][0] * J[2][1]) * r;
-  Ji[2][2] = (J[0][0] * J[1][1] - J[0][1] * J[1][0]) * r;
-#pragma unroll
-  for (int d = 0; d < 3; ++d)
-#pragma unroll
-    for (int a = 0; a < 8; ++a) {
-      double s = Ji[d][0] * hr[a];
-      s = fma(Ji[d][1], hr[8 + a], s);
-      s = fma(Ji[d][2], hr[16 + a], s);
-      G[d][a] = s;
-    }
-  return det;
-}
-
-// Ji[x][d] = (hc . X)^-1 (physical axis x, reference axis d), returns detJ
-__device__ __forceinline__ double jacobian_inverse(const double* __restrict__ hc, const double (&X)[8][3], double (&Ji)[3][3]) {
-  double J[3][3];
-#pragma unroll
-  for (int d = 0; d < 3; ++d)
-#pragma unroll
-    for (int x = 0; x < 3; ++x) {
-      double s = 0.0;
-#pragma unroll
-      for (int c = 0; c < 8; ++c) s = fma(hc[d * 8 + c], X[c][x], s);
-      J[d][x] = s;
-    }
-  const double c00 = J[1][1] * J[2][2] - J[1][2] * J[2][1];
-  const double c01 = J[1][2] * J[2][0] - J[1][0] * J[2][2];
-  const double c02 = J[1][0] * J[2][1] - J[1][1] * J[2][0];
-  const double det = J[0][0] * c00 + J[0][1] * c01 + J[0][2] * c02;
-  const double r = 1.0 / det;
-  Ji[0][0] = c00 * r;
-  Ji[0][1] = (J[0][2] * J[2][1] - J[0][1] * J[2][2]) * r;
-  Ji[0][2] = (J[0][1] * J[1][2] - J[0][2] * J[1][1]) * r;
-  Ji[1][0] = c01 * r;
-  Ji[1][1] = (J[0][0] * J[2][2] - J[0][2] * J[2][0]) * r;
-  Ji[1][2] = (J[0][2] * J[1][0] - J[0][0] * J[1][2]) * r;
-  Ji[2][0] = c02 * r;
-  Ji[2][1] = (J[0][1] * J[2][0] - J[0][0] * J[2][1]) * r;
-  Ji[2][2] = (J[0][0] * J[1][1] - J[0][1] * J[1][0]) * r;
-  return det;
-}
 
 // one (m, half) pass of the Rw element block: T_m[a][b] = sum_g c_g H_g[a] G_g[m][b] for the four row
 // nodes a = 4*AH .. 4*AH+3, plus the reduced-point term, scattered into the LDS rows of the patch
@@ -1433,224 +760,6 @@ __global__ void __launch_bounds__(KLE_AFF_THREADS, 3) assemble_q1_hex_kle_affine
   }
 }
 
-// ---- plan-free KLE assembly on lattices of parallelepipeds: the scalar lattice kernel's scheme (index
-// arithmetic, stencil-ordered LDS rows, straight x-line copies for interior tiles) with the four-wave closed-form
-// element blocks of assemble_q1_hex_kle_affine_kernel.  LDS row of a node = [p][27 stencil slots][q] = exactly the
-// node's block-CSR row when it has all 27 neighbours.
-struct KleLatArgs {
-  LatArgs L;              // A = K or Rw, Arhs = Krhs (K only, may be null); bcmask per DOF (3 per node)
-  double alpha_d, alpha_w;
-  const double *wr, *hrsr, *Hr, *hcoor;   // reduced (centroid) rule
-};
-
-template <int TX, int TY, int TZ, bool RW, int A0>
-__device__ __forceinline__ void kle_lat_rows(const KleLatArgs& T, const double (&Ji)[3][3], double det, int lx, int ly, int lz,
-                                             int z0, double* acc) {
-  constexpr int CX[8] = {0, 0, 1, 1, 0, 1, 1, 0};
-  constexpr int CY[8] = {0, 1, 1, 0, 0, 0, 1, 1};
-  constexpr int CZ[8] = {0, 0, 0, 0, 1, 1, 1, 1};
-  const double cr = T.wr[0] * det;
-  const double caw = cr * T.alpha_w, cad = cr * T.alpha_d;
-  const double* __restrict__ hr = T.hrsr;
-  double Gr[3][8];
-#pragma unroll
-  for (int d = 0; d < 3; ++d)
-#pragma unroll
-    for (int a = 0; a < 8; ++a) Gr[d][a] = fma(Ji[d][2], hr[16 + a], fma(Ji[d][1], hr[8 + a], Ji[d][0] * hr[a]));
-  double D[3][3], M2[3][2], DM[3][3][3];
-  if (!RW) {
-    constexpr int RS[6][2] = {{0, 0}, {1, 1}, {2, 2}, {0, 1}, {0, 2}, {1, 2}};
-#pragma unroll
-    for (int u = 0; u < 3; ++u) {
-      const int a0 = RS[u][0], a1 = RS[3 + u][0], b1 = RS[3 + u][1];
-      const double qd = det * (Ji[0][a0] * Ji[0][a0] + Ji[1][a0] * Ji[1][a0] + Ji[2][a0] * Ji[2][a0]) * (1.0 / 72.0);
-      const double qm = det * (Ji[0][a1] * Ji[0][b1] + Ji[1][a1] * Ji[1][b1] + Ji[2][a1] * Ji[2][b1]) * (1.0 / 72.0);
-      D[u][0] = 4.0 * qd, D[u][1] = 8.0 * qd, D[u][2] = 16.0 * qd;
-      M2[u][0] = 12.0 * qm, M2[u][1] = 24.0 * qm;
-    }
-  } else {
-#pragma unroll
-    for (int m = 0; m < 3; ++m)
-#pragma unroll
-      for (int d = 0; d < 3; ++d) {
-        const double x = det * Ji[m][d] * (1.0 / 72.0);
-        DM[m][d][0] = 4.0 * x, DM[m][d][1] = 8.0 * x, DM[m][d][2] = 16.0 * x;
-      }
-  }
-#pragma unroll
-  for (int h = 0; h < 2; ++h) {
-    const int a = A0 + h;
-    const int rx = lx - 1 + CX[a], ry = ly - 1 + CY[a], rz = lz - 1 + CZ[a];
-    if (rx < 0 || rx >= TX || ry < 0 || ry >= TY || rz < 0 || rz >= TZ || z0 + rz >= T.L.n_own) continue;
-    double* rowp = acc + ((rz * TY + ry) * TX + rx) * 243;
-#pragma unroll
-    for (int b = 0; b < 8; ++b) {
-      const int kk = (CZ[b] - CZ[a] + 1) * 9 + (CY[b] - CY[a] + 1) * 3 + (CX[b] - CX[a] + 1);
-      if (!RW) {
-        double lab = 0.0;
-#pragma unroll
-        for (int u = 0; u < 6; ++u) {
-          const int n = q1_aff_int(u, a, b);
-          const int an = n < 0 ? -n : n;
-          if (an == 0) continue;
-          const double x = u < 3 ? D[u][an == 4 ? 0 : (an == 8 ? 1 : 2)] : M2[u - 3][an == 12 ? 0 : 1];
-          lab = n > 0 ? lab + x : lab - x;
-        }
-        const double s_ab = Gr[0][a] * Gr[0][b] + Gr[1][a] * Gr[1][b] + Gr[2][a] * Gr[2][b];
-        const double diag = lab + caw * s_ab;
-#pragma unroll
-        for (int pp = 0; pp < 3; ++pp)
-#pragma unroll
-          for (int q = 0; q < 3; ++q) {
-            double v = cad * Gr[pp][a] * Gr[q][b] - caw * Gr[q][a] * Gr[pp][b];
-            if (pp == q) v += diag;
-            atomicAdd(&rowp[(pp * 27 + kk) * 3 + q], v);
-          }
-      } else {
-        const double hb = T.Hr[b];
-#pragma unroll
-        for (int m = 0; m < 3; ++m) {
-          double tv = 0.0;
-#pragma unroll
-          for (int d = 0; d < 3; ++d) {
-            const int n = q1_mix_int(d, a, b);
-            const int an = n < 0 ? -n : n;
-            const double x = DM[m][d][an == 4 ? 0 : (an == 8 ? 1 : 2)];
-            tv = n > 0 ? tv + x : tv - x;
-          }
-          const double wv = tv - caw * Gr[m][a] * hb;
-          const int P1 = (m + 1) % 3, P2 = (m + 2) % 3;
-          atomicAdd(&rowp[(P2 * 27 + kk) * 3 + P1], wv);
-          atomicAdd(&rowp[(P1 * 27 + kk) * 3 + P2], -wv);
-        }
-      }
-    }
-  }
-}
-
-template <int TX, int TY, int TZ, bool RW>
-__global__ void __launch_bounds__(256, 3) assemble_q1_hex_kle_lattice_kernel(KleLatArgs T) {
-  using LT = LatTile<TX, TY, TZ>;
-  constexpr int ROW = 243, ACC = LT::NR * ROW;
-  extern __shared__ __align__(16) double lds[];
-  double* acc = lds;
-  int* rlo = reinterpret_cast<int*>(acc + ACC);
-  int* zrd = rlo + LT::NR;
-  unsigned char* nbc = reinterpret_cast<unsigned char*>(zrd + TZ);
-  const LatArgs& L = T.L;
-  const int tid = threadIdx.x, lane = tid & 63, part = tid >> 6;
-  const int b = blockIdx.x;
-  const int bx = b % L.ntx, by = (b / L.ntx) % L.nty, bz = b / (L.ntx * L.nty);
-  const int x0 = bx * TX, y0 = by * TY, z0 = bz * TZ;
-  const int nx = L.nx, ny = L.ny;
-  LatMeta<TX, TY, TZ, 256> meta;
-  lat_meta_load<TX, TY, TZ, 256, 3>(L, x0, y0, z0, tid, meta);
-  for (int i = tid; i < ACC; i += 256) acc[i] = 0.0;
-  __syncthreads();
-
-  const double* __restrict__ S = L.q.aff + 248;
-  for (int t = lane; t < LT::NE && L.ablate != 1; t += 64) {
-    const int lx = t % LT::EX, ly = (t / LT::EX) % LT::EY, lz = t / (LT::EX * LT::EY);
-    const int gx = x0 - 1 + lx, gy = y0 - 1 + ly, gl = L.p_own0 + z0 - 1 + lz;
-    if (gx < 0 || gx >= nx - 1 || gy < 0 || gy >= ny - 1 || gl < 0 || gl >= L.npl - 1) continue;
-    const int n00 = gy * nx + gx;
-    const double* q0 = L.xyz + (int64_t)(lat_plane(L, gl) + n00) * 3;
-    const double* qz = L.xyz + (int64_t)(lat_plane(L, gl + 1) + n00) * 3;
-    double E[3][3];
-#pragma unroll
-    for (int x = 0; x < 3; ++x) {
-      const double o = q0[x];
-      E[0][x] = q0[3 + x] - o;
-      E[1][x] = q0[3 * nx + x] - o;
-      E[2][x] = qz[x] - o;
-    }
-    double J[3][3];
-#pragma unroll
-    for (int d = 0; d < 3; ++d)
-#pragma unroll
-      for (int x = 0; x < 3; ++x) J[d][x] = fma(S[d * 3 + 2], E[2][x], fma(S[d * 3 + 1], E[1][x], S[d * 3] * E[0][x]));
-    const double c00 = J[1][1] * J[2][2] - J[1][2] * J[2][1];
-    const double c01 = J[1][2] * J[2][0] - J[1][0] * J[2][2];
-    const double c02 = J[1][0] * J[2][1] - J[1][1] * J[2][0];
-    const double det = J[0][0] * c00 + J[0][1] * c01 + J[0][2] * c02;
-    const double r = 1.0 / det;
-    double Ji[3][3];
-    Ji[0][0] = c00 * r;
-    Ji[0][1] = (J[0][2] * J[2][1] - J[0][1] * J[2][2]) * r;
-    Ji[0][2] = (J[0][1] * J[1][2] - J[0][2] * J[1][1]) * r;
-    Ji[1][0] = c01 * r;
-    Ji[1][1] = (J[0][0] * J[2][2] - J[0][2] * J[2][0]) * r;
-    Ji[1][2] = (J[0][2] * J[1][0] - J[0][0] * J[1][2]) * r;
-    Ji[2][0] = c02 * r;
-    Ji[2][1] = (J[0][1] * J[2][0] - J[0][0] * J[2][1]) * r;
-    Ji[2][2] = (J[0][0] * J[1][1] - J[0][1] * J[1][0]) * r;
-    switch (part) {   // wave-uniform: wave w adds the node rows {2w, 2w+1} of every element
-      case 0: kle_lat_rows<TX, TY, TZ, RW, 0>(T, Ji, det, lx, ly, lz, z0, acc); break;
-      case 1: kle_lat_rows<TX, TY, TZ, RW, 2>(T, Ji, det, lx, ly, lz, z0, acc); break;
-      case 2: kle_lat_rows<TX, TY, TZ, RW, 4>(T, Ji, det, lx, ly, lz, z0, acc); break;
-      default: kle_lat_rows<TX, TY, TZ, RW, 6>(T, Ji, det, lx, ly, lz, z0, acc); break;
-    }
-  }
-  const int anybc = __syncthreads_or(lat_meta_commit<TX, TY, TZ, 256>(L, z0, tid, meta, rlo, zrd, nbc));
-
-  double* __restrict__ outA = L.A;
-  double* __restrict__ outR = L.Arhs;
-  if (lat_tile_plain<TX, TY, TZ>(L, x0, y0, z0, zrd, anybc)) {
-    // interior tile: the TX node rows of an x-line are one contiguous run of TX*243 doubles here and in HBM
-    constexpr int LINE = TX * ROW, NL = TY * TZ;
-    for (int l = part; l < NL; l += 4) {
-      const int64_t base = (int64_t)rlo[l * TX] * 9;
-      for (int i = lane; i < LINE; i += 64) {
-        outA[base + i] = acc[l * LINE + i];
-        if (!RW && outR) outR[base + i] = 0.0;
-      }
-    }
-    return;
-  }
-  // boundary tile: one wave per scalar row (node row s, component p), CSR slot -> stencil position as in lat_store
-  for (int sr = part; sr < LT::NR * 3; sr += 4) {
-    const int s = sr / 3, pp = sr - s * 3;
-    const int rl = rlo[s];
-    if (rl < 0) continue;
-    const int rx = s % TX, ry = (s / TX) % TY, rz = s / (TX * TY);
-    const int x = x0 + rx, y = y0 + ry;
-    const int zi = zrd[rz];
-    const int cx = 3 - (x == 0) - (x == nx - 1), cy = 3 - (y == 0) - (y == ny - 1), cz = zi & 3;
-    const int cc = cx * cy, len = cc * cz;
-    const int bi = ((rz + 1) * LT::BY + ry + 1) * LT::BX + rx + 1;
-    const bool rowbc = (nbc[bi] >> pp) & 1;
-    const int64_t gbase = ((int64_t)rl * 3 + (int64_t)pp * len) * 3;
-    for (int idx = lane; idx < len * 3; idx += 64) {
-      const int k = idx / 3, q = idx - k * 3;
-      const int kz = (k >= cc) + (k >= 2 * cc);
-      const int rr = k - kz * cc;
-      const int ky = (rr >= cx) + (rr >= 2 * cx);
-      const int kx = rr - ky * cx;
-      const int dz = ((zi >> (2 + 2 * kz)) & 3) - 1;
-      const int dy = ky - (y != 0), dx = kx - (x != 0);
-      const double v = acc[s * ROW + (pp * 27 + (dz + 1) * 9 + (dy + 1) * 3 + (dx + 1)) * 3 + q];
-      double va, vr;
-      if (rowbc) {
-        va = vr = (!RW && q == pp && dx == 0 && dy == 0 && dz == 0) ? 1.0 : 0.0;
-      } else if (!RW && ((nbc[bi + (dz * LT::BY + dy) * LT::BX + dx] >> q) & 1)) {
-        va = 0.0;
-        vr = -v;
-      } else {
-        va = v;
-        vr = 0.0;
-      }
-      outA[gbase + idx] = va;
-      if (!RW && outR) outR[gbase + idx] = vr;
-    }
-  }
-}
-
-__global__ void colbc_kernel(const int32_t* __restrict__ colidx, const uint8_t* __restrict__ bcmask, int64_t nnz,
-                             uint8_t* __restrict__ colbc) {
-  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < nnz; i += (int64_t)gridDim.x * blockDim.x)
-    colbc[i] = bcmask[colidx[i]];
-}
-
 static size_t kle_lds_bytes(int max_rows, int maxlen) {
   return (size_t)max_rows * 9 * maxlen * sizeof(double) + (size_t)max_rows * 2 * sizeof(int) + (size_t)max_rows * 3 * sizeof(unsigned);
 }
@@ -1796,8 +905,28 @@ extern "C" int pyn_patch_plan_set_kind(pyn_ctx* c, int kind, int n_patch, const 
   return PYN_OK;
 }
 
+namespace {
+// one-off check for any Q1 hex mesh (connectivity-driven): is every element a parallelepiped?
+__global__ void mesh_all_affine_kernel(const int32_t* __restrict__ conn, const double* __restrict__ xyz, int64_t n_elem,
+                                       TileArgs q, int* flag) {
+  const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= n_elem) return;
+  double X[8][3];
+#pragma unroll
+  for (int a = 0; a < 8; ++a) {
+    const double* p = xyz + (int64_t)conn[e * 8 + a] * 3;
+    X[a][0] = p[0];
+    X[a][1] = p[1];
+    X[a][2] = p[2];
+  }
+  if (!element_is_affine(q, X)) *flag = 0;
+}
+
+
+}  // namespace
+
 // 1 iff every element of the (Q1 hex) mesh is a parallelepiped; computed once per mesh, cached in the context
-static int mesh_all_affine(pyn_ctx* c, int* out) {
+int pyn_mesh_all_affine(pyn_ctx* c, int* out) {
   if (!c->d_aff || c->dim != 3 || c->nn != 8) {  // tables not uploaded (yet): nothing to cache
     *out = 0;
     return PYN_OK;
@@ -1861,7 +990,7 @@ static int assemble_kle_tiled(pyn_ctx* c, double alpha_d, double alpha_w, double
     T.K = K;
     T.Krhs = Krhs;
     int all_aff = 0;
-    if (T.aff && c->aff_standard) PYN_TRY(mesh_all_affine(c, &all_aff));
+    if (T.aff && c->aff_standard) PYN_TRY(pyn_mesh_all_affine(c, &all_aff));
     if (all_aff)
       assemble_q1_hex_kle_affine_kernel<false><<<P.npatch, KLE_AFF_THREADS, lds, c->stream>>>(T);
     else
@@ -1871,7 +1000,7 @@ static int assemble_kle_tiled(pyn_ctx* c, double alpha_d, double alpha_w, double
     T.K = Rw;
     T.Krhs = nullptr;
     int all_aff = 0;
-    if (T.aff_rw) PYN_TRY(mesh_all_affine(c, &all_aff));
+    if (T.aff_rw) PYN_TRY(pyn_mesh_all_affine(c, &all_aff));
     if (all_aff)
       assemble_q1_hex_kle_affine_kernel<true><<<P.npatch, KLE_AFF_THREADS, lds, c->stream>>>(T);
     else
@@ -1884,238 +1013,6 @@ static int assemble_kle_tiled(pyn_ctx* c, double alpha_d, double alpha_w, double
 
 // Meshes without a caller-supplied plan get patches of consecutive rows: optimal for no numbering in
 // particular, but any partition is valid and even 8x redundant integration beats the HBM-atomic scatter.
-
-// ---- structured topology: detection (host, once per pyn_mesh_set) and launch -------------------------
-int pyn_lattice_detect(pyn_ctx* c, const int32_t* conn) {
-  Lattice& L = c->lat;
-  (void)hipFree(L.d_P);
-  (void)hipFree(L.d_zord);
-  L = Lattice();
-  if (c->dim != 3 || c->nn != 8 || c->n_elem < 1 || getenv("PYNAMA_NO_LATTICE")) return PYN_OK;
-  const int64_t ne = c->n_elem;
-  const int64_t nx = (int64_t)conn[1] - conn[0];
-  if (nx < 2 || conn[3] != conn[0] + 1) return PYN_OK;
-  const int64_t ex = nx - 1;
-  if (ne % ex) return PYN_OK;
-  // rows of elements per layer: the first element row that does not continue the bottom plane of layer 0
-  int64_t ey = 0;
-  for (int64_t j = 0; j * ex < ne; ++j) {
-    if (conn[j * ex * 8] != conn[0] + j * nx) break;
-    ey = j + 1;
-  }
-  if (ey < 1 || (ne / ex) % ey) return PYN_OK;
-  const int64_t ny = ey + 1, ezl = ne / (ex * ey), npl = ezl + 1, nxny = nx * ny;
-  if (nxny * npl != c->n_node || nxny > INT32_MAX / 2) return PYN_OK;
-  std::vector<int32_t> P((size_t)npl);
-  for (int64_t l = 0; l < ezl; ++l) {
-    const int32_t* e0 = conn + l * ex * ey * 8;
-    P[l] = e0[0];
-    if (l + 1 == ezl) P[l + 1] = e0[4];
-    if (l > 0 && P[l] != conn[(l - 1) * ex * ey * 8 + 4]) return PYN_OK;
-  }
-  for (int64_t l = 0; l < ezl; ++l)
-    for (int64_t iy = 0; iy < ey; ++iy)
-      for (int64_t ix = 0; ix < ex; ++ix) {
-        const int32_t* q = conn + ((l * ey + iy) * ex + ix) * 8;
-        const int32_t lo = (int32_t)(P[l] + iy * nx + ix), hi = (int32_t)(P[l + 1] + iy * nx + ix);
-        if (q[0] != lo || q[1] != lo + nx || q[2] != lo + nx + 1 || q[3] != lo + 1 || q[4] != hi || q[5] != hi + 1 ||
-            q[6] != hi + nx + 1 || q[7] != hi + nx)
-          return PYN_OK;
-      }
-  // planes are disjoint blocks of nx*ny ids; the owned ones are consecutive in z and carry ids 0..n_owned-1
-  std::vector<int32_t> sorted(P);
-  std::sort(sorted.begin(), sorted.end());
-  for (int64_t j = 0; j < npl; ++j)
-    if (sorted[j] != j * nxny) return PYN_OK;
-  if (c->n_owned % nxny) return PYN_OK;
-  const int n_own = (int)(c->n_owned / nxny);
-  int p0 = -1;
-  for (int64_t j = 0; j < npl; ++j)
-    if (P[j] == 0) p0 = (int)j;
-  if (p0 < 0 || p0 + n_own > npl) return PYN_OK;
-  for (int j = 0; j < n_own; ++j)
-    if (P[p0 + j] != (int64_t)j * nxny) return PYN_OK;
-  std::vector<int32_t> zord((size_t)npl);
-  for (int64_t j = 0; j < npl; ++j) {
-    int dz[3], n = 0;
-    for (int d = -1; d <= 1; ++d)
-      if (j + d >= 0 && j + d < npl) dz[n++] = d;
-    std::sort(dz, dz + n, [&](int a, int b2) { return P[j + a] < P[j + b2]; });
-    int code = n;
-    for (int i = 0; i < n; ++i) code |= (dz[i] + 1) << (2 + 2 * i);
-    zord[j] = code;
-  }
-  PYN_HIP(hipMalloc((void**)&L.d_P, npl * sizeof(int32_t)));
-  PYN_HIP(hipMalloc((void**)&L.d_zord, npl * sizeof(int32_t)));
-  PYN_HIP(hipMemcpy(L.d_P, P.data(), npl * sizeof(int32_t), hipMemcpyHostToDevice));
-  PYN_HIP(hipMemcpy(L.d_zord, zord.data(), npl * sizeof(int32_t), hipMemcpyHostToDevice));
-  L.nx = (int)nx;
-  L.ny = (int)ny;
-  L.npl = (int)npl;
-  L.p_own0 = p0;
-  L.n_own = n_own;
-  // does the numbering have the arithmetic shape lat_plane / lat_zcode assume (one rank, or a rank's z-slab)?
-  L.std_shape = true;
-  for (int64_t j = 0; j < npl && L.std_shape; ++j) {
-    int64_t want;
-    if (j < p0) want = (n_own + j) * nxny;
-    else if (j >= p0 + n_own) want = (n_own + p0 + (j - p0 - n_own)) * nxny;
-    else want = (j - p0) * nxny;
-    L.std_shape = P[j] == want;
-  }
-  L.valid = true;
-  return PYN_OK;
-}
-
-template <int TX, int TY, int TZ>
-static int launch_lattice(pyn_ctx* c, LatArgs& T, bool affine) {
-  using LT = LatTile<TX, TY, TZ>;
-  T.ntx = (T.nx + TX - 1) / TX;
-  T.nty = (T.ny + TY - 1) / TY;
-  const int ntz = (T.n_own + TZ - 1) / TZ;
-  const int n_tiles = T.ntx * T.nty * ntz;
-  static bool attr_done = false;
-  if (!attr_done) {
-    PYN_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(assemble_q1_hex_lattice_kernel<TX, TY, TZ, false>),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)LT::BYTES));
-    PYN_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(assemble_q1_hex_lattice_kernel<TX, TY, TZ, true>),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)LT::BYTES));
-    attr_done = true;
-  }
-  if (affine)
-    assemble_q1_hex_lattice_kernel<TX, TY, TZ, true><<<n_tiles, TILE_THREADS, LT::BYTES, c->stream>>>(T);
-  else
-    assemble_q1_hex_lattice_kernel<TX, TY, TZ, false><<<n_tiles, TILE_THREADS, LT::BYTES, c->stream>>>(T);
-  PYN_HIP(hipGetLastError());
-  return PYN_OK;
-}
-
-// lattice descriptor -> kernel arguments (+ the one-off verification that index arithmetic may replace the loads)
-static int lat_fill_args(pyn_ctx* c, LatArgs& T, double* A, double* Arhs, int* mesh_aff) {
-  Lattice& L = c->lat;
-  T.xyz = c->d_xyz;
-  T.rowptr = c->d_rowptr;
-  T.bcmask = c->d_bcmask;
-  T.P = L.d_P;
-  T.zord = L.d_zord;
-  T.nx = L.nx;
-  T.ny = L.ny;
-  T.npl = L.npl;
-  T.p_own0 = L.p_own0;
-  T.n_own = L.n_own;
-  T.ntx = T.nty = 0;
-  T.std_lat = 0;
-  T.q = TileArgs();
-  T.q.w = c->quad[0].w;
-  T.q.hrs = c->quad[0].Hrs;
-  T.q.hcoo = c->quad[0].HrsCoo;
-  T.q.aff = getenv("PYNAMA_NO_AFFINE") ? nullptr : c->d_aff;
-  T.A = A;
-  T.Arhs = Arhs;
-  const char* ab = getenv("PYNAMA_LATTICE_ABLATE");  // diagnostics: 1 = no element phase, 4 = no plain-tile store path
-  T.ablate = ab ? atoi(ab) : 0;
-  PYN_TRY(mesh_all_affine(c, mesh_aff));
-  if (L.std_ok < 0) {      // once per graph: may the index arithmetic replace P / zord / rowptr?
-    L.std_ok = 0;
-    if (L.std_shape && !getenv("PYNAMA_NO_STD_LATTICE")) {
-      DevTmp flag;
-      PYN_HIP(flag.alloc(sizeof(int)));
-      const int one = 1;
-      PYN_HIP(hipMemcpyAsync(flag.p, &one, sizeof(int), hipMemcpyHostToDevice, c->stream));
-      LatArgs Tc = T;
-      Tc.std_lat = 1;
-      lattice_rowptr_check_kernel<<<(int)((c->n_owned + 255) / 256), 256, 0, c->stream>>>(Tc, c->d_rowptr, c->n_owned, flag.as<int>());
-      int h = 0;
-      PYN_HIP(hipMemcpyAsync(&h, flag.p, sizeof(int), hipMemcpyDeviceToHost, c->stream));
-      PYN_HIP(hipStreamSynchronize(c->stream));
-      L.std_ok = h;
-    }
-  }
-  T.std_lat = L.std_ok == 1;
-  return PYN_OK;
-}
-
-template <int TX, int TY, int TZ>
-static int launch_kle_lattice(pyn_ctx* c, KleLatArgs& T, double* K, double* Krhs, double* Rw) {
-  using LT = LatTile<TX, TY, TZ>;
-  T.L.ntx = (T.L.nx + TX - 1) / TX;
-  T.L.nty = (T.L.ny + TY - 1) / TY;
-  const int n_tiles = T.L.ntx * T.L.nty * ((T.L.n_own + TZ - 1) / TZ);
-  const size_t lds = (size_t)LT::NR * 243 * sizeof(double) + LT::META_INTS * sizeof(int);
-  static bool attr_done = false;
-  if (!attr_done) {
-    PYN_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(assemble_q1_hex_kle_lattice_kernel<TX, TY, TZ, false>),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    PYN_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(assemble_q1_hex_kle_lattice_kernel<TX, TY, TZ, true>),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    attr_done = true;
-  }
-  if (K) {
-    T.L.A = K;
-    T.L.Arhs = Krhs;
-    assemble_q1_hex_kle_lattice_kernel<TX, TY, TZ, false><<<n_tiles, 256, lds, c->stream>>>(T);
-  }
-  if (Rw) {
-    T.L.A = Rw;
-    T.L.Arhs = nullptr;
-    assemble_q1_hex_kle_lattice_kernel<TX, TY, TZ, true><<<n_tiles, 256, lds, c->stream>>>(T);
-  }
-  PYN_HIP(hipGetLastError());
-  return PYN_OK;
-}
-
-// KLE on lattices of parallelepipeds (the reference's box meshes): plan-free kernels
-static int assemble_kle_lattice(pyn_ctx* c, double alpha_d, double alpha_w, double* K, double* Krhs, double* Rw, bool* handled) {
-  if (!c->lat.valid || c->quad[0].ngp != 8 || c->quad[1].ngp != 1 || !c->aff_standard || !c->aff_rw_standard ||
-      getenv("PYNAMA_NO_AFFINE") || getenv("PYNAMA_NO_KLE_LATTICE"))
-    return PYN_OK;
-  KleLatArgs T;
-  int mesh_aff = 0;
-  PYN_TRY(lat_fill_args(c, T.L, nullptr, nullptr, &mesh_aff));
-  if (!mesh_aff) return PYN_OK;   // general geometry: the patch-plan kernels with quadrature
-  T.alpha_d = alpha_d;
-  T.alpha_w = alpha_w;
-  T.wr = c->quad[1].w;
-  T.hrsr = c->quad[1].Hrs;
-  T.Hr = c->quad[1].H;
-  T.hcoor = c->quad[1].HrsCoo;
-  const char* tl = getenv("PYNAMA_KLE_LATTICE_TILE");
-  switch (tl ? atoi(tl) : 0) {
-    case 1: PYN_TRY((launch_kle_lattice<6, 2, 2>(c, T, K, Krhs, Rw))); break;
-    case 2: PYN_TRY((launch_kle_lattice<3, 3, 2>(c, T, K, Krhs, Rw))); break;
-    case 3: PYN_TRY((launch_kle_lattice<4, 3, 3>(c, T, K, Krhs, Rw))); break;
-    default: PYN_TRY((launch_kle_lattice<3, 3, 3>(c, T, K, Krhs, Rw))); break;
-  }
-  *handled = true;
-  return PYN_OK;
-}
-
-static int assemble_lattice(pyn_ctx* c, double* A, double* Arhs, bool* handled) {
-  Lattice& L = c->lat;
-  if (!L.valid || c->quad[0].ngp != 8) return PYN_OK;
-  LatArgs T;
-  int mesh_aff = 0;
-  PYN_TRY(lat_fill_args(c, T, A, Arhs, &mesh_aff));
-  const bool affine = mesh_aff == 1 && T.q.aff != nullptr && c->aff_standard;
-  // measured at 10M DOFs: parallelepipeds are store-bound -> small tiles, 5 workgroups per CU;
-  // the quadrature path is FP64-bound -> 7x7x7 tiles (least redundant integration that fits the LDS twice)
-  const char* tl = getenv("PYNAMA_LATTICE_TILE");
-  const int sel = tl ? atoi(tl) : (affine ? 0 : 1);
-  switch (sel) {
-    case 1: PYN_TRY((launch_lattice<7, 7, 7>(c, T, affine))); break;
-    case 2: PYN_TRY((launch_lattice<6, 6, 6>(c, T, affine))); break;
-    case 3: PYN_TRY((launch_lattice<8, 6, 6>(c, T, affine))); break;
-    case 4: PYN_TRY((launch_lattice<7, 6, 6>(c, T, affine))); break;
-    case 5: PYN_TRY((launch_lattice<6, 6, 4>(c, T, affine))); break;
-    case 6: PYN_TRY((launch_lattice<6, 5, 5>(c, T, affine))); break;
-    case 7: PYN_TRY((launch_lattice<7, 4, 4>(c, T, affine))); break;
-    case 8: PYN_TRY((launch_lattice<14, 3, 3>(c, T, affine))); break;
-    case 9: PYN_TRY((launch_lattice<7, 5, 5>(c, T, affine))); break;
-    default: PYN_TRY((launch_lattice<7, 5, 4>(c, T, affine))); break;
-  }
-  *handled = true;
-  return PYN_OK;
-}
 
 static int ensure_default_plan(pyn_ctx* c, int kind) {
   if (c->plan[kind].npatch || c->dim != 3 || c->nn != 8 || getenv("PYNAMA_NO_AUTO_PLAN")) return PYN_OK;
@@ -2153,11 +1050,11 @@ static int ensure_default_plan(pyn_ctx* c, int kind) {
 int pyn_assemble_q1_tiled(pyn_ctx* c, int form, double alpha_d, double alpha_w, double* K, double* Krhs, double* Rw, double* Rd, bool* handled) {
   *handled = false;
   if (form == PYN_FORM_LAPLACE && K && !Rw && !Rd && c->lat.valid && !c->plan[0].user) {
-    PYN_TRY(assemble_lattice(c, K, Krhs, handled));
+    PYN_TRY(pyn_assemble_lattice(c, K, Krhs, handled));
     if (*handled) return PYN_OK;
   }
   if (form == PYN_FORM_KLE && K && !Rd && !c->plan[1].user) {
-    PYN_TRY(assemble_kle_lattice(c, alpha_d, alpha_w, K, Krhs, Rw, handled));
+    PYN_TRY(pyn_assemble_kle_lattice(c, alpha_d, alpha_w, K, Krhs, Rw, handled));
     if (*handled) return PYN_OK;
   }
   if (form == PYN_FORM_KLE && K && !Rd) PYN_TRY(ensure_default_plan(c, 1));
@@ -2202,3 +1099,4 @@ int pyn_assemble_q1_tiled(pyn_ctx* c, int form, double alpha_d, double alpha_w, 
   *handled = true;
   return PYN_OK;
 }
+
