@@ -629,6 +629,32 @@ __global__ void __launch_bounds__(256, 3) assemble_q1_hex_kle_lattice_kernel(Kle
   }
 }
 
+
+// Symbolic phase of a lattice in closed form (no sort): rowptr from lat_rowptr_std, the columns of a row in
+// ascending id order = z-planes in zcode order, then y, then x, clipped at the domain faces.
+__global__ void lattice_symbolic_kernel(LatArgs T, int64_t n_rows, int32_t* __restrict__ rowptr, int32_t* __restrict__ colidx) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i > n_rows) return;
+  if (i == n_rows) {   // one past the last row: total number of entries
+    const int sx = 3 * T.nx - 2, sy = 3 * T.ny - 2;
+    const bool bot = T.p_own0 == 0;
+    rowptr[i] = (3 * T.n_own - (bot && T.n_own > 0) - (T.p_own0 + T.n_own == T.npl)) * sy * sx;
+    return;
+  }
+  const int x = (int)(i % T.nx), y = (int)((i / T.nx) % T.ny), zo = (int)(i / ((int64_t)T.nx * T.ny));
+  const int lo = lat_rowptr_std(T, x, y, zo);
+  rowptr[i] = lo;
+  const int zi = lat_zcode(T, T.p_own0 + zo);
+  const int cz = zi & 3;
+  int k = lo;
+  for (int kz = 0; kz < cz; ++kz) {
+    const int dz = ((zi >> (2 + 2 * kz)) & 3) - 1;
+    const int base = lat_plane(T, T.p_own0 + zo + dz);
+    for (int dy = (y == 0 ? 0 : -1); dy <= (y == T.ny - 1 ? 0 : 1); ++dy)
+      for (int dx = (x == 0 ? 0 : -1); dx <= (x == T.nx - 1 ? 0 : 1); ++dx) colidx[k++] = base + (y + dy) * T.nx + x + dx;
+  }
+}
+
 }  // namespace
 
 // ---- structured topology: detection (host, once per pyn_mesh_set) and launch -------------------------
@@ -863,3 +889,41 @@ int pyn_assemble_lattice(pyn_ctx* c, double* A, double* Arhs, bool* handled) {
   return PYN_OK;
 }
 
+
+// Node graph of a lattice whose numbering has the arithmetic shape (one rank, or a rank's z-slab): built directly,
+// without the sort of pyn_csr_symbolic.  *done = false when the mesh does not qualify.
+int pyn_lattice_symbolic(pyn_ctx* c, bool* done) {
+  *done = false;
+  const Lattice& L = c->lat;
+  if (!L.valid || !L.std_shape || getenv("PYNAMA_NO_LATTICE_SYMBOLIC")) return PYN_OK;
+  LatArgs T;
+  T.xyz = c->d_xyz;
+  T.rowptr = nullptr;
+  T.bcmask = nullptr;
+  T.P = L.d_P;
+  T.zord = L.d_zord;
+  T.nx = L.nx;
+  T.ny = L.ny;
+  T.npl = L.npl;
+  T.p_own0 = L.p_own0;
+  T.n_own = L.n_own;
+  T.ntx = T.nty = 0;
+  T.std_lat = 1;
+  T.ablate = 0;
+  T.q = TileArgs();
+  T.A = T.Arhs = nullptr;
+  const int64_t sx = 3 * (int64_t)L.nx - 2, sy = 3 * (int64_t)L.ny - 2;
+  const int64_t nnz = (3 * (int64_t)L.n_own - (L.p_own0 == 0 ? 1 : 0) - (L.p_own0 + L.n_own == L.npl ? 1 : 0)) * sy * sx;
+  PYN_CHECK(nnz > 0 && nnz < (int64_t)INT32_MAX, "pattern has %lld entries (int32 CSR limit)", (long long)nnz);
+  (void)hipFree(c->d_rowptr);
+  (void)hipFree(c->d_colidx);
+  c->d_rowptr = nullptr;
+  c->d_colidx = nullptr;
+  PYN_HIP(hipMalloc((void**)&c->d_rowptr, (c->n_owned + 1) * sizeof(int32_t)));
+  PYN_HIP(hipMalloc((void**)&c->d_colidx, nnz * sizeof(int32_t)));
+  lattice_symbolic_kernel<<<(int)((c->n_owned + 1 + 255) / 256), 256, 0, c->stream>>>(T, c->n_owned, c->d_rowptr, c->d_colidx);
+  PYN_HIP(hipGetLastError());
+  c->nnzb = nnz;
+  *done = true;
+  return PYN_OK;
+}

@@ -213,6 +213,7 @@ int pyn_sell_spmv_range(pyn_ctx* c, const DMat& A, const double* x, double* y, b
 int pyn_lattice_detect(pyn_ctx* c, const int32_t* conn_host);  // pyn_assemble_tiled.hip
 bool pyn_q1_affine_tables_standard(const double* aff);
 int pyn_mesh_all_affine(pyn_ctx* c, int* out);                        // pyn_assemble_tiled.hip
+int pyn_lattice_symbolic(pyn_ctx* c, bool* done);
 int pyn_assemble_lattice(pyn_ctx* c, double* A, double* Arhs, bool* handled);   // pyn_assemble_lattice.hip
 int pyn_assemble_kle_lattice(pyn_ctx* c, double alpha_d, double alpha_w, double* K, double* Krhs, double* Rw, bool* handled);
 bool pyn_q1_mixed_tables_standard(const double* w, const double* H, const double* Hrs);

@@ -31,12 +31,36 @@ __global__ void split_keys_kernel(const unsigned long long* __restrict__ keys, i
   }
 }
 
+// the patch plans, the SELL structures and all matrices are tied to the graph
+static int pyn_symbolic_reset_dependents(pyn_ctx* c) {
+  PYN_TRY(pyn_patch_plan_set_kind(c, 0, 0, nullptr, nullptr));
+  PYN_TRY(pyn_patch_plan_set_kind(c, 1, 0, nullptr, nullptr));
+  for (auto& m : c->mats) {
+    (void)hipFree(m.val);
+    (void)hipFree(m.sell_val);
+  }
+  c->mats.clear();
+  pyn_sell_drop_structure(c);
+  c->lat.std_ok = -1;  // closed-form row offsets are re-verified against the new graph
+  return PYN_OK;
+}
+
 extern "C" int pyn_csr_symbolic(pyn_ctx* c) {
   PYN_CHECK(c, "ctx is NULL");
   PYN_CHECK(c->n_elem > 0, "pyn_mesh_set first");
   PYN_HIP(hipSetDevice(c->device));
   hipStream_t s = c->stream;
   PYN_HIP(hipEventRecord(c->ev0, s));
+  bool arithmetic = false;   // structured topology: the graph in closed form, no sort
+  PYN_TRY(pyn_lattice_symbolic(c, &arithmetic));
+  if (arithmetic) {
+    PYN_HIP(hipEventRecord(c->ev1, s));
+    PYN_HIP(hipStreamSynchronize(s));
+    float ms0 = 0;
+    PYN_HIP(hipEventElapsedTime(&ms0, c->ev0, c->ev1));
+    c->timers[PYN_T_SYMBOLIC] = ms0;
+    return pyn_symbolic_reset_dependents(c);
+  }
   const int64_t total = c->n_elem * c->nn * c->nn;
   DevTmp tk0, tk1, tn, tmp, tcnt;
   PYN_HIP(tk0.alloc(total * sizeof(unsigned long long)));
@@ -88,17 +112,7 @@ extern "C" int pyn_csr_symbolic(pyn_ctx* c) {
   PYN_HIP(hipEventElapsedTime(&ms, c->ev0, c->ev1));
   c->timers[PYN_T_SYMBOLIC] = ms;
   c->nnzb = nuniq;
-  // the patch plans, the SELL structures and all matrices are tied to the graph
-  PYN_TRY(pyn_patch_plan_set_kind(c, 0, 0, nullptr, nullptr));
-  PYN_TRY(pyn_patch_plan_set_kind(c, 1, 0, nullptr, nullptr));
-  for (auto& m : c->mats) {
-    (void)hipFree(m.val);
-    (void)hipFree(m.sell_val);
-  }
-  c->mats.clear();
-  pyn_sell_drop_structure(c);
-  c->lat.std_ok = -1;  // closed-form row offsets are re-verified against the new graph
-  return PYN_OK;
+  return pyn_symbolic_reset_dependents(c);
 }
 
 extern "C" int pyn_csr_info(pyn_ctx* c, int64_t* n_rows, int64_t* nnz_blocks) {

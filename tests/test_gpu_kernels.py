@@ -656,6 +656,9 @@ def test_assemble_lattice_kernel(lib, tile, nelem, jitter):
     try:
         ctx = make_ctx(lib, mesh, 2, bc_ndof=1, bc_nodes=mesh.boundary)
         assert ctx.mesh_topology() == ("lattice", nelem[0] + 1, nelem[1] + 1, nelem[2] + 1)
+        rp, ci = ctx.csr_get()                       # closed-form symbolic phase == the oracle's graph, bit for bit
+        rp_o, ci_o = fo.node_graph(mesh)
+        assert np.array_equal(rp, rp_o) and np.array_equal(ci, ci_o)
         A, Arhs = ctx.mat_create(1, 1), ctx.mat_create(1, 1)
         ctx.assemble_scalar(lib.FORM_LAPLACE, A, Arhs)
         assert sp_rel_err(mat_to_scipy(ctx, A, 1, 1), ref["A"]) < FP_TOL
@@ -727,6 +730,14 @@ def test_lattice_kernel_on_rank_slabs(lib, size):
         ctx.bc_set(1, dom.boundaryMaskLocal())
         ctx.csr_symbolic()
         assert ctx.mesh_topology() == ("lattice", 7, 6, dom.nLocal // 42)
+        rp, ci = ctx.csr_get()                       # closed-form graph of the slab == owned rows of the global graph
+        rp_g, ci_g = fo.node_graph(glob)
+        l2g = dom._local2global(np.arange(dom.nLocal))
+        for i in (0, dom.nOwned // 2, dom.nOwned - 1):
+            gi = dom.rStart + i
+            assert np.array_equal(np.sort(l2g[ci[rp[i]:rp[i + 1]]]), ci_g[rp_g[gi]:rp_g[gi + 1]])
+            assert np.all(np.diff(ci[rp[i]:rp[i + 1]]) > 0)
+        assert rp[-1] == sum(rp_g[dom.rStart + i + 1] - rp_g[dom.rStart + i] for i in range(dom.nOwned))
         A, Ar = ctx.mat_create(1, 1), ctx.mat_create(1, 1)
         ctx.assemble_scalar(lib.FORM_LAPLACE, A, Ar)          # no plan set: lattice kernel
         cols = dom._local2global(np.arange(dom.nLocal))
