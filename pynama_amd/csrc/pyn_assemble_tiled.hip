@@ -91,7 +91,9 @@ __global__ void plan_fill_kernel(const unsigned long long* __restrict__ keys, in
     atomicAdd(&p_ecount[p], 1);
     unsigned short rs[8];
     unsigned char km[64];
-    for (int a = 0; a < 8; ++a) {
+    for (int a = 0; a < 8; ++a) rs[a] = 0xFFFF;
+    for (int i = 0; i < 64; ++i) km[i] = 0xFF;
+    for (int a = 0; a < nn; ++a) {   // nn = 8 (hexahedra) or 4 (tetrahedra): same record, partly used
       int node = conn[e * nn + a];
       bool mine = node < n_owned && node2patch[node] == p;
       rs[a] = mine ? (unsigned short)node2slot[node] : (unsigned short)0xFFFF;
@@ -100,7 +102,7 @@ __global__ void plan_fill_kernel(const unsigned long long* __restrict__ keys, in
         lo = rowptr[node];
         len = rowptr[node + 1] - lo;
       }
-      for (int b = 0; b < 8; ++b) km[a * 8 + b] = mine ? (unsigned char)find_slot_t(colidx, lo, len, conn[e * nn + b]) : 0xFF;
+      for (int b = 0; b < nn; ++b) km[a * 8 + b] = mine ? (unsigned char)find_slot_t(colidx, lo, len, conn[e * nn + b]) : 0xFF;
     }
     uint4 r;
     r.x = rs[0] | ((unsigned)rs[1] << 16);
@@ -120,7 +122,52 @@ __global__ void plan_fill_kernel(const unsigned long long* __restrict__ keys, in
   }
 }
 
-// ---- the numeric kernel -------------------------------------------------------------------------
+// ---- the numeric kernels ------------------------------------------------------------------------
+// Store phase shared by the scalar patch kernels: write every owned row once: A gets the free columns, Arhs the
+// imposed ones (negated); imposed rows become identity rows (mat_generator.py:113-118).  Half a wave per row
+// (<= 32 entries), rows and per-entry bytes are fetched UNROLL at a time so that no store waits on a load it
+// does not need.
+__device__ __forceinline__ void plan_store_rows(const TileArgs& T, const double* acc, const int* rmeta, const unsigned* cflag,
+                                                int r_lo, int nrows, int ml, int tid) {
+  double* __restrict__ outA = T.A;
+  double* __restrict__ outR = T.Arhs;
+  const int32_t* __restrict__ colidx = T.colidx;
+  const int half = tid >> 5, k = tid & 31;                  // TILE_THREADS/32 half-waves
+  constexpr int NH = TILE_THREADS / 32, UNROLL = 4;
+  for (int s0 = half; s0 < nrows; s0 += NH * UNROLL) {
+    int lo[UNROLL], m1[UNROLL];
+    unsigned char cb[UNROLL];
+    double v[UNROLL];
+#pragma unroll
+    for (int u = 0; u < UNROLL; ++u) {
+      const int slot = s0 + u * NH;
+      const bool ok = slot < nrows;
+      lo[u] = ok ? rmeta[2 * slot] : 0;
+      m1[u] = ok ? rmeta[2 * slot + 1] : 0;
+      const bool act = k < (m1[u] & 0xFFFF);
+      v[u] = act ? acc[slot * ml + k] : 0.0;
+      cb[u] = act ? ((cflag[slot] >> k) & 1u) : 0;
+      if (act && (m1[u] >> 16)) cb[u] = (colidx[lo[u] + k] == T.p_rows[r_lo + slot]) ? 2 : 3;  // imposed row: diag?
+    }
+#pragma unroll
+    for (int u = 0; u < UNROLL; ++u) {
+      if (k >= (m1[u] & 0xFFFF)) continue;
+      double va, vr;
+      if (m1[u] >> 16) {
+        va = vr = (cb[u] == 2) ? 1.0 : 0.0;
+      } else if (cb[u]) {
+        va = 0.0;
+        vr = -v[u];
+      } else {
+        va = v[u];
+        vr = 0.0;
+      }
+      outA[lo[u] + k] = va;
+      if (outR) outR[lo[u] + k] = vr;
+    }
+  }
+}
+
 template <int ABLATE>
 __global__ void __launch_bounds__(TILE_THREADS, 2) assemble_q1_hex_tiled_kernel(TileArgs T) {
   extern __shared__ __align__(16) double acc[];  // [maxrows][maxlen] accumulators, then per-row meta
@@ -234,52 +281,108 @@ __global__ void __launch_bounds__(TILE_THREADS, 2) assemble_q1_hex_tiled_kernel(
   }
   __syncthreads();
 
-  // ---- write every owned row once: A gets the free columns, Arhs the imposed ones (negated);
-  //      imposed rows become identity rows (mat_generator.py:113-118).  Half a wave per row
-  //      (27 of 32 lanes active), rows and per-entry bytes are fetched UNROLL at a time so that
-  //      no store waits on a load it does not need.
-  {
-    double* __restrict__ outA = T.A;
-    double* __restrict__ outR = T.Arhs;
-    const int32_t* __restrict__ colidx = T.colidx;
-    const int half = tid >> 5, k = tid & 31;                  // TILE_THREADS/32 half-waves
-    constexpr int NH = TILE_THREADS / 32, UNROLL = 4;
-    for (int s0 = half; s0 < nrows; s0 += NH * UNROLL) {
-      int lo[UNROLL], m1[UNROLL];
-      unsigned char cb[UNROLL];
-      double v[UNROLL];
+  plan_store_rows(T, acc, rmeta, cflag, r_lo, nrows, ml, tid);
+}
+
+// Linear tetrahedra through the same patch scheme (BASELINE.json configs[4], irregular indexing): patches of
+// consecutive rows (compact in the Morton numbering of imported meshes), one element per lane, constant gradients
+// G = J^-1 Hrs (table-driven), 16 LDS adds, rows written once -- no HBM atomics.
+__global__ void __launch_bounds__(TILE_THREADS, 3) assemble_p1_tet_tiled_kernel(TileArgs T, double wsum) {
+  extern __shared__ __align__(16) double acc[];
+  const int p = blockIdx.x;
+  const int r_lo = T.p_rowptr[p];
+  const int nrows = T.p_rowptr[p + 1] - r_lo;
+  const int e_lo = T.p_eptr[p];
+  const int ne = T.p_eptr[p + 1] - e_lo;
+  const int ml = T.maxlen;
+  int* rmeta = reinterpret_cast<int*>(acc + (size_t)T.maxrows * ml);
+  unsigned* cflag = reinterpret_cast<unsigned*>(rmeta + 2 * T.maxrows);
+  const int tid = threadIdx.x;
+  for (int i = tid; i < nrows * ml; i += TILE_THREADS) acc[i] = 0.0;
+  for (int sl = tid; sl < nrows; sl += TILE_THREADS) {
+    cflag[sl] = 0u;
+    const int row = T.p_rows[r_lo + sl];
+    const int lo = T.rowptr[row], hi = T.rowptr[row + 1];
+    rmeta[2 * sl] = lo;
+    rmeta[2 * sl + 1] = (hi - lo) | ((T.bcmask && T.bcmask[row]) ? (1 << 16) : 0);
+  }
+  __syncthreads();
+  const double* __restrict__ hr = T.hrs;   // [3][4] reference gradients (constant over the element)
+  for (int t = tid; t < ne; t += TILE_THREADS) {
+    const int64_t pe = (int64_t)e_lo + t;
+    const int e = T.p_elem[pe];
+    const int4 cn = reinterpret_cast<const int4*>(T.conn)[e];
+    const int nd[4] = {cn.x, cn.y, cn.z, cn.w};
+    double X[4][3];
 #pragma unroll
-      for (int u = 0; u < UNROLL; ++u) {
-        const int slot = s0 + u * NH;
-        const bool ok = slot < nrows;
-        lo[u] = ok ? rmeta[2 * slot] : 0;
-        m1[u] = ok ? rmeta[2 * slot + 1] : 0;
-        const bool act = k < (m1[u] & 0xFFFF);
-        v[u] = act ? acc[slot * ml + k] : 0.0;
-        cb[u] = act ? ((cflag[slot] >> k) & 1u) : 0;
-        if (act && (m1[u] >> 16)) cb[u] = (colidx[lo[u] + k] == T.p_rows[r_lo + slot]) ? 2 : 3;  // imposed row: diag?
+    for (int a = 0; a < 4; ++a) {
+      const double* q = T.xyz + (int64_t)nd[a] * 3;
+      X[a][0] = q[0];
+      X[a][1] = q[1];
+      X[a][2] = q[2];
+    }
+    unsigned bcn = 0;
+    if (T.bcmask) {
+#pragma unroll
+      for (int b = 0; b < 4; ++b) bcn |= (T.bcmask[nd[b]] ? 1u : 0u) << b;
+    }
+    const uint4 rs4 = T.rowslot4[pe];
+    const uint4 k0 = T.kmap4[pe], k1 = T.kmap4[T.npe + pe];
+    const unsigned kw[4] = {k0.x, k0.z, k1.x, k1.z};        // bytes a*8 + b, b < 4
+    double J[3][3];
+#pragma unroll
+    for (int d = 0; d < 3; ++d)
+#pragma unroll
+      for (int x = 0; x < 3; ++x) {
+        double sacc = 0.0;
+#pragma unroll
+        for (int a = 0; a < 4; ++a) sacc = fma(hr[d * 4 + a], X[a][x], sacc);
+        J[d][x] = sacc;
+      }
+    const double c00 = J[1][1] * J[2][2] - J[1][2] * J[2][1];
+    const double c01 = J[1][2] * J[2][0] - J[1][0] * J[2][2];
+    const double c02 = J[1][0] * J[2][1] - J[1][1] * J[2][0];
+    const double det = J[0][0] * c00 + J[0][1] * c01 + J[0][2] * c02;
+    const double r = 1.0 / det;
+    double Ji[3][3];
+    Ji[0][0] = c00 * r;
+    Ji[0][1] = (J[0][2] * J[2][1] - J[0][1] * J[2][2]) * r;
+    Ji[0][2] = (J[0][1] * J[1][2] - J[0][2] * J[1][1]) * r;
+    Ji[1][0] = c01 * r;
+    Ji[1][1] = (J[0][0] * J[2][2] - J[0][2] * J[2][0]) * r;
+    Ji[1][2] = (J[0][2] * J[1][0] - J[0][0] * J[1][2]) * r;
+    Ji[2][0] = c02 * r;
+    Ji[2][1] = (J[0][1] * J[2][0] - J[0][0] * J[2][1]) * r;
+    Ji[2][2] = (J[0][0] * J[1][1] - J[0][1] * J[1][0]) * r;
+    double G[3][4];
+#pragma unroll
+    for (int x = 0; x < 3; ++x)
+#pragma unroll
+      for (int a = 0; a < 4; ++a) G[x][a] = fma(Ji[x][2], hr[8 + a], fma(Ji[x][1], hr[4 + a], Ji[x][0] * hr[a]));
+    const double cw = wsum * det;
+    const unsigned rsw[2] = {rs4.x, rs4.y};
+#pragma unroll
+    for (int a = 0; a < 4; ++a) {
+      const unsigned slot = (rsw[a >> 1] >> (16 * (a & 1))) & 0xFFFFu;
+      if (slot == 0xFFFFu) continue;
+      double* row = acc + slot * ml;
+      if (bcn) {
+        unsigned m = 0;
+#pragma unroll
+        for (int b = 0; b < 4; ++b)
+          if ((bcn >> b) & 1u) m |= 1u << ((kw[a] >> (8 * b)) & 0xFFu);
+        atomicOr(&cflag[slot], m);
       }
 #pragma unroll
-      for (int u = 0; u < UNROLL; ++u) {
-        if (k >= (m1[u] & 0xFFFF)) continue;
-        double va, vr;
-        if (m1[u] >> 16) {
-          va = vr = (cb[u] == 2) ? 1.0 : 0.0;
-        } else if (cb[u]) {
-          va = 0.0;
-          vr = -v[u];
-        } else {
-          va = v[u];
-          vr = 0.0;
-        }
-        outA[lo[u] + k] = va;
-        if (outR) outR[lo[u] + k] = vr;
+      for (int b = 0; b < 4; ++b) {
+        const unsigned k = (kw[a] >> (8 * b)) & 0xFFu;
+        atomicAdd(&row[k], cw * (G[0][a] * G[0][b] + G[1][a] * G[1][b] + G[2][a] * G[2][b]));
       }
     }
   }
+  __syncthreads();
+  plan_store_rows(T, acc, rmeta, cflag, r_lo, nrows, ml, tid);
 }
-
-
 
 // =================================================================================================
 // Tiled KLE assembly (3 DOF per node): K, Krhs (WHICH = 0) and Rw (WHICH = 1) of
@@ -812,7 +915,7 @@ extern "C" int pyn_patch_plan_set_kind(pyn_ctx* c, int kind, int n_patch, const 
   if (n_patch == 0) return PYN_OK;
   PYN_CHECK(patch_ptr && patch_rows, "NULL argument");
   PYN_CHECK(c->d_rowptr, "pyn_csr_symbolic first");
-  PYN_CHECK(c->dim == 3 && c->nn == 8, "patch plans are implemented for Q1 hexahedra");
+  PYN_CHECK(c->dim == 3 && (c->nn == 8 || (c->nn == 4 && kind == 0)), "patch plans are implemented for Q1 hexahedra (and, scalar forms, linear tetrahedra)");
   PYN_CHECK(patch_ptr[0] == 0 && patch_ptr[n_patch] == c->n_owned, "patches must cover the owned rows exactly once");
   int max_rows = 0;
   for (int p = 0; p < n_patch; ++p) {
@@ -889,6 +992,8 @@ extern "C" int pyn_patch_plan_set_kind(pyn_ctx* c, int kind, int n_patch, const 
     PYN_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(assemble_q1_hex_tiled_kernel<1>),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     PYN_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(assemble_q1_hex_tiled_kernel<2>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    PYN_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(assemble_p1_tet_tiled_kernel),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   } else {
     size_t lds = kle_lds_bytes(max_rows, maxlen);
@@ -1015,7 +1120,8 @@ static int assemble_kle_tiled(pyn_ctx* c, double alpha_d, double alpha_w, double
 // particular, but any partition is valid and even 8x redundant integration beats the HBM-atomic scatter.
 
 static int ensure_default_plan(pyn_ctx* c, int kind) {
-  if (c->plan[kind].npatch || c->dim != 3 || c->nn != 8 || getenv("PYNAMA_NO_AUTO_PLAN")) return PYN_OK;
+  const bool tets = kind == 0 && c->nn == 4 && c->quad[0].const_grad;
+  if (c->plan[kind].npatch || c->plan_unfit[kind] || c->dim != 3 || !(c->nn == 8 || tets) || getenv("PYNAMA_NO_AUTO_PLAN")) return PYN_OK;
   const int64_t n = c->n_owned;
   std::vector<int32_t> ptr, rows((size_t)n);
   if (c->lat.valid) {
@@ -1042,8 +1148,13 @@ static int ensure_default_plan(pyn_ctx* c, int kind) {
     for (int64_t i = 0; i < n; ++i) rows[i] = (int32_t)i;
   }
   g_default_plan = true;
-  const int rc = pyn_patch_plan_set_kind(c, kind, (int)ptr.size() - 1, ptr.data(), rows.data());
+  int rc = pyn_patch_plan_set_kind(c, kind, (int)ptr.size() - 1, ptr.data(), rows.data());
   g_default_plan = false;
+  if (rc != PYN_OK && tets) {   // e.g. rows longer than the 32 entries the store phase handles: atomics kernel instead
+    (void)pyn_patch_plan_set_kind(c, kind, 0, nullptr, nullptr);
+    c->plan_unfit[kind] = true;
+    rc = PYN_OK;
+  }
   return rc;
 }
 
@@ -1062,7 +1173,8 @@ int pyn_assemble_q1_tiled(pyn_ctx* c, int form, double alpha_d, double alpha_w, 
   if (form == PYN_FORM_KLE && K && !Rd) return assemble_kle_tiled(c, alpha_d, alpha_w, K, Krhs, Rw, handled);
   PatchPlan& P = c->plan[0];
   if (!P.npatch || form != PYN_FORM_LAPLACE || !K || Rw || Rd) return PYN_OK;
-  if (c->dim != 3 || c->nn != 8 || c->quad[0].ngp != 8) return PYN_OK;
+  const bool tets = c->dim == 3 && c->nn == 4 && c->quad[0].const_grad && !getenv("PYNAMA_NO_P1_TILED");
+  if (!tets && (c->dim != 3 || c->nn != 8 || c->quad[0].ngp != 8)) return PYN_OK;
   TileArgs T;
   T.conn = c->d_conn;
   T.xyz = c->d_xyz;
@@ -1089,7 +1201,9 @@ int pyn_assemble_q1_tiled(pyn_ctx* c, int form, double alpha_d, double alpha_w, 
   size_t lds = (size_t)P.maxrows * P.maxlen * sizeof(double) + (size_t)P.maxrows * 3 * sizeof(int);
   const char* ab = getenv("PYNAMA_TILED_ABLATE");  // diagnostics only: 1 = no LDS adds, 2 = no quadrature
   const int abl = ab ? atoi(ab) : 0;
-  if (abl == 1)
+  if (tets)
+    assemble_p1_tet_tiled_kernel<<<P.npatch, TILE_THREADS, lds, c->stream>>>(T, c->quad[0].wsum);
+  else if (abl == 1)
     assemble_q1_hex_tiled_kernel<1><<<P.npatch, TILE_THREADS, lds, c->stream>>>(T);
   else if (abl == 2)
     assemble_q1_hex_tiled_kernel<2><<<P.npatch, TILE_THREADS, lds, c->stream>>>(T);

@@ -165,6 +165,7 @@ struct pyn_ctx {
 
   // patch plans of the tiled assemblies (pyn_assemble_tiled.hip): [0] scalar forms, [1] KLE (3x3 blocks)
   PatchPlan plan[2];
+  bool plan_unfit[2] = {false, false};  // the automatic plan did not fit this graph (reset by pyn_csr_symbolic)
   Lattice lat;  // structured topology, if the mesh has one (plan-free assembly kernel)
 
   // SELL-64 structures, one per block shape, + the node-level column-pattern dictionary (pyn_sell.hip)

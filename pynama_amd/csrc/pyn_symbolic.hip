@@ -42,6 +42,7 @@ static int pyn_symbolic_reset_dependents(pyn_ctx* c) {
   c->mats.clear();
   pyn_sell_drop_structure(c);
   c->lat.std_ok = -1;  // closed-form row offsets are re-verified against the new graph
+  c->plan_unfit[0] = c->plan_unfit[1] = false;
   return PYN_OK;
 }
 

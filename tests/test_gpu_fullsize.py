@@ -157,14 +157,14 @@ def test_c5_unstructured_tets_gmsh_gmres(tmp_path):
     n_edges = len(np.unique(edges[:, 0].astype(np.int64) * src.n_node + edges[:, 1]))
     assert nnz == n_rows + 2 * n_edges                                  # node graph = mesh edges + diagonal
     del edges
-    # (1) no mask: the one-lane-per-cell kernel and the table-driven generic kernel agree entry by entry
+    # (1) no mask: the LDS patch kernel and the one-lane-per-cell atomics kernel agree entry by entry
     A, B = ctx.mat_create(1, 1), ctx.mat_create(1, 1)
     ctx.assemble_scalar(_lib.FORM_LAPLACE, A)
-    os.environ["PYNAMA_NO_P1"] = "1"
+    os.environ["PYNAMA_NO_P1_TILED"] = "1"          # the one-lane-per-cell atomics kernel instead of the LDS patch kernel
     try:
         ctx.assemble_scalar(_lib.FORM_LAPLACE, B)
     finally:
-        del os.environ["PYNAMA_NO_P1"]
+        del os.environ["PYNAMA_NO_P1_TILED"]
     va, vb_ = ctx.mat_values(A, 1, 1), ctx.mat_values(B, 1, 1)
     assert np.abs(va - vb_).max() < 2e-13 * np.abs(vb_).max()
     del va, vb_

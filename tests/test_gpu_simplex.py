@@ -68,14 +68,19 @@ def test_simplex_assembly_and_krylov_vs_oracle(lib, dim, nelem):
     ref = fo.assemble_scalar(mesh, tb, "laplace", dirichlet=mesh.boundary)
     S = mat_to_scipy(ctx, A, 1, 1)
     assert sp_rel_err(S, ref["A"]) < FP_TOL and sp_rel_err(mat_to_scipy(ctx, Ar, 1, 1), ref["Arhs"]) < FP_TOL
-    os.environ["PYNAMA_NO_P1"] = "1"            # the table-driven generic kernel instead of the one-lane-per-cell one
-    try:
-        A2, Ar2 = ctx.mat_create(1, 1), ctx.mat_create(1, 1)
-        ctx.assemble_scalar(lib.FORM_LAPLACE, A2, Ar2)
-    finally:
-        del os.environ["PYNAMA_NO_P1"]
-    assert sp_rel_err(mat_to_scipy(ctx, A2, 1, 1), ref["A"]) < FP_TOL
-    assert sp_rel_err(mat_to_scipy(ctx, Ar2, 1, 1), ref["Arhs"]) < FP_TOL
+    # three independent device paths: LDS patch kernel (3-D default), one-lane-per-cell atomics kernel, and the
+    # table-driven generic kernel
+    for env in (("PYNAMA_NO_P1_TILED",), ("PYNAMA_NO_P1_TILED", "PYNAMA_NO_P1")):
+        for e in env:
+            os.environ[e] = "1"
+        try:
+            A2, Ar2 = ctx.mat_create(1, 1), ctx.mat_create(1, 1)
+            ctx.assemble_scalar(lib.FORM_LAPLACE, A2, Ar2)
+        finally:
+            for e in env:
+                del os.environ[e]
+        assert sp_rel_err(mat_to_scipy(ctx, A2, 1, 1), ref["A"]) < FP_TOL
+        assert sp_rel_err(mat_to_scipy(ctx, Ar2, 1, 1), ref["Arhs"]) < FP_TOL
     rng = np.random.default_rng(1)
     b = rng.standard_normal(mesh.n_node)
     b[mesh.boundary] = 0.0
