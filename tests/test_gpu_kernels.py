@@ -708,14 +708,14 @@ def test_lattice_kernel_parallelepipeds(lib, kind):
     ctx.close()
 
 
-@pytest.mark.parametrize("size", [2, 3])
-def test_lattice_kernel_on_rank_slabs(lib, size):
+@pytest.mark.parametrize("size,nz", [(2, 9), (3, 9), (4, 3)])
+def test_lattice_kernel_on_rank_slabs(lib, size, nz):
     """a rank's z-slab is a lattice whose ghost planes carry the LAST node ids: the z-order table of the
     plan-free kernel sorts the column blocks of interface rows accordingly"""
     from pynama_amd.common.comm import Comm
     from pynama_amd.domain.dmplex import DMPlexDom
     from pynama_amd.elements.spectral import Spectral
-    nelem = [6, 5, 9]
+    nelem = [6, 5, nz]                                # (4, 3): every rank owns ONE node plane, ghosts on both sides
     glob = fo.box_mesh(nelem, [0, 0, 0], [1, 1, 1], 2, jitter=0.2)
     ref = fo.assemble_scalar(glob, fo.Tables(2, 3), "laplace", dirichlet=glob.boundary)
     for r in range(size):
@@ -881,12 +881,12 @@ def test_assemble_kle_lattice_kernel(lib, tile, kind):
         del os.environ["PYNAMA_KLE_LATTICE_TILE"]
 
 
-@pytest.mark.parametrize("size", [2, 3])
-def test_kle_lattice_kernel_on_rank_slabs(lib, size):
+@pytest.mark.parametrize("size,nz", [(2, 9), (3, 9), (4, 3)])
+def test_kle_lattice_kernel_on_rank_slabs(lib, size, nz):
     from pynama_amd.common.comm import Comm
     from pynama_amd.domain.dmplex import DMPlexDom
     from pynama_amd.elements.spectral import Spectral
-    nelem = [5, 4, 9]
+    nelem = [5, 4, nz]
     glob = fo.box_mesh(nelem, [0, 0, 0], [1, 1, 1], 2)
     ref = fo.assemble_kle_freeslip(glob, fo.Tables(2, 3))
     for r in range(size):
