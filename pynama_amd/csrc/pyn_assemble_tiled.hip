@@ -284,6 +284,128 @@ __global__ void __launch_bounds__(TILE_THREADS, 2) assemble_q1_hex_tiled_kernel(
   plan_store_rows(T, acc, rmeta, cflag, r_lo, nrows, ml, tid);
 }
 
+// All-parallelepiped meshes without structured topology (imported / renumbered hexahedral meshes; checked once per
+// mesh on the device): four corner loads, J = S.E from the edge vectors, L_ab from the integer reference matrices
+// right before its LDS adds -- the integration of the lattice kernel's lean path behind the patch plan.
+__global__ void __launch_bounds__(TILE_THREADS, 4) assemble_q1_hex_tiled_affine_kernel(TileArgs T) {
+  extern __shared__ __align__(16) double acc[];
+  const int p = blockIdx.x;
+  const int r_lo = T.p_rowptr[p];
+  const int nrows = T.p_rowptr[p + 1] - r_lo;
+  const int e_lo = T.p_eptr[p];
+  const int ne = T.p_eptr[p + 1] - e_lo;
+  const int ml = T.maxlen;
+  int* rmeta = reinterpret_cast<int*>(acc + (size_t)T.maxrows * ml);
+  unsigned* cflag = reinterpret_cast<unsigned*>(rmeta + 2 * T.maxrows);
+  const int tid = threadIdx.x;
+  for (int i = tid; i < nrows * ml; i += TILE_THREADS) acc[i] = 0.0;
+  for (int sl = tid; sl < nrows; sl += TILE_THREADS) {
+    cflag[sl] = 0u;
+    const int row = T.p_rows[r_lo + sl];
+    const int lo = T.rowptr[row], hi = T.rowptr[row + 1];
+    rmeta[2 * sl] = lo;
+    rmeta[2 * sl + 1] = (hi - lo) | ((T.bcmask && T.bcmask[row]) ? (1 << 16) : 0);
+  }
+  __syncthreads();
+  const double* __restrict__ S = T.aff + 248;
+  for (int t = tid; t < ne; t += TILE_THREADS) {
+    const int64_t pe = (int64_t)e_lo + t;
+    const int e = T.p_elem[pe];
+    const int4 c0 = reinterpret_cast<const int4*>(T.conn)[(int64_t)e * 2];
+    const int4 c1 = reinterpret_cast<const int4*>(T.conn)[(int64_t)e * 2 + 1];
+    const int nd[8] = {c0.x, c0.y, c0.z, c0.w, c1.x, c1.y, c1.z, c1.w};
+    // corners 0, 3 (+x), 1 (+y), 4 (+z) of the closure order span the parallelepiped
+    const double* q0 = T.xyz + (int64_t)nd[0] * 3;
+    const double* qx = T.xyz + (int64_t)nd[3] * 3;
+    const double* qy = T.xyz + (int64_t)nd[1] * 3;
+    const double* qz = T.xyz + (int64_t)nd[4] * 3;
+    double E[3][3];
+#pragma unroll
+    for (int x = 0; x < 3; ++x) {
+      const double o = q0[x];
+      E[0][x] = qx[x] - o;
+      E[1][x] = qy[x] - o;
+      E[2][x] = qz[x] - o;
+    }
+    unsigned bcn = 0;
+    if (T.bcmask) {
+#pragma unroll
+      for (int b = 0; b < 8; ++b) bcn |= (T.bcmask[nd[b]] ? 1u : 0u) << b;
+    }
+    const uint4 rs4 = T.rowslot4[pe];
+    uint4 km4[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) km4[j] = T.kmap4[(int64_t)j * T.npe + pe];
+    double J[3][3];
+#pragma unroll
+    for (int d = 0; d < 3; ++d)
+#pragma unroll
+      for (int x = 0; x < 3; ++x) J[d][x] = fma(S[d * 3 + 2], E[2][x], fma(S[d * 3 + 1], E[1][x], S[d * 3] * E[0][x]));
+    const double c00 = J[1][1] * J[2][2] - J[1][2] * J[2][1];
+    const double c01 = J[1][2] * J[2][0] - J[1][0] * J[2][2];
+    const double c02 = J[1][0] * J[2][1] - J[1][1] * J[2][0];
+    const double det = J[0][0] * c00 + J[0][1] * c01 + J[0][2] * c02;
+    const double r = 1.0 / det;
+    double Ji[3][3];
+    Ji[0][0] = c00 * r;
+    Ji[0][1] = (J[0][2] * J[2][1] - J[0][1] * J[2][2]) * r;
+    Ji[0][2] = (J[0][1] * J[1][2] - J[0][2] * J[1][1]) * r;
+    Ji[1][0] = c01 * r;
+    Ji[1][1] = (J[0][0] * J[2][2] - J[0][2] * J[2][0]) * r;
+    Ji[1][2] = (J[0][2] * J[1][0] - J[0][0] * J[1][2]) * r;
+    Ji[2][0] = c02 * r;
+    Ji[2][1] = (J[0][1] * J[2][0] - J[0][0] * J[2][1]) * r;
+    Ji[2][2] = (J[0][0] * J[1][1] - J[0][1] * J[1][0]) * r;
+    double D[3][3], M2[3][2];
+    {
+      constexpr int RS[6][2] = {{0, 0}, {1, 1}, {2, 2}, {0, 1}, {0, 2}, {1, 2}};
+#pragma unroll
+      for (int u = 0; u < 3; ++u) {
+        const int a0 = RS[u][0], a1 = RS[3 + u][0], b1 = RS[3 + u][1];
+        const double qd = det * (Ji[0][a0] * Ji[0][a0] + Ji[1][a0] * Ji[1][a0] + Ji[2][a0] * Ji[2][a0]) * (1.0 / 72.0);
+        const double qm = det * (Ji[0][a1] * Ji[0][b1] + Ji[1][a1] * Ji[1][b1] + Ji[2][a1] * Ji[2][b1]) * (1.0 / 72.0);
+        D[u][0] = 4.0 * qd, D[u][1] = 8.0 * qd, D[u][2] = 16.0 * qd;
+        M2[u][0] = 12.0 * qm, M2[u][1] = 24.0 * qm;
+      }
+    }
+    const unsigned rsw[4] = {rs4.x, rs4.y, rs4.z, rs4.w};
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const unsigned kw[4] = {km4[j].x, km4[j].y, km4[j].z, km4[j].w};
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        const int a = 2 * j + h;
+        const unsigned slot = (rsw[j] >> (16 * h)) & 0xFFFFu;
+        if (slot == 0xFFFFu) continue;
+        double* row = acc + slot * ml;
+        if (bcn) {
+          unsigned m = 0;
+#pragma unroll
+          for (int b = 0; b < 8; ++b)
+            if ((bcn >> b) & 1u) m |= 1u << ((kw[2 * h + (b >> 2)] >> (8 * (b & 3))) & 0xFFu);
+          atomicOr(&cflag[slot], m);
+        }
+#pragma unroll
+        for (int b = 0; b < 8; ++b) {
+          const unsigned k = (kw[2 * h + (b >> 2)] >> (8 * (b & 3))) & 0xFFu;
+          double v = 0.0;
+#pragma unroll
+          for (int u = 0; u < 6; ++u) {
+            const int n = q1_aff_int(u, a, b);
+            const int an = n < 0 ? -n : n;
+            if (an == 0) continue;
+            const double x = u < 3 ? D[u][an == 4 ? 0 : (an == 8 ? 1 : 2)] : M2[u - 3][an == 12 ? 0 : 1];
+            v = n > 0 ? v + x : v - x;
+          }
+          atomicAdd(&row[k], v);
+        }
+      }
+    }
+  }
+  __syncthreads();
+  plan_store_rows(T, acc, rmeta, cflag, r_lo, nrows, ml, tid);
+}
+
 // Linear tetrahedra through the same patch scheme (BASELINE.json configs[4], irregular indexing): patches of
 // consecutive rows (compact in the Morton numbering of imported meshes), one element per lane, constant gradients
 // G = J^-1 Hrs (table-driven), 16 LDS adds, rows written once -- no HBM atomics.
@@ -995,6 +1117,8 @@ extern "C" int pyn_patch_plan_set_kind(pyn_ctx* c, int kind, int n_patch, const 
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     PYN_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(assemble_p1_tet_tiled_kernel),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    PYN_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(assemble_q1_hex_tiled_affine_kernel),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   } else {
     size_t lds = kle_lds_bytes(max_rows, maxlen);
     PYN_CHECK(lds <= 160 * 1024, "KLE patch accumulators need %zu B of LDS", lds);
@@ -1201,8 +1325,12 @@ int pyn_assemble_q1_tiled(pyn_ctx* c, int form, double alpha_d, double alpha_w, 
   size_t lds = (size_t)P.maxrows * P.maxlen * sizeof(double) + (size_t)P.maxrows * 3 * sizeof(int);
   const char* ab = getenv("PYNAMA_TILED_ABLATE");  // diagnostics only: 1 = no LDS adds, 2 = no quadrature
   const int abl = ab ? atoi(ab) : 0;
+  int all_aff = 0;
+  if (!tets && T.aff && c->aff_standard && !abl && !getenv("PYNAMA_NO_LEAN_PLAN")) PYN_TRY(pyn_mesh_all_affine(c, &all_aff));
   if (tets)
     assemble_p1_tet_tiled_kernel<<<P.npatch, TILE_THREADS, lds, c->stream>>>(T, c->quad[0].wsum);
+  else if (all_aff)
+    assemble_q1_hex_tiled_affine_kernel<<<P.npatch, TILE_THREADS, lds, c->stream>>>(T);
   else if (abl == 1)
     assemble_q1_hex_tiled_kernel<1><<<P.npatch, TILE_THREADS, lds, c->stream>>>(T);
   else if (abl == 2)
