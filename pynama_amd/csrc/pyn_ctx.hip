@@ -99,6 +99,8 @@ extern "C" int pyn_ctx_destroy(pyn_ctx* c) {
   (void)hipFree(c->d_conn);
   (void)hipFree(c->d_xyz);
   (void)hipFree(c->d_aff);
+  (void)hipFree(c->lat.d_P);
+  (void)hipFree(c->lat.d_zord);
   (void)hipFree(c->d_bcmask);
   (void)hipFree(c->d_rowptr);
   (void)hipFree(c->d_colidx);
