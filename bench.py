@@ -173,7 +173,7 @@ def main():
         traffic = {}
         try:
             if world.size == 1 and n == 215:
-                with open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")) as fh:
+                with open(os.path.join(ROOT, "profiles", "r01c_pmc_traffic.json")) as fh:
                     traffic = {k: v["hbm_bytes_per_launch"] for k, v in json.load(fh)["kernels"].items()}
         except (OSError, KeyError, ValueError):
             traffic = {}
