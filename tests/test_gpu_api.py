@@ -233,3 +233,44 @@ def test_save_step_writes_hdf5_and_xdmf(tmp_path):
     assert np.array_equal(hdf5_writer.read_dataset(os.path.join(d, "vec-data-00003.h5"), "/fields/vorticity"), fem.vort.getArray())
     assert np.array_equal(hdf5_writer.read_dataset(os.path.join(d, "mesh.h5"), "/fields/mesh"), fem.dom.fullCoordVec.getArray())
     assert os.path.exists(os.path.join(d, f"{fem.caseName}.xmf"))
+
+
+class TestDomainVecHelpers:
+    """src/tests/test_domain.py:175-248 (DomainModTests2D): coordinates and the apply*ToVec helpers, here writing
+    into device vectors"""
+
+    def setup_method(self):
+        from domain.dmplex import DMPlexDom
+        from elements.spectral import Spectral
+        self.dom = DMPlexDom(boxMesh={'lower': [0, 0], 'upper': [1, 1], "nelem": [2, 2]})
+        self.dom.setFemIndexing(2)
+        self.dom.computeFullCoordinates(Spectral(2, 2))
+        self.testVelVec = self.dom.createGlobalVec()
+        self.coords = np.array([[0., 0.], [0.5, 0.], [1., 0.], [0., 0.5], [0.5, 0.5], [1., 0.5], [0., 1.], [0.5, 1.], [1., 1.]])
+
+    def test_get_nodes_coordinates_2D(self):                       # :197-201
+        np.testing.assert_array_almost_equal(self.coords, self.dom.getNodesCoordinates(self.dom.getAllNodes()))
+
+    def test_set_function_vec_to_vec_2D(self):                     # :205-214
+        f = lambda c: (np.sqrt(c[0]), np.sqrt(c[1]))
+        self.dom.applyFunctionVecToVec(self.dom.getAllNodes(), f, self.testVelVec, 2)
+        np.testing.assert_array_almost_equal(np.sqrt(self.coords), self.testVelVec.getArray().reshape(9, 2), decimal=12)
+
+    def test_set_function_vec_to_vec_2D_some_nodes(self):          # :216-227
+        expect = np.sqrt(np.array([[0., 0.], [1, 1.], [1., 1.], [0., 0.5], [1., 1.], [1., 1.], [1., 1.], [0.5, 1.], [1., 1.]]))
+        self.testVelVec.set(1.0)
+        f = lambda c: (np.sqrt(c[0]), np.sqrt(c[1]))
+        self.dom.applyFunctionVecToVec([0, 3, 7], f, self.testVelVec, 2)
+        np.testing.assert_array_almost_equal(expect, self.testVelVec.getArray().reshape(9, 2), decimal=12)
+
+    def test_set_function_scalar_to_vec_2D(self):                  # :229-238
+        from pynama_amd.vectors import Vec
+        vec = Vec(self.dom.ctx, 1)
+        self.dom.applyFunctionScalarToVec(self.dom.getAllNodes(), lambda c: c[0] + c[1], vec)
+        np.testing.assert_array_almost_equal([0, 0.5, 1, 0.5, 1., 1.5, 1, 1.5, 2], vec.getArray(), decimal=12)
+
+    def test_set_constant_to_vec_2D(self):                         # :240-248
+        from pynama_amd.vectors import Vec
+        vec = Vec(self.dom.ctx, 2)
+        self.dom.applyValuesToVec(self.dom.getAllNodes(), [3, 5], vec)
+        np.testing.assert_array_almost_equal(np.array([3, 5] * 9).reshape(9, 2), vec.getArray().reshape(9, 2), decimal=12)
