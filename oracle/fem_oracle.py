@@ -19,7 +19,6 @@ captured PETSc vectors exist ("parity unpinned" w.r.t. PETSc's own iterates).
 """
 from __future__ import annotations
 
-import itertools
 from dataclasses import dataclass
 
 import numpy as np

@@ -1,7 +1,6 @@
 """Wall bookkeeping of the no-slip split: the known answers of the reference's own suite
 (/root/reference/src/tests/test_nswalls.py:6-373) on pynama_amd.common.nswalls."""
 import numpy as np
-import pytest
 
 from pynama_amd.common.nswalls import NoSlipWalls
 

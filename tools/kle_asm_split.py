@@ -1,7 +1,6 @@
 import os, sys
 import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-from pynama_amd import _lib
 from pynama_amd.domain.dmplex import DMPlexDom
 from pynama_amd.elements.spectral import Spectral
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 128
