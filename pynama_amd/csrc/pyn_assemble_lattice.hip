@@ -26,7 +26,8 @@ struct LatArgs {
   int ntx, nty;            // tiles per direction
   int std_lat;             // P[j] == j*nx*ny, all planes owned, standard z order: plane bases, z codes AND row offsets
                            // come from arithmetic (no index loads at all)
-  int ablate;              // diagnostics (PYNAMA_LATTICE_ABLATE): 1 no element phase, 2 no LDS adds, 3 no coordinate loads
+  int ablate;              // diagnostics (PYNAMA_LATTICE_ABLATE): 1 no element phase, 4 no plain-tile store path,
+                           // 6 round-robin instead of XCD-contiguous tile order
   TileArgs q;              // quadrature tables (w, hrs, hcoo, aff) -- only those fields are used
   double* A;
   double* Arhs;
@@ -387,6 +388,13 @@ __global__ void lattice_rowptr_check_kernel(LatArgs T, const int32_t* __restrict
   if (rowptr[i] != lat_rowptr_std(T, x, y, zo)) *flag = 0;
 }
 
+// Workgroups are dealt round-robin to the 8 XCDs (each with its own L2).  Remap so that every XCD works on ONE
+// contiguous range of tiles: neighbouring tiles share node coordinates / flags, which then hit the same L2.
+__device__ __forceinline__ int xcd_contiguous_tile(int bid, int n) {
+  const int q = n >> 3, r = n & 7, j = bid & 7, idx = bid >> 3;
+  return j * q + (j < r ? j : r) + idx;
+}
+
 // one tile per workgroup
 template <int TX, int TY, int TZ, bool AFF>
 __global__ void __launch_bounds__(TILE_THREADS, AFF ? 3 : 2) assemble_q1_hex_lattice_kernel(LatArgs T) {
@@ -397,7 +405,7 @@ __global__ void __launch_bounds__(TILE_THREADS, AFF ? 3 : 2) assemble_q1_hex_lat
   int* zrd = rlo + LT::NR;
   unsigned char* nbc = reinterpret_cast<unsigned char*>(zrd + TZ);
   const int tid = threadIdx.x;
-  const int b = blockIdx.x;
+  const int b = T.ablate == 6 ? (int)blockIdx.x : xcd_contiguous_tile(blockIdx.x, gridDim.x);
   const int bx = b % T.ntx, by = (b / T.ntx) % T.nty, bz = b / (T.ntx * T.nty);
   const int x0 = bx * TX, y0 = by * TY, z0 = bz * TZ;
   LatMeta<TX, TY, TZ, TILE_THREADS> meta;
@@ -523,7 +531,7 @@ __global__ void __launch_bounds__(256, 3) assemble_q1_hex_kle_lattice_kernel(Kle
   unsigned char* nbc = reinterpret_cast<unsigned char*>(zrd + TZ);
   const LatArgs& L = T.L;
   const int tid = threadIdx.x, lane = tid & 63, part = tid >> 6;
-  const int b = blockIdx.x;
+  const int b = L.ablate == 6 ? (int)blockIdx.x : xcd_contiguous_tile(blockIdx.x, gridDim.x);
   const int bx = b % L.ntx, by = (b / L.ntx) % L.nty, bz = b / (L.ntx * L.nty);
   const int x0 = bx * TX, y0 = by * TY, z0 = bz * TZ;
   const int nx = L.nx, ny = L.ny;
