@@ -209,6 +209,9 @@ typedef struct pyn_solve_opts {
   int fixed_iters;   /* >0: run exactly this many iterations, no convergence exit (benchmarking) */
   int profile;       /* !=0: bracket every SpMV launch with HIP events (first 256 iterations) */
   int cg_variant;    /* 0 auto, 1 standard PCG, 2 single-reduction PCG (Chronopoulos-Gear; default for nranks>1) */
+  int gmres_orthog;  /* 0 classical Gram-Schmidt + one refinement pass (-ksp_gmres_cgs_refinement_type refine_always),
+                        1 classical without refinement (refine_never, PETSc's own default), 2 modified Gram-Schmidt
+                        (-ksp_gmres_modifiedgramschmidt) */
   double rtol, atol, dtol;   /* PETSc defaults 1e-5, 1e-50, 1e5 */
 } pyn_solve_opts;
 typedef struct pyn_solve_info {

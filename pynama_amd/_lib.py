@@ -31,7 +31,7 @@ class PynamaHipError(RuntimeError):
 class SolveOpts(C.Structure):
     _fields_ = [("method", C.c_int), ("pc", C.c_int), ("norm_type", C.c_int), ("maxit", C.c_int),
                 ("restart", C.c_int), ("fixed_iters", C.c_int), ("profile", C.c_int), ("cg_variant", C.c_int),
-                ("rtol", C.c_double), ("atol", C.c_double), ("dtol", C.c_double)]
+                ("gmres_orthog", C.c_int), ("rtol", C.c_double), ("atol", C.c_double), ("dtol", C.c_double)]
 
 
 class SolveInfo(C.Structure):
@@ -380,8 +380,8 @@ class Context:
         _check(self.lib.pyn_spmv(self.h, mid, x, y))
 
     def solve(self, mid, b, x, method=KSP_CG, pc=PC_JACOBI, rtol=1e-5, atol=1e-50, dtol=1e5, maxit=10000,
-              restart=30, norm_type=NORM_PRECONDITIONED, fixed_iters=0, profile=0, cg_variant=0) -> SolveInfo:
-        o = SolveOpts(method, pc, norm_type, maxit, restart, fixed_iters, profile, cg_variant, rtol, atol, dtol)
+              restart=30, norm_type=NORM_PRECONDITIONED, fixed_iters=0, profile=0, cg_variant=0, gmres_orthog=0) -> SolveInfo:
+        o = SolveOpts(method, pc, norm_type, maxit, restart, fixed_iters, profile, cg_variant, gmres_orthog, rtol, atol, dtol)
         info = SolveInfo()
         _check(self.lib.pyn_solve(self.h, mid, b, x, C.byref(o), C.byref(info)))
         return info

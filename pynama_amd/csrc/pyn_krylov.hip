@@ -781,7 +781,8 @@ static int solve_gmres(pyn_ctx* c, const DMat& A, const double* b, double* x, co
   double* mpart = dinv + n;         // (m+1) x MD_GRID partial sums of the fused projections
   double* dh = mpart + (int64_t)(m + 1) * MD_GRID;       // device copy of the projection coefficients
   std::vector<double> hh_host((size_t)3 * mh);
-  const bool mgs = getenv("PYNAMA_GMRES_MGS") != nullptr;
+  const bool mgs = o.gmres_orthog == 2 || getenv("PYNAMA_GMRES_MGS") != nullptr;
+  const int npass = o.gmres_orthog == 1 ? 1 : 2;
   const int mdg = (int)std::max<int64_t>(1, std::min<int64_t>((n + 255) / 256, MD_GRID));
   const bool jac = o.pc == PYN_PC_JACOBI;
   if (jac) PYN_TRY(pyn_extract_diag_inv(c, A, dinv, true));
@@ -836,7 +837,7 @@ static int solve_gmres(pyn_ctx* c, const DMat& A, const double* b, double* x, co
         if (hh > 0) waxpby_kernel<<<g, 256, 0, s>>>(vn, 1.0 / hh, vn, 0.0, vn, n);
       } else {
         const int k1 = k + 1;
-        for (int pass = 0; pass < 2; ++pass) {          // projection + update, then once more (refinement)
+        for (int pass = 0; pass < npass; ++pass) {      // projection + update (, then once more: refinement)
           multi_dot_kernel<<<mdg, 256, 0, s>>>(V, nl, k1, vn, n, mpart);
           multi_finish_kernel<<<k1, 256, 0, s>>>(mpart, mdg, dh + pass * mh);
           if (c->comm) PYN_NCCL(ncclAllReduce(dh + pass * mh, dh + pass * mh, k1, ncclDouble, ncclSum, c->comm, s));
@@ -848,7 +849,7 @@ static int solve_gmres(pyn_ctx* c, const DMat& A, const double* b, double* x, co
         scale_rsqrt_kernel<<<g, 256, 0, s>>>(vn, dh + 2 * mh, n);
         PYN_HIP(hipMemcpyAsync(hh_host.data(), dh, 3 * mh * sizeof(double), hipMemcpyDeviceToHost, s));
         PYN_HIP(hipStreamSynchronize(s));
-        for (int j = 0; j <= k; ++j) H[(size_t)j * m + k] = hh_host[j] + hh_host[mh + j];
+        for (int j = 0; j <= k; ++j) H[(size_t)j * m + k] = hh_host[j] + (npass == 2 ? hh_host[mh + j] : 0.0);
         hh = sqrt(std::max(0.0, hh_host[2 * mh]));
       }
       H[(size_t)(k + 1) * m + k] = hh;

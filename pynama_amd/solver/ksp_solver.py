@@ -4,7 +4,9 @@ Mirrors ``src/solver/ksp_solver.py:6-19`` (``KspSolver(KSP)``: ``createSolver(ma
 ``solver(b, x)`` == ``KSP.__call__`` == solve).  PETSc's KSP/PC objects become one C-ABI call,
 ``pyn_solve`` (device-resident Jacobi-PCG / GMRES).  Options follow PETSc's names:
 ``-ksp_type cg|gmres|preonly  -pc_type jacobi|none|lu  -ksp_rtol -ksp_atol -ksp_divtol
--ksp_max_it -ksp_gmres_restart -ksp_norm_type preconditioned|unpreconditioned|natural``.
+-ksp_max_it -ksp_gmres_restart -ksp_norm_type preconditioned|unpreconditioned|natural
+-ksp_gmres_modifiedgramschmidt -ksp_gmres_cgs_refinement_type refine_never|refine_ifneeded|refine_always``
+(GMRES orthogonalisation; default as in PETSc: classical Gram-Schmidt without refinement).
 
 The reference's hard-wired default is ``preonly`` + ``lu`` (:13-16).  There is no sparse direct
 solver on the device path: that combination is served by Jacobi-PCG driven to round-off
@@ -27,6 +29,7 @@ class KspSolver(object):
         self.ksp_type, self.pc_type = 'preonly', 'lu'
         self.rtol, self.atol, self.divtol, self.max_it = 1e-5, 1e-50, 1e5, 10000     # PETSc defaults
         self.restart = 30
+        self.gmres_orthog = 1            # KSPGMRES default: classical Gram-Schmidt, refine_never
         self.norm_type = "preconditioned"
         self.info = None
 
@@ -57,6 +60,14 @@ class KspSolver(object):
         self.max_it = o.getInt('ksp_max_it', self.max_it)
         self.restart = o.getInt('ksp_gmres_restart', self.restart)
         self.norm_type = o.getString('ksp_norm_type', self.norm_type)
+        if o.hasName('ksp_gmres_modifiedgramschmidt'):
+            self.gmres_orthog = 2
+        else:
+            ref = o.getString('ksp_gmres_cgs_refinement_type', None)
+            if ref is not None:
+                if ref not in ('refine_never', 'refine_ifneeded', 'refine_always'):
+                    raise ValueError(f"unknown -ksp_gmres_cgs_refinement_type {ref}")
+                self.gmres_orthog = 1 if ref == 'refine_never' else 0
 
     def setOperators(self, mat):
         self.mat = mat
@@ -90,7 +101,7 @@ class KspSolver(object):
                              method=_lib.KSP_CG if self.ksp_type == 'cg' else _lib.KSP_GMRES,
                              pc=_lib.PC_JACOBI if self.pc_type == 'jacobi' else _lib.PC_NONE,
                              rtol=self.rtol, atol=self.atol, dtol=self.divtol, maxit=self.max_it,
-                             restart=self.restart, norm_type=_NORMS[self.norm_type])
+                             restart=self.restart, norm_type=_NORMS[self.norm_type], gmres_orthog=self.gmres_orthog)
         self.info = info
         return info
 

@@ -345,10 +345,13 @@ def test_cg_zero_rhs_and_maxit(lib, variant):
     ctx.close()
 
 
-def test_gmres_matches_oracle(lib):
+@pytest.mark.parametrize("orthog", [0, 1, 2])
+def test_gmres_matches_oracle(lib, orthog):
+    """0: classical Gram-Schmidt + refinement (fused, default), 1: classical without refinement (PETSc's default),
+    2: modified Gram-Schmidt -- all reproduce the oracle's (modified Gram-Schmidt) iteration count and solution"""
     mesh, ctx, A, vb, vx, b = _poisson(lib, [8, 7, 6])
     S = mat_to_scipy(ctx, A, 1, 1)
-    info = ctx.solve(A, vb, vx, method=lib.KSP_GMRES, pc=lib.PC_JACOBI, rtol=1e-10, restart=30)
+    info = ctx.solve(A, vb, vx, method=lib.KSP_GMRES, pc=lib.PC_JACOBI, rtol=1e-10, restart=30, gmres_orthog=orthog)
     x_o, it_o, hist = fo.gmres(S, b, rtol=1e-10, restart=30)
     assert info.reason == 2 and abs(info.iters - it_o) <= 1
     assert rel_err(ctx.vec_get(vx, 1), x_o) < 1e-7

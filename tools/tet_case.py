@@ -76,8 +76,12 @@ for _ in range(3):
 ms = ctx.timers()["spmv_ms"]
 B_spmv = 12 * nnz + 4 * (n_rows + 1) + 16 * n_rows
 print(f"spmv ms {ms:.4f} -> {B_spmv / ms / 1e6:.0f} GB/s algorithmic")
-info = ctx.solve(A, vb, vx, method=_lib.KSP_GMRES, pc=_lib.PC_JACOBI, fixed_iters=300, restart=30)
-print(f"gmres(30) {info.iters} its in {info.solve_ms:.1f} ms -> {info.iters / info.solve_ms * 1e3:.0f} it/s")
+for og, name in ((0, "classical GS + refinement"), (1, "classical GS, no refinement"), (2, "modified GS")):
+    info = ctx.solve(A, vb, vx, method=_lib.KSP_GMRES, pc=_lib.PC_JACOBI, fixed_iters=300, restart=30, gmres_orthog=og)
+    print(f"gmres(30) [{name}] {info.iters} its in {info.solve_ms:.1f} ms -> {info.iters / info.solve_ms * 1e3:.0f} it/s")
+    info = ctx.solve(A, vb, vx, method=_lib.KSP_GMRES, pc=_lib.PC_JACOBI, rtol=1e-10, restart=30, maxit=100000,
+                     norm_type=_lib.NORM_UNPRECONDITIONED, gmres_orthog=og)
+    print(f"   to 1e-10: its {info.iters} reason {info.reason} true_resid {info.true_resid:.3e} ms {info.solve_ms:.1f}")
 info = ctx.solve(A, vb, vx, method=_lib.KSP_GMRES, pc=_lib.PC_JACOBI, rtol=1e-10, restart=30, maxit=100000,
                  norm_type=_lib.NORM_UNPRECONDITIONED)
 print("gmres to 1e-10: its", info.iters, "reason", info.reason, "true_resid", info.true_resid, "ms", info.solve_ms)
