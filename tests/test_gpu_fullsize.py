@@ -200,3 +200,45 @@ def test_c5_unstructured_tets_gmsh_gmres(tmp_path):
     assert info.reason == 2
     assert rel_err(xg, ctx.vec_get(v, 1)) < 1e-6
     ctx.close()
+
+
+def test_c4_poisson_256cubed_single_gpu_properties():
+    """configs[3] is 256^3 over 8 GPUs; the same mesh also fits ONE MI355X (16,974,593 DOFs, nnz 769^3 = 454,756,609:
+    5.4 GB of CSR values): closed-form graph, plan-free assembly, SELL image and CG at that size"""
+    from pynama_amd import _lib
+    n = 256
+    dom, ctx = _domain([n, n, n])
+    n_rows, nnz = ctx.csr_symbolic()
+    assert n_rows == (n + 1) ** 3 and nnz == (3 * n + 1) ** 3            # SURVEY.md 8a
+    assert ctx.mesh_topology() == ("lattice", n + 1, n + 1, n + 1)
+    A = ctx.mat_create(1, 1)
+    ctx.assemble_scalar(_lib.FORM_LAPLACE, A)
+    one, y, u, v, Au, Av = (ctx.vec_create(1) for _ in range(6))
+    ctx.vec_fill(one, 1.0)
+    ctx.spmv(A, one, y)
+    assert ctx.vec_norm(y, 3) < 1e-12                                    # constants annihilated
+    rng = np.random.default_rng(4)
+    ctx.vec_set(u, rng.standard_normal(n_rows))
+    ctx.vec_set(v, rng.standard_normal(n_rows))
+    ctx.spmv(A, u, Au)
+    ctx.spmv(A, v, Av)
+    assert abs(ctx.vec_dot(v, Au) - ctx.vec_dot(u, Av)) < 1e-10 * abs(ctx.vec_dot(v, Au))
+    # uniform mesh: the interior stencil is the classical 27-point one, diagonal 8 h / 3
+    h = 1.0 / n
+    e = np.zeros(n_rows)
+    centre = (n // 2) * (n + 1) ** 2 + (n // 2) * (n + 1) + n // 2
+    e[centre] = 1.0
+    ctx.vec_set(u, e)
+    ctx.spmv(A, u, Au)
+    col = ctx.vec_get(Au, 1)
+    assert abs(col[centre] - 8.0 * h / 3.0) < 1e-14
+    assert np.count_nonzero(col) == 27 - 6                               # face neighbours vanish for the trilinear Laplacian
+    bm = dom.boundaryMaskLocal()
+    ctx.bc_set(1, bm)
+    ctx.assemble_scalar(_lib.FORM_LAPLACE, A)
+    f = (1.0 + dom.xyz[:, 0] + np.exp(dom.xyz[:, 1] * dom.xyz[:, 2])) * h ** 3
+    f[bm != 0] = 0.0
+    ctx.vec_set(u, f)
+    info = ctx.solve(A, u, v, rtol=1e-10, norm_type=_lib.NORM_UNPRECONDITIONED, maxit=5000)
+    assert info.reason == 2 and info.true_resid <= 1e-10
+    ctx.close()
