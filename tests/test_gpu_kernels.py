@@ -911,3 +911,62 @@ def test_kle_lattice_kernel_on_rank_slabs(lib, size, nz):
         for mid, name in ((K, "K"), (Kr, "Krhs"), (Rw, "Rw")):
             assert sp_rel_err(mat_to_scipy(ctx, mid, 3, 3), ref[name][rows3][:, cols3]) < FP_TOL, name
         ctx.close()
+
+
+def test_lattice_kernels_fuzz_against_generic(lib):
+    """seeded sweep over box sizes, geometry (uniform / sheared / jittered), Dirichlet masks, tile shapes and slab
+    partitions: the plan-free scalar and KLE kernels equal the generic atomics kernel entry by entry (both on the
+    device: an independent implementation with a different data path)"""
+    import os
+    from pynama_amd.common.comm import Comm
+    from pynama_amd.domain.dmplex import DMPlexDom
+    from pynama_amd.elements.spectral import Spectral
+    rng = np.random.default_rng(20240607)
+    tables = Spectral(2, 3).deviceTables()
+    for case in range(24):
+        nelem = [int(v) for v in rng.integers(1, 15, size=3)]
+        size = int(rng.choice([1, 1, 2, 3]))
+        if nelem[2] + 1 < size:
+            size = 1
+        geom = rng.choice(["uniform", "sheared", "jitter"])
+        rank = int(rng.integers(0, size))
+        dom = DMPlexDom(boxMesh={'nelem': nelem, 'lower': [0, 0, 0], 'upper': [1.0, 0.7, 1.3]}, comm=Comm(rank, size),
+                        jitter=0.2 if geom == "jitter" else 0.0)
+        dom.setFemIndexing(2)
+        xyz = dom.xyz
+        if geom == "sheared":
+            xyz = xyz @ np.array([[1.0, 0.3, -0.2], [0.1, 0.9, 0.25], [-0.15, 0.2, 1.1]]).T
+        os.environ["PYNAMA_LATTICE_TILE"] = str(int(rng.integers(0, 10)))
+        os.environ["PYNAMA_KLE_LATTICE_TILE"] = str(int(rng.integers(0, 4)))
+        try:
+            ctx = lib.Context(0)
+            if size > 1:
+                ctx.comm_init(rank, size, None)
+                ctx.halo_set(*dom._halo_plan())
+            ctx.mesh_set(3, dom.conn, xyz)
+            for t in tables:
+                ctx.tables_set(*t)
+            ctx.csr_symbolic()
+            assert ctx.mesh_topology()[0] == "lattice"
+            # scalar
+            mask = (rng.random(dom.nLocal) < rng.choice([0.0, 0.1, 0.5])).astype(np.uint8)
+            ctx.bc_set(1, mask if mask.any() else None)
+            A, Ar, B, Br = (ctx.mat_create(1, 1) for _ in range(4))
+            ctx.assemble_scalar(lib.FORM_LAPLACE, A, Ar)                 # lattice kernel
+            ctx.assemble_scalar(lib.FORM_LAPLACE, B, Br, variant=0)      # generic atomics kernel
+            for x, y in ((A, B), (Ar, Br)):
+                vx, vy = ctx.mat_values(x, 1, 1), ctx.mat_values(y, 1, 1)
+                assert np.abs(vx - vy).max() <= FP_TOL * max(1e-300, np.abs(vy).max()), (case, nelem, size, rank, geom)
+            # KLE (the plan-free kernels need parallelepipeds; jittered meshes take the patch-plan kernels)
+            mask3 = (rng.random((dom.nLocal, 3)) < rng.choice([0.0, 0.15])).astype(np.uint8)
+            ctx.bc_set(3, mask3 if mask3.any() else None)
+            K, Kr, Rw, K0, Kr0, Rw0 = (ctx.mat_create(3, 3) for _ in range(6))
+            ctx.assemble_kle(1e3, 1e2, K, Kr, Rw, -1)
+            ctx.assemble_kle(1e3, 1e2, K0, Kr0, Rw0, -1, variant=0)
+            for x, y in ((K, K0), (Kr, Kr0), (Rw, Rw0)):
+                vx, vy = ctx.mat_values(x, 3, 3), ctx.mat_values(y, 3, 3)
+                assert np.abs(vx - vy).max() <= FP_TOL * max(1e-300, np.abs(vy).max()), (case, nelem, size, rank, geom, "kle")
+            ctx.close()
+        finally:
+            del os.environ["PYNAMA_LATTICE_TILE"]
+            del os.environ["PYNAMA_KLE_LATTICE_TILE"]
