@@ -50,6 +50,7 @@ struct AsmArgs {
   // scratch for high order
   double* gscratch;
   int64_t gscratch_stride;  // doubles per block
+  int ho_chunk;             // > 0: high-order KLE path, Gauss points staged through LDS `ho_chunk` at a time
 };
 
 __device__ inline int find_slot(const int32_t* __restrict__ colidx, int lo, int len, int col) {
@@ -106,6 +107,9 @@ __device__ inline int curl_term(int dim, int p, int k, int* m) {
 
 // Generic element kernel: one workgroup per element (grid-stride).  All per-point data
 // (J^-1, c, G) live in `pt` -- LDS when it fits (PT_LDS), per-block global scratch otherwise.
+// v[m] for a runtime m without dynamic register-array indexing (which would put the array in scratch memory)
+__device__ __forceinline__ double pick3(const double (&v)[3], int m) { return m == 0 ? v[0] : (m == 1 ? v[1] : v[2]); }
+
 template <int BLOCK, bool PT_LDS, bool DENSE>
 __global__ void __launch_bounds__(BLOCK) assemble_generic_kernel(AsmArgs A) {
   extern __shared__ __align__(16) unsigned char smem_raw[];
@@ -193,6 +197,180 @@ __global__ void __launch_bounds__(BLOCK) assemble_generic_kernel(AsmArgs A) {
       }
     };
 
+    if (!PT_LDS && !DENSE && A.ho_chunk > 0) {
+      // ---- high-order KLE elements: the point data (pt) sits in global scratch and an entry-per-lane loop re-reads
+      //      it nn^2 times.  Here the points go through LDS `CH` at a time and every lane owns a 2x2 micro-block of
+      //      node pairs whose 3x3 blocks accumulate in registers: 17 LDS reads per point serve 4 pairs.  Entries are
+      //      summed in the order g = 0, 1, ... as everywhere else (bit-identical to the per-entry formulation).
+      const int CH = A.ho_chunk;
+      const int CS = (dim * nn + nn + 1 + 1) & ~1;                 // per point: G[dim][nn], H row [nn], c
+      double* chunk = reinterpret_cast<double*>(ids + ((nn + 1) & ~1));
+      const int nb2 = (nn + 1) / 2, n_mb = nb2 * nb2;
+      int sgv[3][3], mv[3][3], sg2v[3][3], m2v[3][3];
+#pragma unroll
+      for (int p = 0; p < 3; ++p)
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+          sgv[p][k] = sg2v[p][k] = 0;
+          mv[p][k] = m2v[p][k] = 0;
+          if (p < dim && k < dw) {
+            int m = 0;
+            sgv[p][k] = curl_term(dim, p, k, &m);
+            mv[p][k] = m;
+            int m2 = 0;
+            if (dim == 2) {
+              m2 = 1 - p;
+              sg2v[p][k] = p == 0 ? -1 : 1;
+            } else {
+              sg2v[p][k] = curl_term(3, k, p, &m2);
+            }
+            m2v[p][k] = m2;
+          }
+        }
+      const bool want_k = A.K || A.Krhs, want_r = A.Rw || A.Rd;
+      for (int pass = 0; pass < 2; ++pass) {
+        if (pass == 0 ? !want_k : !want_r) continue;
+        for (int mb0 = 0; mb0 < n_mb; mb0 += BLOCK) {
+          const int mb = mb0 + tid;
+          const bool active = mb < n_mb;
+          const int bi = active ? mb / nb2 : 0, bj = active ? mb - bi * nb2 : 0;
+          const int an[2] = {2 * bi, min(2 * bi + 1, nn - 1)}, bn[2] = {2 * bj, min(2 * bj + 1, nn - 1)};
+          const bool av[2] = {active, active && 2 * bi + 1 < nn}, bv[2] = {active, active && 2 * bj + 1 < nn};
+          double acc[4][3][3], accd[4][3];
+#pragma unroll
+          for (int pr = 0; pr < 4; ++pr)
+#pragma unroll
+            for (int p = 0; p < 3; ++p) {
+              accd[pr][p] = 0.0;
+#pragma unroll
+              for (int q = 0; q < 3; ++q) acc[pr][p][q] = 0.0;
+            }
+          for (int g0 = 0; g0 < ngt; g0 += CH) {
+            const int ng = min(CH, ngt - g0);
+            __syncthreads();
+            for (int t = tid; t < ng * CS; t += BLOCK) {
+              const int gg = t / CS, idx = t - gg * CS, g = g0 + gg;
+              const double* P = pt + (int64_t)g * pt_stride;
+              double val = 0.0;
+              if (idx < dim * nn)
+                val = P[dd + 1 + idx];
+              else if (idx < dim * nn + nn)
+                val = g < nga ? A.H[0][(int64_t)g * nn + (idx - dim * nn)] : A.H[1][(int64_t)(g - nga) * nn + (idx - dim * nn)];
+              else if (idx == dim * nn + nn)
+                val = P[dd];
+              chunk[t] = val;
+            }
+            __syncthreads();
+            if (!active) continue;
+            for (int gg = 0; gg < ng; ++gg) {
+              const double* Cg = chunk + gg * CS;
+              const bool full = g0 + gg < nga;
+              const double cg = Cg[dim * nn + nn];
+              double ga[2][3], gb[2][3], ha[2], hb[2];
+#pragma unroll
+              for (int u = 0; u < 2; ++u) {
+                ha[u] = Cg[dim * nn + an[u]];
+                hb[u] = Cg[dim * nn + bn[u]];
+#pragma unroll
+                for (int d = 0; d < 3; ++d) {
+                  ga[u][d] = d < dim ? Cg[d * nn + an[u]] : 0.0;
+                  gb[u][d] = d < dim ? Cg[d * nn + bn[u]] : 0.0;
+                }
+              }
+#pragma unroll
+              for (int ua = 0; ua < 2; ++ua)
+#pragma unroll
+                for (int ub = 0; ub < 2; ++ub) {
+                  const int pr = ua * 2 + ub;
+                  if (pass == 0) {
+                    double sdot = 0.0;
+#pragma unroll
+                    for (int d = 0; d < 3; ++d)
+                      if (d < dim) sdot += ga[ua][d] * gb[ub][d];
+                    if (full) {
+#pragma unroll
+                      for (int p = 0; p < 3; ++p)
+                        if (p < dim) acc[pr][p][p] += cg * sdot;
+                    } else {
+#pragma unroll
+                      for (int p = 0; p < 3; ++p)
+#pragma unroll
+                        for (int q = 0; q < 3; ++q)
+                          if (p < dim && q < dim) {
+                            double pen = A.alpha_d * ga[ua][p] * gb[ub][q] - A.alpha_w * ga[ua][q] * gb[ub][p];
+                            if (p == q) pen += A.alpha_w * sdot;
+                            acc[pr][p][q] += cg * pen;
+                          }
+                    }
+                  } else if (full) {
+#pragma unroll
+                    for (int p = 0; p < 3; ++p) {
+                      if (p < dim) accd[pr][p] -= cg * ha[ua] * gb[ub][p];
+#pragma unroll
+                      for (int k = 0; k < 3; ++k)
+                        if (sgv[p][k] != 0) acc[pr][p][k] += cg * ha[ua] * (double)sgv[p][k] * pick3(gb[ub], mv[p][k]);
+                    }
+                  } else {
+#pragma unroll
+                    for (int p = 0; p < 3; ++p) {
+                      if (p < dim) accd[pr][p] += cg * A.alpha_d * ga[ua][p] * hb[ub];
+#pragma unroll
+                      for (int k = 0; k < 3; ++k)
+                        if (sgv[p][k] != 0) acc[pr][p][k] += cg * A.alpha_w * (double)sg2v[p][k] * pick3(ga[ua], m2v[p][k]) * hb[ub];
+                    }
+                  }
+                }
+            }
+          }
+          // ---- scatter the micro-block (same routing as the per-pair path)
+#pragma unroll
+          for (int ua = 0; ua < 2; ++ua)
+#pragma unroll
+            for (int ub = 0; ub < 2; ++ub) {
+              if (!av[ua] || !bv[ub]) continue;
+              const int pr = ua * 2 + ub, a = an[ua], b = bn[ub];
+              const int row = ids[a];
+              if (row >= A.n_owned) continue;
+              const int lo = A.rowptr[row], len = A.rowptr[row + 1] - lo;
+              const int sl = find_slot(A.colidx, lo, len, ids[b]);
+#pragma unroll
+              for (int p = 0; p < 3; ++p) {
+                if (p >= dim) continue;
+                const int64_t rd = (int64_t)row * dim + p;
+                const int ci = A.bcmask ? A.bcmask[rd] : 0;
+                if (pass == 0) {
+#pragma unroll
+                  for (int q = 0; q < 3; ++q) {
+                    if (q >= dim) continue;
+                    const int cj = A.bcmask ? A.bcmask[(int64_t)ids[b] * dim + q] : 0;
+                    const int64_t off = ((int64_t)lo * dim + (int64_t)p * len + sl) * dim + q;
+                    const double vv = acc[pr][p][q];
+                    if (ci == 0) {
+                      if (cj == 0) {
+                        if (A.K) atomicAdd(&A.K[off], vv);
+                      } else if (A.Krhs) {
+                        atomicAdd(&A.Krhs[off], -vv);
+                      }
+                    }
+                  }
+                } else {
+                  if (A.Rw) {
+#pragma unroll
+                    for (int k = 0; k < 3; ++k) {
+                      if (k >= dw) continue;
+                      const double vv = acc[pr][p][k];
+                      if (vv != 0.0 && ci == 0) atomicAdd(&A.Rw[((int64_t)lo * dim + (int64_t)p * len + sl) * dw + k], vv);
+                    }
+                  }
+                  if (A.Rd && ci == 0) atomicAdd(&A.Rd[(int64_t)lo * dim + (int64_t)p * len + sl], accd[pr][p]);
+                }
+              }
+            }
+        }
+      }
+      continue;
+    }
+
     if (oper) {
       const int br = A.op_br, bc = A.op_bc;
       for (int t = tid; t < npair * br * bc; t += BLOCK) {
@@ -257,120 +435,185 @@ __global__ void __launch_bounds__(BLOCK) assemble_generic_kernel(AsmArgs A) {
       continue;
     }
 
-    // ---- KLE stiffness K (dim x dim blocks)
+    // ---- KLE blocks.  One lane per NODE PAIR (a, b) computing all components of its block: the point data
+    //      (c, G[.][a], G[.][b], H) is read once per pair instead of once per entry, which is what bounds the
+    //      high-order elements whose point data lives in global scratch.  Every entry is still summed in the
+    //      order g = 0, 1, ... of the per-entry formulation (bit-identical results).
+    // ---- K (dim x dim blocks); component loops have the static bound 3 with `< dim` guards so that the
+    //      accumulators stay in registers
     if (DENSE ? (A.out0 != nullptr) : (A.K != nullptr || A.Krhs != nullptr || A.Kfs != nullptr || A.Krhsfs != nullptr)) {
-      for (int t = tid; t < npair * dd; t += BLOCK) {
-        int pq = t / npair, ab = t - pq * npair;
-        int a = ab / nn, b = ab - a * nn;
-        int p = pq / dim, q = pq - p * dim;
-        double v = 0.0;
-        if (p == q) {
-          for (int g = 0; g < nga; ++g) {
-            const double* P = pt + (int64_t)g * pt_stride;
-            double s = 0.0;
-            for (int d = 0; d < dim; ++d) s += P[dd + 1 + d * nn + a] * P[dd + 1 + d * nn + b];
-            v += P[dd] * s;
-          }
+      for (int ab = tid; ab < npair; ab += BLOCK) {
+        const int a = ab / nn, b = ab - a * nn;
+        double vfull = 0.0;
+        for (int g = 0; g < nga; ++g) {
+          const double* P = pt + (int64_t)g * pt_stride;
+          double s = 0.0;
+          for (int d = 0; d < dim; ++d) s += P[dd + 1 + d * nn + a] * P[dd + 1 + d * nn + b];
+          vfull += P[dd] * s;
         }
+        double v[3][3];
+#pragma unroll
+        for (int p = 0; p < 3; ++p)
+#pragma unroll
+          for (int q = 0; q < 3; ++q) v[p][q] = p == q ? vfull : 0.0;
         for (int g = nga; g < ngt; ++g) {
           const double* P = pt + (int64_t)g * pt_stride;
           const double* G = P + dd + 1;
-          double pen = A.alpha_d * G[p * nn + a] * G[q * nn + b] - A.alpha_w * G[q * nn + a] * G[p * nn + b];
-          if (p == q) {
-            double s = 0.0;
-            for (int d = 0; d < dim; ++d) s += G[d * nn + a] * G[d * nn + b];
-            pen += A.alpha_w * s;
-          }
-          v += P[dd] * pen;
+          double ga[3] = {0.0, 0.0, 0.0}, gb[3] = {0.0, 0.0, 0.0}, s = 0.0;
+#pragma unroll
+          for (int d = 0; d < 3; ++d)
+            if (d < dim) {
+              ga[d] = G[d * nn + a];
+              gb[d] = G[d * nn + b];
+              s += ga[d] * gb[d];
+            }
+          const double cg = P[dd];
+#pragma unroll
+          for (int p = 0; p < 3; ++p)
+#pragma unroll
+            for (int q = 0; q < 3; ++q)
+              if (p < dim && q < dim) {
+                double pen = A.alpha_d * ga[p] * gb[q] - A.alpha_w * ga[q] * gb[p];
+                if (p == q) pen += A.alpha_w * s;
+                v[p][q] += cg * pen;
+              }
         }
-        if (DENSE) {
-          A.out0[(int64_t)(a * dim + p) * (dim * nn) + b * dim + q] = v;
-        } else {
+        if (!DENSE) {
           locate(ab, a, b);
           if (r_len < 0) continue;
-          int64_t rd = (int64_t)ids[a] * dim + p, cd = (int64_t)ids[b] * dim + q;
-          const int ci = A.bcmask ? A.bcmask[rd] : 0, cj = A.bcmask ? A.bcmask[cd] : 0;
-          int64_t off = ((int64_t)r_lo * dim + (int64_t)p * r_len + slot) * dim + q;
-          if (ci == 0) {                                   // base_problem.py:426-427 / 388-390
-            if (cj == 0) {
-              if (A.K) atomicAdd(&A.K[off], v);
-            } else if (A.Krhs) {
-              atomicAdd(&A.Krhs[off], -v);
-            }
-          }
-          if (A.Kfs && ((ci == 1 && cj <= 1) || (ci == 0 && cj == 1))) atomicAdd(&A.Kfs[off], v);   // :396-407
-          if (A.Krhsfs && ci <= 1 && cj == 2) atomicAdd(&A.Krhsfs[off], -v);                        // :417-422
         }
+#pragma unroll
+        for (int p = 0; p < 3; ++p)
+#pragma unroll
+          for (int q = 0; q < 3; ++q)
+            if (p < dim && q < dim) {
+              const double vv = v[p][q];
+              if (DENSE) {
+                A.out0[(int64_t)(a * dim + p) * (dim * nn) + b * dim + q] = vv;
+              } else {
+                int64_t rd = (int64_t)ids[a] * dim + p, cd = (int64_t)ids[b] * dim + q;
+                const int ci = A.bcmask ? A.bcmask[rd] : 0, cj = A.bcmask ? A.bcmask[cd] : 0;
+                int64_t off = ((int64_t)r_lo * dim + (int64_t)p * r_len + slot) * dim + q;
+                if (ci == 0) {                                   // base_problem.py:426-427 / 388-390
+                  if (cj == 0) {
+                    if (A.K) atomicAdd(&A.K[off], vv);
+                  } else if (A.Krhs) {
+                    atomicAdd(&A.Krhs[off], -vv);
+                  }
+                }
+                if (A.Kfs && ((ci == 1 && cj <= 1) || (ci == 0 && cj == 1))) atomicAdd(&A.Kfs[off], vv);   // :396-407
+                if (A.Krhsfs && ci <= 1 && cj == 2) atomicAdd(&A.Krhsfs[off], -vv);                        // :417-422
+              }
+            }
       }
     }
     // ---- Rw (dim x dim_w blocks)
     if (DENSE ? (A.out1 != nullptr) : (A.Rw != nullptr || A.Rwfs != nullptr)) {
-      for (int t = tid; t < npair * dim * dw; t += BLOCK) {
-        int pk = t / npair, ab = t - pk * npair;
-        int a = ab / nn, b = ab - a * nn;
-        int p = pk / dw, k = pk - p * dw;
-        double v = 0.0;
-        int m = 0;
-        int sg = curl_term(dim, p, k, &m);  // (curl w)_p picks  sg * d_m w_k
-        if (sg != 0) {
-          for (int g = 0; g < nga; ++g) {
-            const double* P = pt + (int64_t)g * pt_stride;
-            v += P[dd] * A.H[0][(int64_t)g * nn + a] * (double)sg * P[dd + 1 + m * nn + b];
+      for (int ab = tid; ab < npair; ab += BLOCK) {
+        const int a = ab / nn, b = ab - a * nn;
+        double v[3][3];
+        int sgv[3][3], mv[3][3], sg2v[3][3], m2v[3][3];
+#pragma unroll
+        for (int p = 0; p < 3; ++p)
+#pragma unroll
+          for (int k = 0; k < 3; ++k) {
+            v[p][k] = 0.0;
+            sgv[p][k] = 0;
+            mv[p][k] = m2v[p][k] = 0;
+            sg2v[p][k] = 0;
+            if (p < dim && k < dw) {
+              int m = 0;
+              sgv[p][k] = curl_term(dim, p, k, &m);  // (curl w)_p picks  sg * d_m w_k
+              mv[p][k] = m;
+              // reduced: alpha_w c Bc[k][(a,p)] H_b with (curl v)_k = eps_{k m p} d_m v_p
+              int m2 = 0;
+              if (dim == 2) {  // w = d_x v_y - d_y v_x
+                m2 = 1 - p;
+                sg2v[p][k] = p == 0 ? -1 : 1;
+              } else {
+                sg2v[p][k] = curl_term(3, k, p, &m2);
+              }
+              m2v[p][k] = m2;
+            }
           }
-          // reduced: alpha_w c Bc[k][(a,p)] H_b with (curl v)_k = eps_{k m p} d_m v_p
-          int m2 = 0;
-          int sg2;
-          if (dim == 2) {  // w = d_x v_y - d_y v_x
-            m2 = 1 - p;
-            sg2 = p == 0 ? -1 : 1;
-          } else {
-            sg2 = curl_term(3, k, p, &m2);
-          }
-          for (int g = nga; g < ngt; ++g) {
-            const double* P = pt + (int64_t)g * pt_stride;
-            v += P[dd] * A.alpha_w * (double)sg2 * P[dd + 1 + m2 * nn + a] * A.H[1][(int64_t)(g - nga) * nn + b];
-          }
+        for (int g = 0; g < nga; ++g) {
+          const double* P = pt + (int64_t)g * pt_stride;
+          const double cg = P[dd], ha = A.H[0][(int64_t)g * nn + a];
+#pragma unroll
+          for (int p = 0; p < 3; ++p)
+#pragma unroll
+            for (int k = 0; k < 3; ++k)
+              if (sgv[p][k] != 0) v[p][k] += cg * ha * (double)sgv[p][k] * P[dd + 1 + mv[p][k] * nn + b];
         }
-        if (DENSE) {
-          A.out1[(int64_t)(a * dim + p) * (dw * nn) + b * dw + k] = v;
-        } else {
+        for (int g = nga; g < ngt; ++g) {
+          const double* P = pt + (int64_t)g * pt_stride;
+          const double cg = P[dd], hb = A.H[1][(int64_t)(g - nga) * nn + b];
+#pragma unroll
+          for (int p = 0; p < 3; ++p)
+#pragma unroll
+            for (int k = 0; k < 3; ++k)
+              if (sgv[p][k] != 0) v[p][k] += cg * A.alpha_w * (double)sg2v[p][k] * P[dd + 1 + m2v[p][k] * nn + a] * hb;
+        }
+        if (!DENSE) {
           locate(ab, a, b);
           if (r_len < 0) continue;
-          int64_t rd = (int64_t)ids[a] * dim + p;
-          const int ci = A.bcmask ? A.bcmask[rd] : 0;
-          int64_t off = ((int64_t)r_lo * dim + (int64_t)p * r_len + slot) * dw + k;
-          if (v != 0.0) {
-            if (ci == 0 && A.Rw) atomicAdd(&A.Rw[off], v);
-            if (ci == 1 && A.Rwfs) atomicAdd(&A.Rwfs[off], v);      // base_problem.py:412-413
-          }
         }
+#pragma unroll
+        for (int p = 0; p < 3; ++p)
+#pragma unroll
+          for (int k = 0; k < 3; ++k)
+            if (p < dim && k < dw) {
+              const double vv = v[p][k];
+              if (DENSE) {
+                A.out1[(int64_t)(a * dim + p) * (dw * nn) + b * dw + k] = vv;
+              } else {
+                int64_t rd = (int64_t)ids[a] * dim + p;
+                const int ci = A.bcmask ? A.bcmask[rd] : 0;
+                int64_t off = ((int64_t)r_lo * dim + (int64_t)p * r_len + slot) * dw + k;
+                if (vv != 0.0) {
+                  if (ci == 0 && A.Rw) atomicAdd(&A.Rw[off], vv);
+                  if (ci == 1 && A.Rwfs) atomicAdd(&A.Rwfs[off], vv);      // base_problem.py:412-413
+                }
+              }
+            }
       }
     }
     // ---- Rd (dim x 1 blocks)
     if (DENSE ? (A.out2 != nullptr) : (A.Rd != nullptr || A.Rdfs != nullptr)) {
-      for (int t = tid; t < npair * dim; t += BLOCK) {
-        int p = t / npair, ab = t - p * npair;
-        int a = ab / nn, b = ab - a * nn;
-        double v = 0.0;
+      for (int ab = tid; ab < npair; ab += BLOCK) {
+        const int a = ab / nn, b = ab - a * nn;
+        double v[3] = {0.0, 0.0, 0.0};
         for (int g = 0; g < nga; ++g) {
           const double* P = pt + (int64_t)g * pt_stride;
-          v -= P[dd] * A.H[0][(int64_t)g * nn + a] * P[dd + 1 + p * nn + b];
+          const double cg = P[dd], ha = A.H[0][(int64_t)g * nn + a];
+#pragma unroll
+          for (int p = 0; p < 3; ++p)
+            if (p < dim) v[p] -= cg * ha * P[dd + 1 + p * nn + b];
         }
         for (int g = nga; g < ngt; ++g) {
           const double* P = pt + (int64_t)g * pt_stride;
-          v += P[dd] * A.alpha_d * P[dd + 1 + p * nn + a] * A.H[1][(int64_t)(g - nga) * nn + b];
+          const double cg = P[dd], hb = A.H[1][(int64_t)(g - nga) * nn + b];
+#pragma unroll
+          for (int p = 0; p < 3; ++p)
+            if (p < dim) v[p] += cg * A.alpha_d * P[dd + 1 + p * nn + a] * hb;
         }
-        if (DENSE) {
-          A.out2[(int64_t)(a * dim + p) * nn + b] = v;
-        } else {
+        if (!DENSE) {
           locate(ab, a, b);
           if (r_len < 0) continue;
-          int64_t rd = (int64_t)ids[a] * dim + p;
-          const int ci = A.bcmask ? A.bcmask[rd] : 0;
-          int64_t off = (int64_t)r_lo * dim + (int64_t)p * r_len + slot;
-          if (ci == 0 && A.Rd) atomicAdd(&A.Rd[off], v);
-          if (ci == 1 && A.Rdfs) atomicAdd(&A.Rdfs[off], v);        // base_problem.py:415-416
         }
+#pragma unroll
+        for (int p = 0; p < 3; ++p)
+          if (p < dim) {
+            if (DENSE) {
+              A.out2[(int64_t)(a * dim + p) * nn + b] = v[p];
+            } else {
+              int64_t rd = (int64_t)ids[a] * dim + p;
+              const int ci = A.bcmask ? A.bcmask[rd] : 0;
+              int64_t off = (int64_t)r_lo * dim + (int64_t)p * r_len + slot;
+              if (ci == 0 && A.Rd) atomicAdd(&A.Rd[off], v[p]);
+              if (ci == 1 && A.Rdfs) atomicAdd(&A.Rdfs[off], v[p]);        // base_problem.py:415-416
+            }
+          }
       }
     }
   }
@@ -507,6 +750,7 @@ int fill_args(pyn_ctx* c, AsmArgs& A, int form) {
   A.out0 = A.out1 = A.out2 = nullptr;
   A.gscratch = nullptr;
   A.gscratch_stride = 0;
+  A.ho_chunk = 0;
   A.op_rule = A.op_br = A.op_bc = A.op_nterms = 0;
   A.op_terms = nullptr;
   A.op_coef = nullptr;
@@ -531,6 +775,18 @@ int launch_generic(pyn_ctx* c, AsmArgs& A, int64_t n_work) {
     A.gscratch = c->d_work;
   }
   size_t smem = generic_smem(c, ngt, pt_lds);
+  // high-order KLE elements (point data in global scratch): stage the Gauss points through LDS, see the kernel
+  if (!DENSE && !pt_lds && A.form == PYN_FORM_KLE && !A.Kfs && !A.Krhsfs && !A.Rwfs && !A.Rdfs && !getenv("PYNAMA_NO_HO")) {
+    const size_t cs = (size_t)((c->dim * c->nn + c->nn + 1 + 1) & ~1) * sizeof(double);
+    const int ch = (int)std::max<size_t>(1, std::min<size_t>(16, (48 * 1024) / cs));
+    PYN_CHECK(smem + ch * cs <= 160 * 1024, "element too large for the high-order staging buffer");
+    A.ho_chunk = ch;
+    smem += ch * cs;
+  }
+  if (smem > 64 * 1024) {
+    PYN_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(assemble_generic_kernel<256, false, DENSE>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+  }
   if (small) {
     assemble_generic_kernel<64, true, DENSE><<<grid, 64, smem, c->stream>>>(A);
   } else if (pt_lds) {
