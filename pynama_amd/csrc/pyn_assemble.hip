@@ -718,6 +718,207 @@ __global__ void __launch_bounds__(256) assemble_p1_laplace_kernel(const int32_t*
   }
 }
 
+// ---- High-order KLE elements on the FP64 matrix cores -----------------------------------------------------------
+// For nn >~ 64 nodes per element the blocks are dense contractions over the Gauss points,
+//   S_f  = sum_full c G_d[a] G_d[b]           T_pq = sum_red c G_p[a] G_q[b]
+//   U_m  = sum_full c H[a]  G_m[b]            V_m  = sum_red c G_m[a] H[b]
+//   K[p][q]  = d_pq (S_f + aw sum_d T_dd) + ad T_pq - aw T_qp                                (spectral.py:131,152-153)
+//   Rw[p][k] = sg_pk U_m(p,k) + aw sg2_pk V_m2(p,k)      Rd[p] = -U_p + ad V_p               (:132-133,155-156)
+// i.e. small GEMMs with the points as the K dimension: v_mfma_f64_16x16x4_f64 (lane l: A[i = l&15][k = l>>4],
+// B[k = l>>4][j = l&15], D col = l&15, row = (l>>4) + 4 reg).  One workgroup per element, each of its 4 waves owns one
+// 16x16 tile of node pairs per round with all 16 accumulator tiles in registers; the points pass through LDS in chunks.
+typedef double pyn_d4 __attribute__((ext_vector_type(4)));
+
+__global__ void __launch_bounds__(256) assemble_kle_ho_mfma_kernel(AsmArgs A, int CH) {
+  extern __shared__ __align__(16) unsigned char smem_raw[];
+  const int dim = A.dim, nn = A.nn, nc = A.nc, dd = dim * dim;
+  const int nga = A.ngp[0], ngb = A.ngp[1], ngt = nga + ngb;
+  const int nn16 = (nn + 15) & ~15, nt16 = nn16 >> 4;
+  double* Xs = reinterpret_cast<double*>(smem_raw);                      // [nc*dim]
+  int32_t* ids = reinterpret_cast<int32_t*>(Xs + nc * dim);             // [nn]
+  double* Gs = reinterpret_cast<double*>(ids + ((nn + 1) & ~1));        // [dim][CH][nn16]
+  double* Hs = Gs + (size_t)dim * CH * nn16;                             // [CH][nn16]
+  double* cs = Hs + (size_t)CH * nn16;                                   // [CH]
+  const int pt_stride = dd + 1 + dim * nn;
+  double* pt = A.gscratch + (int64_t)blockIdx.x * A.gscratch_stride;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int dw = dim == 2 ? 1 : 3;
+  const int li = lane & 15, lk = lane >> 4;
+
+  int sgv[3][3], mv[3][3], sg2v[3][3], m2v[3][3];
+#pragma unroll
+  for (int p = 0; p < 3; ++p)
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+      sgv[p][k] = sg2v[p][k] = 0;
+      mv[p][k] = m2v[p][k] = 0;
+      if (p < dim && k < dw) {
+        int m = 0;
+        sgv[p][k] = curl_term(dim, p, k, &m);
+        mv[p][k] = m;
+        int m2 = 0;
+        if (dim == 2) {
+          m2 = 1 - p;
+          sg2v[p][k] = p == 0 ? -1 : 1;
+        } else {
+          sg2v[p][k] = curl_term(3, k, p, &m2);
+        }
+        m2v[p][k] = m2;
+      }
+    }
+
+  for (int64_t e = blockIdx.x; e < A.n_elem; e += gridDim.x) {
+    __syncthreads();
+    for (int t = tid; t < nn; t += 256) ids[t] = A.conn[e * nn + t];
+    for (int t = tid; t < nc * dim; t += 256) {
+      int cn = t / dim, x = t - cn * dim;
+      Xs[t] = A.xyz[(int64_t)A.conn[e * nn + cn] * dim + x];
+    }
+    __syncthreads();
+    for (int g = tid; g < ngt; g += 256) {   // geometry at every point (spectral.py:120-122,140-142)
+      const int q = g < nga ? 0 : 1;
+      const int gl = g < nga ? g : g - nga;
+      const double* hc = A.HrsCoo[q] + (int64_t)gl * dim * nc;
+      double J[9], Ji[9];
+      for (int d = 0; d < dim; ++d)
+        for (int x = 0; x < dim; ++x) {
+          double sacc = 0.0;
+          for (int cn = 0; cn < nc; ++cn) sacc += hc[d * nc + cn] * Xs[cn * dim + x];
+          J[d * dim + x] = sacc;
+        }
+      double det = inv_det(J, Ji, dim);
+      double* P = pt + (int64_t)g * pt_stride;
+      for (int i = 0; i < dd; ++i) P[i] = Ji[i];
+      P[dd] = A.w[q][gl] * det;
+    }
+    __syncthreads();
+    for (int t = tid; t < ngt * dim * nn; t += 256) {   // G = J^-1 Hrs (:121,141)
+      int g = t / (dim * nn);
+      int r = t - g * dim * nn;
+      int d = r / nn, a = r - d * nn;
+      const int q = g < nga ? 0 : 1;
+      const int gl = g < nga ? g : g - nga;
+      const double* hrs = A.Hrs[q] + (int64_t)gl * dim * nn;
+      double* P = pt + (int64_t)g * pt_stride;
+      double sacc = 0.0;
+      for (int x = 0; x < dim; ++x) sacc += P[d * dim + x] * hrs[x * nn + a];
+      P[dd + 1 + d * nn + a] = sacc;
+    }
+    __syncthreads();
+
+    // ---- tiles of 16 x 16 node pairs, four at a time (one per wave)
+    const int n_tiles = nt16 * nt16;
+    for (int t0 = 0; t0 < n_tiles; t0 += 4) {
+      const int tile = t0 + wave;
+      const bool active = tile < n_tiles;
+      const int ta = active ? tile / nt16 : 0, tb = active ? tile - ta * nt16 : 0;
+      const int a0 = ta * 16, b0 = tb * 16;
+      pyn_d4 S = {0, 0, 0, 0}, T[3][3], U[3], V[3];
+#pragma unroll
+      for (int p = 0; p < 3; ++p) {
+        U[p] = S;
+        V[p] = S;
+#pragma unroll
+        for (int q = 0; q < 3; ++q) T[p][q] = S;
+      }
+      for (int rule = 0; rule < 2; ++rule) {
+        const int gbeg = rule == 0 ? 0 : nga, gend = rule == 0 ? nga : ngt;
+        for (int g0 = gbeg; g0 < gend; g0 += CH) {
+          __syncthreads();
+          // stage CH points (zero-padded past the rule's end and past nn)
+          for (int t = tid; t < CH * nn16; t += 256) {
+            const int kk = t / nn16, a = t - kk * nn16, g = g0 + kk;
+            const bool ok = g < gend && a < nn;
+            const double* P = pt + (int64_t)(ok ? g : 0) * pt_stride;
+#pragma unroll
+            for (int d = 0; d < 3; ++d)
+              if (d < dim) Gs[((size_t)d * CH + kk) * nn16 + a] = ok ? P[dd + 1 + d * nn + a] : 0.0;
+            Hs[(size_t)kk * nn16 + a] = ok ? A.H[rule][(int64_t)(g - gbeg) * nn + a] : 0.0;
+            if (a == 0) cs[kk] = g < gend ? P[dd] : 0.0;
+          }
+          __syncthreads();
+          if (!active) continue;
+          for (int k4 = 0; k4 < CH; k4 += 4) {
+            const int kk = k4 + lk;
+            const double cg = cs[kk];
+            double ga[3], gb[3];
+#pragma unroll
+            for (int d = 0; d < 3; ++d) {
+              ga[d] = d < dim ? Gs[((size_t)d * CH + kk) * nn16 + a0 + li] : 0.0;
+              gb[d] = d < dim ? Gs[((size_t)d * CH + kk) * nn16 + b0 + li] : 0.0;
+            }
+            const double ha = Hs[(size_t)kk * nn16 + a0 + li], hb = Hs[(size_t)kk * nn16 + b0 + li];
+            if (rule == 0) {
+#pragma unroll
+              for (int d = 0; d < 3; ++d)
+                if (d < dim) {
+                  S = __builtin_amdgcn_mfma_f64_16x16x4f64(cg * ga[d], gb[d], S, 0, 0, 0);
+                  U[d] = __builtin_amdgcn_mfma_f64_16x16x4f64(cg * ha, gb[d], U[d], 0, 0, 0);
+                }
+            } else {
+#pragma unroll
+              for (int p = 0; p < 3; ++p)
+                if (p < dim) {
+                  V[p] = __builtin_amdgcn_mfma_f64_16x16x4f64(cg * ga[p], hb, V[p], 0, 0, 0);
+#pragma unroll
+                  for (int q = 0; q < 3; ++q)
+                    if (q < dim) T[p][q] = __builtin_amdgcn_mfma_f64_16x16x4f64(cg * ga[p], gb[q], T[p][q], 0, 0, 0);
+                }
+            }
+          }
+        }
+      }
+      if (!active) continue;
+      // ---- combine and scatter: lane holds rows (lane>>4) + 4 r, column lane&15 of the tile
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int a = a0 + lk + 4 * r, b = b0 + li;
+        if (a >= nn || b >= nn) continue;
+        const int row = ids[a];
+        if (row >= A.n_owned) continue;
+        const int lo = A.rowptr[row], len = A.rowptr[row + 1] - lo;
+        const int sl = find_slot(A.colidx, lo, len, ids[b]);
+        double tdd = 0.0;
+#pragma unroll
+        for (int d = 0; d < 3; ++d)
+          if (d < dim) tdd += T[d][d][r];
+        const double diag = S[r] + A.alpha_w * tdd;
+        double uu[3] = {U[0][r], U[1][r], U[2][r]}, vv3[3] = {V[0][r], V[1][r], V[2][r]};
+#pragma unroll
+        for (int p = 0; p < 3; ++p) {
+          if (p >= dim) continue;
+          const int ci = A.bcmask ? A.bcmask[(int64_t)row * dim + p] : 0;
+          if (ci != 0) continue;
+          if (A.K || A.Krhs) {
+#pragma unroll
+            for (int q = 0; q < 3; ++q) {
+              if (q >= dim) continue;
+              double v = A.alpha_d * T[p][q][r] - A.alpha_w * T[q][p][r];
+              if (p == q) v += diag;
+              const int cj = A.bcmask ? A.bcmask[(int64_t)ids[b] * dim + q] : 0;
+              const int64_t off = ((int64_t)lo * dim + (int64_t)p * len + sl) * dim + q;
+              if (cj == 0) {
+                if (A.K) atomicAdd(&A.K[off], v);
+              } else if (A.Krhs) {
+                atomicAdd(&A.Krhs[off], -v);
+              }
+            }
+          }
+          if (A.Rw) {
+#pragma unroll
+            for (int k = 0; k < 3; ++k) {
+              if (k >= dw || sgv[p][k] == 0) continue;
+              const double v = (double)sgv[p][k] * pick3(uu, mv[p][k]) + A.alpha_w * (double)sg2v[p][k] * pick3(vv3, m2v[p][k]);
+              if (v != 0.0) atomicAdd(&A.Rw[((int64_t)lo * dim + (int64_t)p * len + sl) * dw + k], v);
+            }
+          }
+          if (A.Rd) atomicAdd(&A.Rd[(int64_t)lo * dim + (int64_t)p * len + sl], A.alpha_d * vv3[p] - uu[p]);
+        }
+      }
+    }
+  }
+}
+
 size_t generic_smem(const pyn_ctx* c, int ngt, bool pt_lds) {
   size_t s = (size_t)c->nc * c->dim * sizeof(double) + (size_t)((c->nn + 1) & ~1) * sizeof(int32_t);
   if (pt_lds) s += (size_t)ngt * (c->dim * c->dim + 1 + c->dim * c->nn) * sizeof(double);
@@ -782,6 +983,25 @@ int launch_generic(pyn_ctx* c, AsmArgs& A, int64_t n_work) {
     PYN_CHECK(smem + ch * cs <= 160 * 1024, "element too large for the high-order staging buffer");
     A.ho_chunk = ch;
     smem += ch * cs;
+  }
+  if (A.ho_chunk > 0 && c->nn >= 48 && !getenv("PYNAMA_NO_HO_MFMA")) {
+    // dense enough for the FP64 matrix cores: largest chunk of points (multiple of 4) whose staging fits the LDS
+    const size_t nn16 = (size_t)((c->nn + 15) & ~15);
+    const size_t fixed = generic_smem(c, ngt, false);
+    int ch = 0;
+    for (int k = 16; k >= 4; k -= 4)
+      if (fixed + ((size_t)(c->dim + 1) * k * nn16 + k) * sizeof(double) <= 96 * 1024) {
+        ch = k;
+        break;
+      }
+    if (ch > 0) {
+      const size_t lds = fixed + ((size_t)(c->dim + 1) * ch * nn16 + ch) * sizeof(double);
+      PYN_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(assemble_kle_ho_mfma_kernel),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+      assemble_kle_ho_mfma_kernel<<<grid, 256, lds, c->stream>>>(A, ch);
+      PYN_HIP(hipGetLastError());
+      return PYN_OK;
+    }
   }
   if (smem > 64 * 1024) {
     PYN_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(assemble_generic_kernel<256, false, DENSE>),

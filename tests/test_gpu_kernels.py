@@ -95,7 +95,9 @@ def test_csr_symbolic_permuted_elements(lib):
 # ---- numeric phase --------------------------------------------------------------------------------
 @pytest.mark.parametrize("nelem,ngl,jitter,variant", [
     ([7, 6], 2, 0.2, 0), ([6, 5, 4], 2, 0.2, 0), ([6, 5, 4], 2, 0.2, 1), ([3, 4], 3, 0.0, 0),
-    ([2, 3, 2], 3, 0.0, 0), ([2, 2], 6, 0.0, 0), ([16, 16, 16], 2, 0.2, 1)])
+    ([2, 3, 2], 3, 0.0, 0), ([2, 2], 6, 0.0, 0), ([16, 16, 16], 2, 0.2, 1),
+    # point data beyond the LDS: Gauss points staged in chunks; nn >= 48 takes the FP64 matrix-core kernel
+    ([3, 2], 8, 0.0, 0), ([2, 2], 11, 0.0, 0), ([2, 2, 2], 4, 0.0, 0), ([2, 1, 2], 5, 0.0, 0)])
 def test_assemble_kle_vs_oracle(lib, nelem, ngl, jitter, variant):
     dim = len(nelem)
     dw = 1 if dim == 2 else 3
