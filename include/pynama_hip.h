@@ -200,6 +200,13 @@ int pyn_elem_operator_local(pyn_ctx* ctx, int rule, int br, int bc, int nterms, 
  * y = A x with halo exchange of x over RCCL when nranks > 1 (PETSc MatMult,
  * base_problem.py:481 "Rw*vort + Krhs*vel"). */
 int pyn_spmv(pyn_ctx* ctx, int mat_id, int x_vec, int y_vec);
+/* y = A x WITHOUT an assembled matrix (PETSc analogue: a MATSHELL operator): A is the scalar Laplacian that
+ * pyn_assemble_scalar(PYN_FORM_LAPLACE) would build from the mesh, the full-rule tables and the current Dirichlet mask
+ * (imposed rows identity, imposed columns eliminated, base_problem.py:531-549).  Element matrices are recomputed on
+ * the fly (Spectral.getElemKLEMatrices' scalar block, spectral.py:120-131) and applied per element; needs a Q1
+ * hexahedral mesh with structured topology (pyn_mesh_topology == lattice), errors otherwise. */
+enum { PYN_MATFREE_OFF = 0, PYN_MATFREE_LAPLACE = 1 };
+int pyn_matfree_apply(pyn_ctx* ctx, int op, int x_vec, int y_vec);
 typedef struct pyn_solve_opts {
   int method;        /* PYN_KSP_*  */
   int pc;            /* PYN_PC_*   */
@@ -212,6 +219,9 @@ typedef struct pyn_solve_opts {
   int gmres_orthog;  /* 0 classical Gram-Schmidt + one refinement pass (-ksp_gmres_cgs_refinement_type refine_always),
                         1 classical without refinement (refine_never, PETSc's own default), 2 modified Gram-Schmidt
                         (-ksp_gmres_modifiedgramschmidt) */
+  int matfree;       /* PYN_MATFREE_*: CG multiplies with the matrix-free operator instead of the assembled matrix, which
+                        then only supplies the Jacobi diagonal and the exit check (KSPSetOperators(Amat = shell, Pmat =
+                        assembled)); pyn_solve first verifies on b that both operators agree */
   double rtol, atol, dtol;   /* PETSc defaults 1e-5, 1e-50, 1e5 */
 } pyn_solve_opts;
 typedef struct pyn_solve_info {

@@ -19,6 +19,7 @@ CSRC = os.path.join(_HERE, "csrc")
 Q_FULL, Q_RED, Q_NODAL = 0, 1, 2
 FORM_LAPLACE, FORM_MASS_NODAL, FORM_MASS_FULL, FORM_KLE = 0, 1, 2, 3
 KSP_CG, KSP_GMRES = 0, 1
+MATFREE_OFF, MATFREE_LAPLACE = 0, 1
 PC_NONE, PC_JACOBI = 0, 1
 NORM_PRECONDITIONED, NORM_UNPRECONDITIONED, NORM_NATURAL = 0, 1, 2
 T_SYMBOLIC, T_ASSEMBLE, T_SPMV, T_SOLVE = 0, 1, 2, 3
@@ -31,7 +32,7 @@ class PynamaHipError(RuntimeError):
 class SolveOpts(C.Structure):
     _fields_ = [("method", C.c_int), ("pc", C.c_int), ("norm_type", C.c_int), ("maxit", C.c_int),
                 ("restart", C.c_int), ("fixed_iters", C.c_int), ("profile", C.c_int), ("cg_variant", C.c_int),
-                ("gmres_orthog", C.c_int), ("rtol", C.c_double), ("atol", C.c_double), ("dtol", C.c_double)]
+                ("gmres_orthog", C.c_int), ("matfree", C.c_int), ("rtol", C.c_double), ("atol", C.c_double), ("dtol", C.c_double)]
 
 
 class SolveInfo(C.Structure):
@@ -94,6 +95,7 @@ SIGNATURES = {
     "pyn_assemble_operator": [_P, _I, _I, _pi32, _pf64, _I],
     "pyn_elem_operator_local": [_P, _I, _I, _I, _I, _pi32, _pf64, _pf64, _pf64],
     "pyn_spmv": [_P, _I, _I, _I],
+    "pyn_matfree_apply": [_P, _I, _I, _I],
     "pyn_solve": [_P, _I, _I, _I, C.POINTER(SolveOpts), C.POINTER(SolveInfo)],
     "pyn_timers_get": [_P, _pf64, _I],
 }
@@ -379,9 +381,15 @@ class Context:
     def spmv(self, mid, x, y):
         _check(self.lib.pyn_spmv(self.h, mid, x, y))
 
+    def matfree_apply(self, x, y, op=1):
+        """y = A x with the matrix-free scalar Laplacian (no assembled matrix; structured Q1 hex meshes)"""
+        _check(self.lib.pyn_matfree_apply(self.h, op, x, y))
+
     def solve(self, mid, b, x, method=KSP_CG, pc=PC_JACOBI, rtol=1e-5, atol=1e-50, dtol=1e5, maxit=10000,
-              restart=30, norm_type=NORM_PRECONDITIONED, fixed_iters=0, profile=0, cg_variant=0, gmres_orthog=0) -> SolveInfo:
-        o = SolveOpts(method, pc, norm_type, maxit, restart, fixed_iters, profile, cg_variant, gmres_orthog, rtol, atol, dtol)
+              restart=30, norm_type=NORM_PRECONDITIONED, fixed_iters=0, profile=0, cg_variant=0, gmres_orthog=0,
+              matfree=0) -> SolveInfo:
+        o = SolveOpts(method, pc, norm_type, maxit, restart, fixed_iters, profile, cg_variant, gmres_orthog, matfree,
+                      rtol, atol, dtol)
         info = SolveInfo()
         _check(self.lib.pyn_solve(self.h, mid, b, x, C.byref(o), C.byref(info)))
         return info

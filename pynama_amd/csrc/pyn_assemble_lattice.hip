@@ -282,7 +282,81 @@ __device__ __forceinline__ bool lat_tile_plain(const LatArgs& T, int x0, int y0,
 // src/domain/dmplex.py:8-21): four corner loads instead of eight, J = S.E from the three edge vectors
 // (S[d][m] = sum_c hcoo[d][c] C_m[c], a table constant), L_ab = detJ sum_{r<=s} Q_rs T_rs[ab]; no quadrature
 // loop, no affinity test: ~110 VGPRs instead of ~170, i.e. 4 instead of 2-3 waves per SIMD to hide the gather
-// and store latencies.
+// and store latencies.  lat_affine_L: the 36 upper-triangle entries of L_e for the element whose lowest corner is
+// node n00 of plane gl (shared with the matrix-free operator below).
+__device__ __forceinline__ void lat_affine_L(const LatArgs& T, const double* __restrict__ S, int n00, int gl, double (&L)[36]) {
+  const int nx = T.nx;
+  const double* q0 = T.xyz + (int64_t)(lat_plane(T, gl) + n00) * 3;
+  const double* qz = T.xyz + (int64_t)(lat_plane(T, gl + 1) + n00) * 3;
+  double E[3][3];  // edge vectors along the lattice x, y, z directions
+#pragma unroll
+  for (int x = 0; x < 3; ++x) {
+    const double o = q0[x];
+    E[0][x] = q0[3 + x] - o;
+    E[1][x] = q0[3 * nx + x] - o;
+    E[2][x] = qz[x] - o;
+  }
+  double J[3][3];
+#pragma unroll
+  for (int d = 0; d < 3; ++d)
+#pragma unroll
+    for (int x = 0; x < 3; ++x) J[d][x] = fma(S[d * 3 + 2], E[2][x], fma(S[d * 3 + 1], E[1][x], S[d * 3] * E[0][x]));
+  const double c00 = J[1][1] * J[2][2] - J[1][2] * J[2][1];
+  const double c01 = J[1][2] * J[2][0] - J[1][0] * J[2][2];
+  const double c02 = J[1][0] * J[2][1] - J[1][1] * J[2][0];
+  const double det = J[0][0] * c00 + J[0][1] * c01 + J[0][2] * c02;
+  const double r = 1.0 / det;
+  double Ji[3][3];
+  Ji[0][0] = c00 * r;
+  Ji[0][1] = (J[0][2] * J[2][1] - J[0][1] * J[2][2]) * r;
+  Ji[0][2] = (J[0][1] * J[1][2] - J[0][2] * J[1][1]) * r;
+  Ji[1][0] = c01 * r;
+  Ji[1][1] = (J[0][0] * J[2][2] - J[0][2] * J[2][0]) * r;
+  Ji[1][2] = (J[0][2] * J[1][0] - J[0][0] * J[1][2]) * r;
+  Ji[2][0] = c02 * r;
+  Ji[2][1] = (J[0][1] * J[2][0] - J[0][0] * J[2][1]) * r;
+  Ji[2][2] = (J[0][0] * J[1][1] - J[0][1] * J[1][0]) * r;
+  double Q[6];
+  {
+    constexpr int RS[6][2] = {{0, 0}, {1, 1}, {2, 2}, {0, 1}, {0, 2}, {1, 2}};
+#pragma unroll
+    for (int u = 0; u < 6; ++u) {
+      const int a = RS[u][0], b = RS[u][1];
+      Q[u] = det * (Ji[0][a] * Ji[0][b] + Ji[1][a] * Ji[1][b] + Ji[2][a] * Ji[2][b]);
+    }
+  }
+  // 72 T_rs[ab] are small integers for the trilinear element (q1_aff_int): 15 products, then signed sums --
+  // no table traffic at all inside the loop
+  {
+    double D[3][3], M[3][2];
+#pragma unroll
+    for (int u = 0; u < 3; ++u) {
+      const double qd = Q[u] * (1.0 / 72.0), qm = Q[3 + u] * (1.0 / 72.0);
+      D[u][0] = 4.0 * qd;
+      D[u][1] = 8.0 * qd;
+      D[u][2] = 16.0 * qd;
+      M[u][0] = 12.0 * qm;
+      M[u][1] = 24.0 * qm;
+    }
+    int idx = 0;
+#pragma unroll
+    for (int a = 0; a < 8; ++a)
+#pragma unroll
+      for (int c = a; c < 8; ++c, ++idx) {
+        double v = 0.0;
+#pragma unroll
+        for (int u = 0; u < 6; ++u) {
+          const int n = q1_aff_int(u, a, c);
+          const int an = n < 0 ? -n : n;
+          if (an == 0) continue;
+          const double x = u < 3 ? D[u][an == 4 ? 0 : (an == 8 ? 1 : 2)] : M[u - 3][an == 12 ? 0 : 1];
+          v = n > 0 ? v + x : v - x;
+        }
+        L[idx] = v;
+      }
+  }
+}
+
 template <int TX, int TY, int TZ>
 __device__ __forceinline__ void lat_integrate_affine(const LatArgs& T, int x0, int y0, int z0, double* acc, int t0, int nt) {
   using LT = LatTile<TX, TY, TZ>;
@@ -296,76 +370,8 @@ __device__ __forceinline__ void lat_integrate_affine(const LatArgs& T, int x0, i
     const int gx = x0 - 1 + lx, gy = y0 - 1 + ly, gl = T.p_own0 + z0 - 1 + lz;
     if (gx < 0 || gx >= nx - 1 || gy < 0 || gy >= ny - 1 || gl < 0 || gl >= T.npl - 1) continue;
     const int n00 = gy * nx + gx;
-    const double* q0 = T.xyz + (int64_t)(lat_plane(T, gl) + n00) * 3;
-    const double* qz = T.xyz + (int64_t)(lat_plane(T, gl + 1) + n00) * 3;
-    double E[3][3];  // edge vectors along the lattice x, y, z directions
-#pragma unroll
-    for (int x = 0; x < 3; ++x) {
-      const double o = q0[x];
-      E[0][x] = q0[3 + x] - o;
-      E[1][x] = q0[3 * nx + x] - o;
-      E[2][x] = qz[x] - o;
-    }
-    double J[3][3];
-#pragma unroll
-    for (int d = 0; d < 3; ++d)
-#pragma unroll
-      for (int x = 0; x < 3; ++x) J[d][x] = fma(S[d * 3 + 2], E[2][x], fma(S[d * 3 + 1], E[1][x], S[d * 3] * E[0][x]));
-    const double c00 = J[1][1] * J[2][2] - J[1][2] * J[2][1];
-    const double c01 = J[1][2] * J[2][0] - J[1][0] * J[2][2];
-    const double c02 = J[1][0] * J[2][1] - J[1][1] * J[2][0];
-    const double det = J[0][0] * c00 + J[0][1] * c01 + J[0][2] * c02;
-    const double r = 1.0 / det;
-    double Ji[3][3];
-    Ji[0][0] = c00 * r;
-    Ji[0][1] = (J[0][2] * J[2][1] - J[0][1] * J[2][2]) * r;
-    Ji[0][2] = (J[0][1] * J[1][2] - J[0][2] * J[1][1]) * r;
-    Ji[1][0] = c01 * r;
-    Ji[1][1] = (J[0][0] * J[2][2] - J[0][2] * J[2][0]) * r;
-    Ji[1][2] = (J[0][2] * J[1][0] - J[0][0] * J[1][2]) * r;
-    Ji[2][0] = c02 * r;
-    Ji[2][1] = (J[0][1] * J[2][0] - J[0][0] * J[2][1]) * r;
-    Ji[2][2] = (J[0][0] * J[1][1] - J[0][1] * J[1][0]) * r;
-    double Q[6];
-    {
-      constexpr int RS[6][2] = {{0, 0}, {1, 1}, {2, 2}, {0, 1}, {0, 2}, {1, 2}};
-#pragma unroll
-      for (int u = 0; u < 6; ++u) {
-        const int a = RS[u][0], b = RS[u][1];
-        Q[u] = det * (Ji[0][a] * Ji[0][b] + Ji[1][a] * Ji[1][b] + Ji[2][a] * Ji[2][b]);
-      }
-    }
-    // 72 T_rs[ab] are small integers for the trilinear element (q1_aff_int): 15 products, then signed sums --
-    // no table traffic at all inside the loop
     double L[36];
-    {
-      double D[3][3], M[3][2];
-#pragma unroll
-      for (int u = 0; u < 3; ++u) {
-        const double qd = Q[u] * (1.0 / 72.0), qm = Q[3 + u] * (1.0 / 72.0);
-        D[u][0] = 4.0 * qd;
-        D[u][1] = 8.0 * qd;
-        D[u][2] = 16.0 * qd;
-        M[u][0] = 12.0 * qm;
-        M[u][1] = 24.0 * qm;
-      }
-      int idx = 0;
-#pragma unroll
-      for (int a = 0; a < 8; ++a)
-#pragma unroll
-        for (int c = a; c < 8; ++c, ++idx) {
-          double v = 0.0;
-#pragma unroll
-          for (int u = 0; u < 6; ++u) {
-            const int n = q1_aff_int(u, a, c);
-            const int an = n < 0 ? -n : n;
-            if (an == 0) continue;
-            const double x = u < 3 ? D[u][an == 4 ? 0 : (an == 8 ? 1 : 2)] : M[u - 3][an == 12 ? 0 : 1];
-            v = n > 0 ? v + x : v - x;
-          }
-          L[idx] = v;
-        }
-    }
+    lat_affine_L(T, S, n00, gl, L);
 #pragma unroll
     for (int a = 0; a < 8; ++a) {
       const int rx = lx - 1 + CX[a], ry = ly - 1 + CY[a], rz = lz - 1 + CZ[a];
@@ -423,6 +429,170 @@ __global__ void __launch_bounds__(TILE_THREADS, AFF ? 3 : 2) assemble_q1_hex_lat
     lat_store_plain<TX, TY, TZ>(T, acc, rlo, tid, TILE_THREADS);
   else
     lat_store<TX, TY, TZ>(T, x0, y0, acc, rlo, zrd, nbc, tid, TILE_THREADS);
+}
+
+// ---- matrix-free operator: y = A x for the scalar Laplacian WITHOUT the assembled matrix -------------------------
+// A is the matrix pyn_assemble_scalar(LAPLACE) builds with the current Dirichlet mask (imposed rows = identity,
+// imposed columns eliminated; base_problem.py:531-549 semantics): y_i = x_i on imposed rows, else
+// y_i = sum_e sum_c L_e[a_i, c] x_c over free nodes c.  Same tile scheme as the assembly: a workgroup owns
+// TX x TY x TZ rows, loads the (TX+2)(TY+2)(TZ+2) node box of x once into LDS (imposed nodes as 0), lets one lane
+// per element form y_e = L_e x_e (parallelepipeds: the closed-form L_e of lat_affine_L, i.e. bit-identical element
+// matrices to the assembly; general geometry: c G^T (G x_e) per Gauss point, no L_e at all) and adds the rows the
+// tile owns with ds_add_f64; every y is written once, p.Ap partials fused.  HBM traffic per row: x 8 B + y 8 B +
+// xyz 24 B + flag 1 B instead of the 27 x 8 B of matrix values the SELL kernel streams.
+template <int TX, int TY, int TZ>
+struct MfTile {
+  static constexpr int NR = TX * TY * TZ, EX = TX + 1, EY = TY + 1, EZ = TZ + 1, NE = EX * EY * EZ;
+  static constexpr int BX = TX + 2, BY = TY + 2, BZ = TZ + 2, NB = BX * BY * BZ;
+  static constexpr size_t BYTES = (size_t)(NB + NR) * sizeof(double) + ((NB + 7) & ~7);
+};
+
+// One Gauss point of the matrix-free apply: ye += w detJ G^T (G xe)
+__device__ __forceinline__ void gauss_point_apply(const TileArgs& T, const int G, const double (&X)[8][3], const double (&xe)[8],
+                                                  double (&ye)[8]) {
+  const double* __restrict__ hc = T.hcoo + G * 24;
+  const double* __restrict__ hr = T.hrs + G * 24;
+  double J[3][3];
+#pragma unroll
+  for (int d = 0; d < 3; ++d)
+#pragma unroll
+    for (int x = 0; x < 3; ++x) {
+      double s = 0.0;
+#pragma unroll
+      for (int c = 0; c < 8; ++c) s = fma(hc[d * 8 + c], X[c][x], s);
+      J[d][x] = s;
+    }
+  const double c00 = J[1][1] * J[2][2] - J[1][2] * J[2][1];
+  const double c01 = J[1][2] * J[2][0] - J[1][0] * J[2][2];
+  const double c02 = J[1][0] * J[2][1] - J[1][1] * J[2][0];
+  const double det = J[0][0] * c00 + J[0][1] * c01 + J[0][2] * c02;
+  const double r = 1.0 / det;
+  double Ji[3][3];
+  Ji[0][0] = c00 * r;
+  Ji[0][1] = (J[0][2] * J[2][1] - J[0][1] * J[2][2]) * r;
+  Ji[0][2] = (J[0][1] * J[1][2] - J[0][2] * J[1][1]) * r;
+  Ji[1][0] = c01 * r;
+  Ji[1][1] = (J[0][0] * J[2][2] - J[0][2] * J[2][0]) * r;
+  Ji[1][2] = (J[0][2] * J[1][0] - J[0][0] * J[1][2]) * r;
+  Ji[2][0] = c02 * r;
+  Ji[2][1] = (J[0][1] * J[2][0] - J[0][0] * J[2][1]) * r;
+  Ji[2][2] = (J[0][0] * J[1][1] - J[0][1] * J[1][0]) * r;
+  // reference-space gradient of the interpolated x, pushed to physical space, scaled, pulled back
+  double gr[3] = {0.0, 0.0, 0.0};
+#pragma unroll
+  for (int d = 0; d < 3; ++d)
+#pragma unroll
+    for (int a = 0; a < 8; ++a) gr[d] = fma(hr[d * 8 + a], xe[a], gr[d]);
+  const double cw = T.w[G] * det;
+  double gp[3], gb[3];
+#pragma unroll
+  for (int d = 0; d < 3; ++d) gp[d] = cw * fma(Ji[d][2], gr[2], fma(Ji[d][1], gr[1], Ji[d][0] * gr[0]));
+#pragma unroll
+  for (int m = 0; m < 3; ++m) gb[m] = fma(Ji[2][m], gp[2], fma(Ji[1][m], gp[1], Ji[0][m] * gp[0]));
+#pragma unroll
+  for (int a = 0; a < 8; ++a) ye[a] = fma(hr[16 + a], gb[2], fma(hr[8 + a], gb[1], fma(hr[a], gb[0], ye[a])));
+}
+
+template <int TX, int TY, int TZ, bool AFF, bool DOT>
+__global__ void __launch_bounds__(256) lattice_matfree_laplace_kernel(LatArgs T, const double* __restrict__ xin, double* __restrict__ yout,
+                                                                       const int* __restrict__ flag, double* __restrict__ part,
+                                                                       int n_tiles) {
+  using MT = MfTile<TX, TY, TZ>;
+  extern __shared__ __align__(16) double lds[];
+  __shared__ double smd[4];
+  if (flag && flag[0]) return;
+  double* xs = lds;                    // [NB] node box of x, imposed nodes as 0
+  double* acc = xs + MT::NB;           // [NR]
+  unsigned char* nbc = reinterpret_cast<unsigned char*>(acc + MT::NR);   // [NB] Dirichlet flags
+  const int tid = threadIdx.x;
+  const int nx = T.nx, ny = T.ny;
+  const double* __restrict__ S = AFF ? T.q.aff + 248 : nullptr;
+  constexpr int CX[8] = {0, 0, 1, 1, 0, 1, 1, 0};
+  constexpr int CY[8] = {0, 1, 1, 0, 0, 0, 1, 1};
+  constexpr int CZ[8] = {0, 0, 0, 0, 1, 1, 1, 1};
+  double dot = 0.0;
+  for (int tb = blockIdx.x; tb < n_tiles; tb += gridDim.x) {   // gridDim.x is a multiple of 8 or >= n_tiles: XCD kept
+    const int b = xcd_contiguous_tile(tb, n_tiles);
+    const int bx = b % T.ntx, by = (b / T.ntx) % T.nty, bz = b / (T.ntx * T.nty);
+    const int x0 = bx * TX, y0 = by * TY, z0 = bz * TZ;
+    // ---- node box
+    for (int i = tid; i < MT::NB; i += 256) {
+      const int qx = i % MT::BX, qy = (i / MT::BX) % MT::BY, qz = i / (MT::BX * MT::BY);
+      const int x = x0 - 1 + qx, y = y0 - 1 + qy, pl = T.p_own0 + z0 - 1 + qz;
+      double v = 0.0;
+      unsigned char f = 0;
+      if (x >= 0 && x < nx && y >= 0 && y < ny && pl >= 0 && pl < T.npl) {
+        const int64_t node = lat_plane(T, pl) + y * nx + x;
+        f = T.bcmask ? T.bcmask[node] : 0;
+        v = f ? 0.0 : xin[node];
+      }
+      xs[i] = v;
+      nbc[i] = f;
+    }
+    for (int i = tid; i < MT::NR; i += 256) acc[i] = 0.0;
+    __syncthreads();
+    // ---- elements
+    for (int t = tid; t < MT::NE; t += 256) {
+      const int lx = t % MT::EX, ly = (t / MT::EX) % MT::EY, lz = t / (MT::EX * MT::EY);
+      const int gx = x0 - 1 + lx, gy = y0 - 1 + ly, gl = T.p_own0 + z0 - 1 + lz;
+      if (gx < 0 || gx >= nx - 1 || gy < 0 || gy >= ny - 1 || gl < 0 || gl >= T.npl - 1) continue;
+      const int n00 = gy * nx + gx;
+      double xe[8], ye[8];
+#pragma unroll
+      for (int a = 0; a < 8; ++a) xe[a] = xs[((lz + CZ[a]) * MT::BY + ly + CY[a]) * MT::BX + lx + CX[a]];
+      if (AFF) {
+        double L[36];
+        lat_affine_L(T, S, n00, gl, L);
+#pragma unroll
+        for (int a = 0; a < 8; ++a) {
+          double sacc = 0.0;
+#pragma unroll
+          for (int c = 0; c < 8; ++c) sacc = fma(L[tri(a, c)], xe[c], sacc);
+          ye[a] = sacc;
+        }
+      } else {
+        const int pb = lat_plane(T, gl) + n00, pt = lat_plane(T, gl + 1) + n00;
+        double X[8][3];
+#pragma unroll
+        for (int a = 0; a < 8; ++a) {
+          const double* q = T.xyz + (int64_t)((CZ[a] ? pt : pb) + CY[a] * nx + CX[a]) * 3;
+          X[a][0] = q[0];
+          X[a][1] = q[1];
+          X[a][2] = q[2];
+        }
+#pragma unroll
+        for (int a = 0; a < 8; ++a) ye[a] = 0.0;
+#pragma nounroll
+        for (int g = 0; g < 8; ++g) gauss_point_apply(T.q, g, X, xe, ye);
+      }
+#pragma unroll
+      for (int a = 0; a < 8; ++a) {
+        const int rx = lx - 1 + CX[a], ry = ly - 1 + CY[a], rz = lz - 1 + CZ[a];
+        if (rx < 0 || rx >= TX || ry < 0 || ry >= TY || rz < 0 || rz >= TZ) continue;
+        atomicAdd(&acc[(rz * TY + ry) * TX + rx], ye[a]);
+      }
+    }
+    __syncthreads();
+    // ---- rows of the tile: each y written once
+    for (int s = tid; s < MT::NR; s += 256) {
+      const int rx = s % TX, ry = (s / TX) % TY, rz = s / (TX * TY);
+      const int x = x0 + rx, y = y0 + ry, zo = z0 + rz;
+      if (x >= nx || y >= ny || zo >= T.n_own) continue;
+      const int64_t node = lat_plane(T, T.p_own0 + zo) + y * nx + x;
+      const int bi = ((rz + 1) * MT::BY + ry + 1) * MT::BX + rx + 1;
+      const double xv = nbc[bi] ? xin[node] : xs[bi];
+      const double yv = nbc[bi] ? xv : acc[s];
+      yout[node] = yv;
+      if (DOT) dot = fma(yv, xv, dot);
+    }
+    __syncthreads();
+  }
+  if (DOT) {
+    for (int o = 32; o > 0; o >>= 1) dot += __shfl_xor(dot, o, 64);
+    if ((tid & 63) == 0) smd[tid >> 6] = dot;
+    __syncthreads();
+    if (tid == 0) part[blockIdx.x] = smd[0] + smd[1] + smd[2] + smd[3];
+  }
 }
 
 // ---- plan-free KLE assembly on lattices of parallelepipeds: the scalar lattice kernel's scheme (index
@@ -897,6 +1067,59 @@ int pyn_assemble_lattice(pyn_ctx* c, double* A, double* Arhs, bool* handled) {
   return PYN_OK;
 }
 
+
+// ---- matrix-free Laplacian (see lattice_matfree_laplace_kernel)
+template <int TX, int TY, int TZ>
+static int launch_matfree(pyn_ctx* c, LatArgs& T, bool affine, const double* x, double* y, bool dot, int* grid_out) {
+  using MT = MfTile<TX, TY, TZ>;
+  T.ntx = (T.nx + TX - 1) / TX;
+  T.nty = (T.ny + TY - 1) / TY;
+  const int ntz = (T.n_own + TZ - 1) / TZ;
+  const int n_tiles = T.ntx * T.nty * ntz;
+  const int grid = std::min(n_tiles, PYN_MAX_PARTIALS);   // 2048: a multiple of 8, the XCD mapping survives the stride
+  const int* flag = dot ? c->d_flag : nullptr;
+  double* part = dot ? c->d_part : nullptr;
+  hipStream_t s = c->stream;
+  if (affine) {
+    if (dot)
+      lattice_matfree_laplace_kernel<TX, TY, TZ, true, true><<<grid, 256, MT::BYTES, s>>>(T, x, y, flag, part, n_tiles);
+    else
+      lattice_matfree_laplace_kernel<TX, TY, TZ, true, false><<<grid, 256, MT::BYTES, s>>>(T, x, y, flag, part, n_tiles);
+  } else {
+    if (dot)
+      lattice_matfree_laplace_kernel<TX, TY, TZ, false, true><<<grid, 256, MT::BYTES, s>>>(T, x, y, flag, part, n_tiles);
+    else
+      lattice_matfree_laplace_kernel<TX, TY, TZ, false, false><<<grid, 256, MT::BYTES, s>>>(T, x, y, flag, part, n_tiles);
+  }
+  PYN_HIP(hipGetLastError());
+  if (grid_out) *grid_out = grid;
+  return PYN_OK;
+}
+
+bool pyn_lattice_matfree_supported(const pyn_ctx* c) {
+  return c->lat.valid && c->dim == 3 && c->nn == 8 && c->quad[0].ngp == 8;
+}
+
+// y = A x with A = the scalar Laplacian under the current Dirichlet mask (bc block size 1); x carries the ghost tail
+int pyn_lattice_matfree_spmv(pyn_ctx* c, const double* x, double* y, bool dot, int* grid_out) {
+  PYN_CHECK(pyn_lattice_matfree_supported(c), "matrix-free operator: needs a Q1 hexahedral mesh with structured topology and the "
+                                               "full-rule tables");
+  PYN_CHECK(!c->d_bcmask || c->bc_ndof == 1, "matrix-free Laplacian: the Dirichlet mask must have one DOF per node");
+  LatArgs T;
+  int mesh_aff = 0;
+  PYN_TRY(lat_fill_args(c, T, nullptr, nullptr, &mesh_aff));
+  const bool affine = mesh_aff == 1 && T.q.aff != nullptr && c->aff_standard;
+  const char* tl = getenv("PYNAMA_MATFREE_TILE");
+  switch (tl ? atoi(tl) : 0) {
+    case 1: PYN_TRY((launch_matfree<16, 8, 4>(c, T, affine, x, y, dot, grid_out))); break;
+    case 2: PYN_TRY((launch_matfree<8, 8, 8>(c, T, affine, x, y, dot, grid_out))); break;
+    case 3: PYN_TRY((launch_matfree<16, 4, 4>(c, T, affine, x, y, dot, grid_out))); break;
+    case 4: PYN_TRY((launch_matfree<32, 4, 4>(c, T, affine, x, y, dot, grid_out))); break;
+    case 5: PYN_TRY((launch_matfree<12, 6, 6>(c, T, affine, x, y, dot, grid_out))); break;
+    default: PYN_TRY((launch_matfree<16, 8, 8>(c, T, affine, x, y, dot, grid_out))); break;
+  }
+  return PYN_OK;
+}
 
 // Node graph of a lattice whose numbering has the arithmetic shape (one rank, or a rank's z-slab): built directly,
 // without the sort of pyn_csr_symbolic.  *done = false when the mesh does not qualify.

@@ -216,5 +216,7 @@ bool pyn_q1_affine_tables_standard(const double* aff);
 int pyn_mesh_all_affine(pyn_ctx* c, int* out);                        // pyn_assemble_tiled.hip
 int pyn_lattice_symbolic(pyn_ctx* c, bool* done);
 int pyn_assemble_lattice(pyn_ctx* c, double* A, double* Arhs, bool* handled);   // pyn_assemble_lattice.hip
+bool pyn_lattice_matfree_supported(const pyn_ctx* c);
+int pyn_lattice_matfree_spmv(pyn_ctx* c, const double* x, double* y, bool dot, int* grid_out);  // matrix-free Laplacian
 int pyn_assemble_kle_lattice(pyn_ctx* c, double alpha_d, double alpha_w, double* K, double* Krhs, double* Rw, bool* handled);
 bool pyn_q1_mixed_tables_standard(const double* w, const double* H, const double* Hrs);

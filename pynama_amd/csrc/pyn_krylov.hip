@@ -497,6 +497,25 @@ extern "C" int pyn_spmv(pyn_ctx* c, int mat_id, int xv, int yv) {
 }
 
 // -----------------------------------------------------------------------------------------------
+extern "C" int pyn_matfree_apply(pyn_ctx* c, int op, int xv, int yv) {
+  PYN_CHECK(c, "NULL context");
+  PYN_CHECK(op == PYN_MATFREE_LAPLACE, "unknown matrix-free operator %d", op);
+  PYN_TRY(pyn_check_vec(c, xv, "pyn_matfree_apply x"));
+  PYN_TRY(pyn_check_vec(c, yv, "pyn_matfree_apply y"));
+  PYN_CHECK(xv != yv, "x and y must differ");
+  PYN_CHECK(c->vecs[xv].bs == 1 && c->vecs[yv].bs == 1, "the matrix-free Laplacian acts on scalar vectors");
+  PYN_HIP(hipSetDevice(c->device));
+  PYN_TRY(pyn_halo_exchange(c, c->vecs[xv].d, 1));
+  PYN_HIP(hipEventRecord(c->ev0, c->stream));
+  PYN_TRY(pyn_lattice_matfree_spmv(c, c->vecs[xv].d, c->vecs[yv].d, false, nullptr));
+  PYN_HIP(hipEventRecord(c->ev1, c->stream));
+  PYN_HIP(hipStreamSynchronize(c->stream));
+  float ms = 0;
+  PYN_HIP(hipEventElapsedTime(&ms, c->ev0, c->ev1));
+  c->timers[PYN_T_SPMV] = ms;
+  return PYN_OK;
+}
+
 static int allreduce_tmp(pyn_ctx* c, int n) {
   if (c->comm)
     PYN_NCCL(ncclAllReduce(c->d_scal + S_TMP0, c->d_scal + S_TMP0, n, ncclDouble, ncclSum, c->comm, c->stream));
@@ -504,7 +523,8 @@ static int allreduce_tmp(pyn_ctx* c, int n) {
 }
 
 static int solve_cg(pyn_ctx* c, DMat& A, const double* b, double* x, const pyn_solve_opts& o, pyn_solve_info* info) {
-  const bool sell = pyn_sell_supported(A) && !getenv("PYNAMA_NO_SELL");
+  const bool mf = o.matfree == PYN_MATFREE_LAPLACE;
+  const bool sell = !mf && pyn_sell_supported(A) && !getenv("PYNAMA_NO_SELL");
   if (sell) PYN_TRY(pyn_sell_ensure(c, A));
   const int64_t n = c->n_owned * A.br;
   const int64_t nl = n_local(c) * A.br;
@@ -554,7 +574,9 @@ static int solve_cg(pyn_ctx* c, DMat& A, const double* b, double* x, const pyn_s
       const bool prof = prof_n < prof_max;
       if (prof) PYN_HIP(hipEventRecord(c->prof_ev[2 * prof_n], s));
       int gsp = gs;
-      if (sell)
+      if (mf)
+        PYN_TRY(pyn_lattice_matfree_spmv(c, p, Ap, true, &gsp));
+      else if (sell)
         PYN_TRY(pyn_sell_spmv(c, A, p, Ap, true, &gsp));
       else
         spmv_kernel<32, true><<<gs, 256, 0, s>>>(c->d_rowptr, c->d_colidx, A.val, p, Ap, rows, A.br, A.bc, c->d_flag, c->d_part);
@@ -598,7 +620,8 @@ static int solve_cg(pyn_ctx* c, DMat& A, const double* b, double* x, const pyn_s
 }
 
 static int solve_cg_sr(pyn_ctx* c, DMat& A, const double* b, double* x, const pyn_solve_opts& o, pyn_solve_info* info) {
-  const bool sell = pyn_sell_supported(A) && !getenv("PYNAMA_NO_SELL");
+  const bool mf = o.matfree == PYN_MATFREE_LAPLACE;
+  const bool sell = !mf && pyn_sell_supported(A) && !getenv("PYNAMA_NO_SELL");
   if (sell) PYN_TRY(pyn_sell_ensure(c, A));
   const int64_t n = c->n_owned * A.br;
   const int64_t nl = n_local(c) * A.br;
@@ -661,7 +684,9 @@ static int solve_cg_sr(pyn_ctx* c, DMat& A, const double* b, double* x, const py
       } else {
         PYN_TRY(pyn_halo_exchange(c, u, A.bc));
         if (prof) PYN_HIP(hipEventRecord(c->prof_ev[2 * prof_n], s));
-        if (sell)
+        if (mf)
+          PYN_TRY(pyn_lattice_matfree_spmv(c, u, w, true, &gsp));
+        else if (sell)
           PYN_TRY(pyn_sell_spmv(c, A, u, w, true, &gsp));
         else
           spmv_kernel<32, true><<<gs, 256, 0, s>>>(c->d_rowptr, c->d_colidx, A.val, u, w, rows, A.br, A.bc, c->d_flag, c->d_part);
@@ -904,10 +929,29 @@ extern "C" int pyn_solve(pyn_ctx* c, int mat_id, int bv, int xv, const pyn_solve
   PYN_CHECK(opts->pc == PYN_PC_NONE || opts->pc == PYN_PC_JACOBI, "unknown preconditioner %d", opts->pc);
   PYN_CHECK(opts->maxit > 0 || opts->fixed_iters > 0, "maxit must be positive");
   PYN_CHECK(!(c->nranks > 1 && c->detached), "detached communicator: the Krylov solve needs collectives");
+  PYN_CHECK(opts->matfree == PYN_MATFREE_OFF || opts->matfree == PYN_MATFREE_LAPLACE, "unknown matrix-free operator %d", opts->matfree);
   PYN_HIP(hipSetDevice(c->device));
   double* b = c->vecs[bv].d;
   double* x = c->vecs[xv].d;
   *info = pyn_solve_info();
+  if (opts->matfree) {
+    // the shell operator must BE the assembled matrix (which keeps supplying the Jacobi diagonal and the exit check):
+    // compare both products on b before iterating
+    PYN_CHECK(opts->method == PYN_KSP_CG, "matrix-free operator: CG only");
+    PYN_CHECK(A.br == 1, "matrix-free Laplacian: scalar matrix expected");
+    const int64_t n1 = c->n_owned;
+    PYN_TRY(pyn_ensure_work(c, (size_t)2 * n1 * sizeof(double)));
+    double *w0 = c->d_work, *w1 = c->d_work + n1;
+    PYN_TRY(pyn_halo_exchange(c, b, 1));
+    PYN_TRY(pyn_spmv_raw(c, A, b, w0));
+    PYN_TRY(pyn_lattice_matfree_spmv(c, b, w1, false, nullptr));
+    waxpby_kernel<<<vgrid(n1), 256, 0, c->stream>>>(w1, 1.0, w0, -1.0, w1, n1);
+    double dd = 0, aa = 0;
+    PYN_TRY(dev_dot(c, w1, w1, n1, &dd));
+    PYN_TRY(dev_dot(c, w0, w0, n1, &aa));
+    PYN_CHECK(dd <= 1e-20 * aa, "matrix-free operator differs from the assembled matrix (relative %.3e): was the matrix "
+                                "assembled as the Laplacian with the current Dirichlet mask?", sqrt(dd / (aa > 0 ? aa : 1.0)));
+  }
   if (opts->method == PYN_KSP_CG) {
     // cg_variant: 0 auto (standard on one GPU, single-reduction across ranks), 1 standard, 2 single-reduction
     const int v = opts->cg_variant ? opts->cg_variant : (c->comm ? 2 : 1);

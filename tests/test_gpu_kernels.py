@@ -972,3 +972,108 @@ def test_lattice_kernels_fuzz_against_generic(lib):
         finally:
             del os.environ["PYNAMA_LATTICE_TILE"]
             del os.environ["PYNAMA_KLE_LATTICE_TILE"]
+
+
+# ---- matrix-free operator (no assembled matrix inside the CG iteration) -----------------------------------------
+def _shear(mesh):
+    """affine map of the whole box: every element stays a parallelepiped, none is a brick"""
+    M = np.array([[1.0, 0.3, 0.1], [0.0, 0.9, 0.2], [0.05, 0.0, 1.1]])
+    mesh.xyz = mesh.xyz @ M.T
+    return mesh
+
+
+@pytest.mark.parametrize("nelem,geom,bc", [
+    ([20, 11, 13], "uniform", "boundary"), ([20, 11, 13], "shear", "left"), ([20, 11, 13], "jitter", "boundary"),
+    ([5, 4, 3], "jitter", "none"), ([33, 9, 9], "uniform", "none"), ([17, 18, 10], "shear", "boundary")])
+@pytest.mark.parametrize("tile", [0, 1, 2, 3, 4, 5])
+def test_matfree_laplace_vs_oracle(lib, monkeypatch, nelem, geom, bc, tile):
+    """y = A x without the matrix == the oracle's assembled Laplacian (Dirichlet rows identity, columns eliminated)
+    applied to x; parallelepiped (closed-form L_e) and general (per-Gauss-point apply) paths, all tile shapes,
+    tiles that overhang the lattice, masks on all / one / no face"""
+    monkeypatch.setenv("PYNAMA_MATFREE_TILE", str(tile))
+    mesh = fo.box_mesh(nelem, [0.0] * 3, [1.0, 0.8, 1.2], 2, jitter=0.2 if geom == "jitter" else 0.0)
+    if geom == "shear":
+        _shear(mesh)
+    nodes = {"boundary": mesh.boundary, "left": mesh.borders["left"], "none": np.zeros(0, np.int64)}[bc]
+    ctx = make_ctx(lib, mesh, 2, bc_ndof=1, bc_nodes=nodes)
+    assert ctx.mesh_topology()[0] == "lattice"
+    ref = fo.assemble_scalar(mesh, fo.Tables(2, 3), "laplace", dirichlet=nodes)
+    x = np.random.default_rng(5).standard_normal(mesh.n_node)
+    vx, vy = ctx.vec_create(1), ctx.vec_create(1)
+    ctx.vec_set(vx, x)
+    ctx.matfree_apply(vx, vy)
+    assert rel_err(ctx.vec_get(vy, 1), ref["A"] @ x) < FP_TOL
+    ctx.close()
+
+
+@pytest.mark.parametrize("geom,variant", [("uniform", 1), ("jitter", 1), ("shear", 2)])
+def test_matfree_cg_equals_assembled_cg(lib, geom, variant):
+    """CG driven by the matrix-free operator (assembled matrix = Jacobi diagonal + exit check only) reproduces the
+    assembled-matrix solve: same iteration count (+-1), same solution, true residual (computed with the ASSEMBLED
+    matrix) below the bar; an assembled matrix that is not this operator is refused"""
+    mesh = fo.box_mesh([18, 12, 10], [0.0] * 3, [1.0] * 3, 2, jitter=0.2 if geom == "jitter" else 0.0)
+    if geom == "shear":
+        _shear(mesh)
+    ctx = make_ctx(lib, mesh, 2, bc_ndof=1, bc_nodes=mesh.boundary)
+    A, M = ctx.mat_create(1, 1), ctx.mat_create(1, 1)
+    ctx.assemble_scalar(lib.FORM_LAPLACE, A)
+    ctx.assemble_scalar(lib.FORM_MASS_NODAL, M)
+    b = np.random.default_rng(9).standard_normal(mesh.n_node)
+    b[mesh.boundary] = 0.0
+    vb, vx = ctx.vec_create(1), ctx.vec_create(1)
+    ctx.vec_set(vb, b)
+    kw = dict(rtol=1e-10, norm_type=lib.NORM_UNPRECONDITIONED, cg_variant=variant)
+    i0 = ctx.solve(A, vb, vx, **kw)
+    x0 = ctx.vec_get(vx, 1)
+    i1 = ctx.solve(A, vb, vx, matfree=lib.MATFREE_LAPLACE, **kw)
+    x1 = ctx.vec_get(vx, 1)
+    assert i0.reason == 2 and i1.reason == 2 and abs(i0.iters - i1.iters) <= 1
+    assert i1.true_resid < 2e-10 and rel_err(x1, x0) < 1e-8
+    with pytest.raises(lib.PynamaHipError, match="differs from the assembled matrix"):
+        ctx.solve(M, vb, vx, matfree=lib.MATFREE_LAPLACE, **kw)
+    with pytest.raises(lib.PynamaHipError, match="CG only"):
+        ctx.solve(A, vb, vx, method=lib.KSP_GMRES, matfree=lib.MATFREE_LAPLACE)
+    ctx.close()
+
+
+def test_matfree_needs_structured_topology(lib):
+    mesh = fo.box_mesh([5, 4, 3], [0, 0, 0], [1, 1, 1], 2)
+    perm = np.random.default_rng(1).permutation(mesh.n_node)
+    mesh.conn = perm[mesh.conn].astype(np.int32)
+    mesh.xyz = mesh.xyz[np.argsort(perm)]
+    ctx = make_ctx(lib, mesh, 2)
+    vx, vy = ctx.vec_create(1), ctx.vec_create(1)
+    with pytest.raises(lib.PynamaHipError, match="structured topology"):
+        ctx.matfree_apply(vx, vy)
+    ctx.close()
+
+
+@pytest.mark.parametrize("size", [2, 3])
+def test_matfree_on_rank_slabs(lib, size):
+    """a rank's z-slab (owned planes + ghost planes, ghosts at the vector tail): matrix-free rows == serial rows"""
+    from pynama_amd.common.comm import Comm
+    from pynama_amd.domain.dmplex import DMPlexDom
+    from pynama_amd.elements.spectral import Spectral
+    nelem = [6, 5, 9]
+    for jitter in (0.0, 0.2):
+        glob = fo.box_mesh(nelem, [0, 0, 0], [1, 1, 1], 2, jitter=jitter)
+        ref = fo.assemble_scalar(glob, fo.Tables(2, 3), "laplace", dirichlet=glob.boundary)
+        xg = np.random.default_rng(11).standard_normal(glob.n_node)
+        yg = ref["A"] @ xg
+        for r in range(size):
+            dom = DMPlexDom(boxMesh={'nelem': nelem, 'lower': [0, 0, 0], 'upper': [1, 1, 1]}, comm=Comm(r, size), jitter=jitter)
+            dom.setFemIndexing(2)
+            ctx = lib.Context(0)
+            ctx.comm_init(r, size, None)                      # detached
+            ctx.halo_set(*dom._halo_plan())
+            ctx.mesh_set(3, dom.conn, dom.xyz)
+            for t in Spectral(2, 3).deviceTables():
+                ctx.tables_set(*t)
+            ctx.bc_set(1, dom.boundaryMaskLocal())
+            ctx.csr_symbolic()
+            cols = dom._local2global(np.arange(dom.nLocal))
+            vx, vy = ctx.vec_create(1), ctx.vec_create(1)
+            ctx.vec_set_local(vx, xg[cols])
+            ctx.matfree_apply(vx, vy)
+            assert rel_err(ctx.vec_get(vy, 1), yg[dom.rStart:dom.rEnd]) < FP_TOL
+            ctx.close()
