@@ -205,8 +205,11 @@ int pyn_spmv(pyn_ctx* ctx, int mat_id, int x_vec, int y_vec);
  * (imposed rows identity, imposed columns eliminated, base_problem.py:531-549).  Element matrices are recomputed on
  * the fly (Spectral.getElemKLEMatrices' scalar block, spectral.py:120-131) and applied per element; needs a Q1
  * hexahedral mesh with structured topology (pyn_mesh_topology == lattice), errors otherwise. */
-enum { PYN_MATFREE_OFF = 0, PYN_MATFREE_LAPLACE = 1 };
+enum { PYN_MATFREE_OFF = 0, PYN_MATFREE_LAPLACE = 1, PYN_MATFREE_KLE = 2 };
 int pyn_matfree_apply(pyn_ctx* ctx, int op, int x_vec, int y_vec);
+/* PYN_MATFREE_KLE: A is the K of pyn_assemble_kle (3 DOFs per node, per-DOF Dirichlet mask; spectral.py:131,152-153);
+ * alpha_d / alpha_w are the penalty weights of that call (1e3 / 1e2 in the reference, spectral.py:152-153). */
+int pyn_matfree_kle_set(pyn_ctx* ctx, double alpha_d, double alpha_w);
 typedef struct pyn_solve_opts {
   int method;        /* PYN_KSP_*  */
   int pc;            /* PYN_PC_*   */

@@ -19,7 +19,7 @@ CSRC = os.path.join(_HERE, "csrc")
 Q_FULL, Q_RED, Q_NODAL = 0, 1, 2
 FORM_LAPLACE, FORM_MASS_NODAL, FORM_MASS_FULL, FORM_KLE = 0, 1, 2, 3
 KSP_CG, KSP_GMRES = 0, 1
-MATFREE_OFF, MATFREE_LAPLACE = 0, 1
+MATFREE_OFF, MATFREE_LAPLACE, MATFREE_KLE = 0, 1, 2
 PC_NONE, PC_JACOBI = 0, 1
 NORM_PRECONDITIONED, NORM_UNPRECONDITIONED, NORM_NATURAL = 0, 1, 2
 T_SYMBOLIC, T_ASSEMBLE, T_SPMV, T_SOLVE = 0, 1, 2, 3
@@ -96,6 +96,7 @@ SIGNATURES = {
     "pyn_elem_operator_local": [_P, _I, _I, _I, _I, _pi32, _pf64, _pf64, _pf64],
     "pyn_spmv": [_P, _I, _I, _I],
     "pyn_matfree_apply": [_P, _I, _I, _I],
+    "pyn_matfree_kle_set": [_P, _D, _D],
     "pyn_solve": [_P, _I, _I, _I, C.POINTER(SolveOpts), C.POINTER(SolveInfo)],
     "pyn_timers_get": [_P, _pf64, _I],
 }
@@ -382,8 +383,12 @@ class Context:
         _check(self.lib.pyn_spmv(self.h, mid, x, y))
 
     def matfree_apply(self, x, y, op=1):
-        """y = A x with the matrix-free scalar Laplacian (no assembled matrix; structured Q1 hex meshes)"""
+        """y = A x without an assembled matrix (op: MATFREE_LAPLACE scalar / MATFREE_KLE 3 DOFs per node; structured Q1
+        hex meshes)"""
         _check(self.lib.pyn_matfree_apply(self.h, op, x, y))
+
+    def matfree_kle_set(self, alpha_d, alpha_w):
+        _check(self.lib.pyn_matfree_kle_set(self.h, alpha_d, alpha_w))
 
     def solve(self, mid, b, x, method=KSP_CG, pc=PC_JACOBI, rtol=1e-5, atol=1e-50, dtol=1e5, maxit=10000,
               restart=30, norm_type=NORM_PRECONDITIONED, fixed_iters=0, profile=0, cg_variant=0, gmres_orthog=0,

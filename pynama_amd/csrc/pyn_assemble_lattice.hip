@@ -284,7 +284,8 @@ __device__ __forceinline__ bool lat_tile_plain(const LatArgs& T, int x0, int y0,
 // loop, no affinity test: ~110 VGPRs instead of ~170, i.e. 4 instead of 2-3 waves per SIMD to hide the gather
 // and store latencies.  lat_affine_L: the 36 upper-triangle entries of L_e for the element whose lowest corner is
 // node n00 of plane gl (shared with the matrix-free operator below).
-__device__ __forceinline__ void lat_affine_L(const LatArgs& T, const double* __restrict__ S, int n00, int gl, double (&L)[36]) {
+// inverse Jacobian and determinant of the parallelepiped element whose lowest corner is node n00 of plane gl
+__device__ __forceinline__ double lat_affine_geom(const LatArgs& T, const double* __restrict__ S, int n00, int gl, double (&Ji)[3][3]) {
   const int nx = T.nx;
   const double* q0 = T.xyz + (int64_t)(lat_plane(T, gl) + n00) * 3;
   const double* qz = T.xyz + (int64_t)(lat_plane(T, gl + 1) + n00) * 3;
@@ -306,7 +307,6 @@ __device__ __forceinline__ void lat_affine_L(const LatArgs& T, const double* __r
   const double c02 = J[1][0] * J[2][1] - J[1][1] * J[2][0];
   const double det = J[0][0] * c00 + J[0][1] * c01 + J[0][2] * c02;
   const double r = 1.0 / det;
-  double Ji[3][3];
   Ji[0][0] = c00 * r;
   Ji[0][1] = (J[0][2] * J[2][1] - J[0][1] * J[2][2]) * r;
   Ji[0][2] = (J[0][1] * J[1][2] - J[0][2] * J[1][1]) * r;
@@ -316,6 +316,10 @@ __device__ __forceinline__ void lat_affine_L(const LatArgs& T, const double* __r
   Ji[2][0] = c02 * r;
   Ji[2][1] = (J[0][1] * J[2][0] - J[0][0] * J[2][1]) * r;
   Ji[2][2] = (J[0][0] * J[1][1] - J[0][1] * J[1][0]) * r;
+  return det;
+}
+
+__device__ __forceinline__ void lat_affine_L_from(const double (&Ji)[3][3], const double det, double (&L)[36]) {
   double Q[6];
   {
     constexpr int RS[6][2] = {{0, 0}, {1, 1}, {2, 2}, {0, 1}, {0, 2}, {1, 2}};
@@ -355,6 +359,12 @@ __device__ __forceinline__ void lat_affine_L(const LatArgs& T, const double* __r
         L[idx] = v;
       }
   }
+}
+
+__device__ __forceinline__ void lat_affine_L(const LatArgs& T, const double* __restrict__ S, int n00, int gl, double (&L)[36]) {
+  double Ji[3][3];
+  const double det = lat_affine_geom(T, S, n00, gl, Ji);
+  lat_affine_L_from(Ji, det, L);
 }
 
 template <int TX, int TY, int TZ>
@@ -604,6 +614,217 @@ struct KleLatArgs {
   double alpha_d, alpha_w;
   const double *wr, *hrsr, *Hr, *hcoor;   // reduced (centroid) rule
 };
+
+// ---- matrix-free KLE operator: y = K x (3 DOFs per node) without the assembled matrix --------------------------------
+// K is what pyn_assemble_kle builds (spectral.py:131,152-153 + base_problem.py:531-549): per element
+//   K[(a,p),(b,q)] = d_pq (L_ab + c aw G_a.G_b) + c (ad G_pa G_qb - aw G_qa G_pb),   G = reduced-point gradients, c = w_r detJ
+// so with the velocity gradient at the centroid D[d][q] = sum_b G_db x_bq the element product is
+//   y_ap = sum_b L_ab x_bp + sum_d G_da W_dp,   W = c aw (D - D^T) + c ad tr(D) I
+// (the Laplacian on every component + a rank-9 correction: ~350 FMAs instead of a 24 x 24 block).  Dirichlet DOFs:
+// imposed columns enter as 0, imposed rows return x.  Same tile scheme as the scalar kernel, 3 doubles per node.
+__device__ __forceinline__ double jac_inverse(const double* __restrict__ hc, const double (&X)[8][3], double (&Ji)[3][3]) {
+  double J[3][3];
+#pragma unroll
+  for (int d = 0; d < 3; ++d)
+#pragma unroll
+    for (int x = 0; x < 3; ++x) {
+      double s = 0.0;
+#pragma unroll
+      for (int c = 0; c < 8; ++c) s = fma(hc[d * 8 + c], X[c][x], s);
+      J[d][x] = s;
+    }
+  const double c00 = J[1][1] * J[2][2] - J[1][2] * J[2][1];
+  const double c01 = J[1][2] * J[2][0] - J[1][0] * J[2][2];
+  const double c02 = J[1][0] * J[2][1] - J[1][1] * J[2][0];
+  const double det = J[0][0] * c00 + J[0][1] * c01 + J[0][2] * c02;
+  const double r = 1.0 / det;
+  Ji[0][0] = c00 * r;
+  Ji[0][1] = (J[0][2] * J[2][1] - J[0][1] * J[2][2]) * r;
+  Ji[0][2] = (J[0][1] * J[1][2] - J[0][2] * J[1][1]) * r;
+  Ji[1][0] = c01 * r;
+  Ji[1][1] = (J[0][0] * J[2][2] - J[0][2] * J[2][0]) * r;
+  Ji[1][2] = (J[0][2] * J[1][0] - J[0][0] * J[1][2]) * r;
+  Ji[2][0] = c02 * r;
+  Ji[2][1] = (J[0][1] * J[2][0] - J[0][0] * J[2][1]) * r;
+  Ji[2][2] = (J[0][0] * J[1][1] - J[0][1] * J[1][0]) * r;
+  return det;
+}
+
+// reduced-rule part of the element product: ye += sum_d G_da W_dp
+__device__ __forceinline__ void kle_reduced_apply(const KleLatArgs& T, const double (&Ji)[3][3], double det, const double (&xe)[8][3],
+                                                  double (&ye)[8][3]) {
+  const double* __restrict__ hr = T.hrsr;
+  const double cr = T.wr[0] * det;
+  const double caw = cr * T.alpha_w, cad = cr * T.alpha_d;
+  double Gr[3][8];
+#pragma unroll
+  for (int d = 0; d < 3; ++d)
+#pragma unroll
+    for (int a = 0; a < 8; ++a) Gr[d][a] = fma(Ji[d][2], hr[16 + a], fma(Ji[d][1], hr[8 + a], Ji[d][0] * hr[a]));
+  double D[3][3];
+#pragma unroll
+  for (int d = 0; d < 3; ++d)
+#pragma unroll
+    for (int q = 0; q < 3; ++q) {
+      double sacc = 0.0;
+#pragma unroll
+      for (int b = 0; b < 8; ++b) sacc = fma(Gr[d][b], xe[b][q], sacc);
+      D[d][q] = sacc;
+    }
+  const double tr = cad * (D[0][0] + D[1][1] + D[2][2]);
+  double W[3][3];
+#pragma unroll
+  for (int d = 0; d < 3; ++d)
+#pragma unroll
+    for (int pp = 0; pp < 3; ++pp) W[d][pp] = d == pp ? tr : caw * (D[d][pp] - D[pp][d]);
+#pragma unroll
+  for (int a = 0; a < 8; ++a)
+#pragma unroll
+    for (int pp = 0; pp < 3; ++pp)
+      ye[a][pp] = fma(Gr[2][a], W[2][pp], fma(Gr[1][a], W[1][pp], fma(Gr[0][a], W[0][pp], ye[a][pp])));
+}
+
+template <int TX, int TY, int TZ, bool AFF, bool DOT>
+__global__ void __launch_bounds__(256) lattice_matfree_kle_kernel(KleLatArgs K, const double* __restrict__ xin, double* __restrict__ yout,
+                                                                   const int* __restrict__ flag, double* __restrict__ part, int n_tiles) {
+  using MT = MfTile<TX, TY, TZ>;
+  extern __shared__ __align__(16) double lds[];
+  __shared__ double smd[4];
+  if (flag && flag[0]) return;
+  const LatArgs& T = K.L;
+  double* xs = lds;                        // [NB][3] node box of x, imposed DOFs as 0
+  double* acc = xs + MT::NB * 3;           // [NR][3]
+  unsigned char* nbc = reinterpret_cast<unsigned char*>(acc + MT::NR * 3);   // [NB] bit q: DOF q imposed
+  const int tid = threadIdx.x;
+  const int nx = T.nx, ny = T.ny;
+  const double* __restrict__ S = AFF ? T.q.aff + 248 : nullptr;
+  constexpr int CX[8] = {0, 0, 1, 1, 0, 1, 1, 0};
+  constexpr int CY[8] = {0, 1, 1, 0, 0, 0, 1, 1};
+  constexpr int CZ[8] = {0, 0, 0, 0, 1, 1, 1, 1};
+  double dot = 0.0;
+  for (int tb = blockIdx.x; tb < n_tiles; tb += gridDim.x) {
+    const int b = xcd_contiguous_tile(tb, n_tiles);
+    const int bx = b % T.ntx, by = (b / T.ntx) % T.nty, bz = b / (T.ntx * T.nty);
+    const int x0 = bx * TX, y0 = by * TY, z0 = bz * TZ;
+    for (int i = tid; i < MT::NB; i += 256) {
+      const int qx = i % MT::BX, qy = (i / MT::BX) % MT::BY, qz = i / (MT::BX * MT::BY);
+      const int x = x0 - 1 + qx, y = y0 - 1 + qy, pl = T.p_own0 + z0 - 1 + qz;
+      double v[3] = {0.0, 0.0, 0.0};
+      unsigned char f = 0;
+      if (x >= 0 && x < nx && y >= 0 && y < ny && pl >= 0 && pl < T.npl) {
+        const int64_t node = lat_plane(T, pl) + y * nx + x;
+#pragma unroll
+        for (int q = 0; q < 3; ++q) {
+          const int fq = T.bcmask ? (T.bcmask[node * 3 + q] ? 1 : 0) : 0;
+          f |= fq << q;
+          v[q] = fq ? 0.0 : xin[node * 3 + q];
+        }
+      }
+      xs[i * 3] = v[0];
+      xs[i * 3 + 1] = v[1];
+      xs[i * 3 + 2] = v[2];
+      nbc[i] = f;
+    }
+    for (int i = tid; i < MT::NR * 3; i += 256) acc[i] = 0.0;
+    __syncthreads();
+    for (int t = tid; t < MT::NE; t += 256) {
+      const int lx = t % MT::EX, ly = (t / MT::EX) % MT::EY, lz = t / (MT::EX * MT::EY);
+      const int gx = x0 - 1 + lx, gy = y0 - 1 + ly, gl = T.p_own0 + z0 - 1 + lz;
+      if (gx < 0 || gx >= nx - 1 || gy < 0 || gy >= ny - 1 || gl < 0 || gl >= T.npl - 1) continue;
+      const int n00 = gy * nx + gx;
+      double xe[8][3], ye[8][3];
+#pragma unroll
+      for (int a = 0; a < 8; ++a) {
+        const double* q = xs + (((lz + CZ[a]) * MT::BY + ly + CY[a]) * MT::BX + lx + CX[a]) * 3;
+        xe[a][0] = q[0];
+        xe[a][1] = q[1];
+        xe[a][2] = q[2];
+      }
+      if (AFF) {
+        double Ji[3][3], L[36];
+        const double det = lat_affine_geom(T, S, n00, gl, Ji);
+        lat_affine_L_from(Ji, det, L);
+#pragma unroll
+        for (int a = 0; a < 8; ++a)
+#pragma unroll
+          for (int pp = 0; pp < 3; ++pp) {
+            double sacc = 0.0;
+#pragma unroll
+            for (int c = 0; c < 8; ++c) sacc = fma(L[tri(a, c)], xe[c][pp], sacc);
+            ye[a][pp] = sacc;
+          }
+        kle_reduced_apply(K, Ji, det, xe, ye);
+      } else {
+        const int pb = lat_plane(T, gl) + n00, pt = lat_plane(T, gl + 1) + n00;
+        double X[8][3];
+#pragma unroll
+        for (int a = 0; a < 8; ++a) {
+          const double* q = T.xyz + (int64_t)((CZ[a] ? pt : pb) + CY[a] * nx + CX[a]) * 3;
+          X[a][0] = q[0];
+          X[a][1] = q[1];
+          X[a][2] = q[2];
+        }
+#pragma unroll
+        for (int a = 0; a < 8; ++a) ye[a][0] = ye[a][1] = ye[a][2] = 0.0;
+#pragma nounroll
+        for (int g = 0; g < 8; ++g) {   // full rule: the Laplacian on every component, ye += w detJ G^T (G xe)
+          const double* __restrict__ hr = T.q.hrs + g * 24;
+          double Ji[3][3];
+          const double cw = T.q.w[g] * jac_inverse(T.q.hcoo + g * 24, X, Ji);
+#pragma unroll
+          for (int pp = 0; pp < 3; ++pp) {
+            double gr[3] = {0.0, 0.0, 0.0};
+#pragma unroll
+            for (int d = 0; d < 3; ++d)
+#pragma unroll
+              for (int a = 0; a < 8; ++a) gr[d] = fma(hr[d * 8 + a], xe[a][pp], gr[d]);
+            double gp[3], gb[3];
+#pragma unroll
+            for (int d = 0; d < 3; ++d) gp[d] = cw * fma(Ji[d][2], gr[2], fma(Ji[d][1], gr[1], Ji[d][0] * gr[0]));
+#pragma unroll
+            for (int m = 0; m < 3; ++m) gb[m] = fma(Ji[2][m], gp[2], fma(Ji[1][m], gp[1], Ji[0][m] * gp[0]));
+#pragma unroll
+            for (int a = 0; a < 8; ++a) ye[a][pp] = fma(hr[16 + a], gb[2], fma(hr[8 + a], gb[1], fma(hr[a], gb[0], ye[a][pp])));
+          }
+        }
+        double Ji[3][3];
+        const double det = jac_inverse(K.hcoor, X, Ji);
+        kle_reduced_apply(K, Ji, det, xe, ye);
+      }
+#pragma unroll
+      for (int a = 0; a < 8; ++a) {
+        const int rx = lx - 1 + CX[a], ry = ly - 1 + CY[a], rz = lz - 1 + CZ[a];
+        if (rx < 0 || rx >= TX || ry < 0 || ry >= TY || rz < 0 || rz >= TZ) continue;
+        double* row = acc + ((rz * TY + ry) * TX + rx) * 3;
+        atomicAdd(&row[0], ye[a][0]);
+        atomicAdd(&row[1], ye[a][1]);
+        atomicAdd(&row[2], ye[a][2]);
+      }
+    }
+    __syncthreads();
+    for (int s = tid; s < MT::NR * 3; s += 256) {
+      const int r = s / 3, q = s - r * 3;
+      const int rx = r % TX, ry = (r / TX) % TY, rz = r / (TX * TY);
+      const int x = x0 + rx, y = y0 + ry, zo = z0 + rz;
+      if (x >= nx || y >= ny || zo >= T.n_own) continue;
+      const int64_t node = lat_plane(T, T.p_own0 + zo) + y * nx + x;
+      const int bi = ((rz + 1) * MT::BY + ry + 1) * MT::BX + rx + 1;
+      const bool imp = (nbc[bi] >> q) & 1;
+      const double xv = imp ? xin[node * 3 + q] : xs[bi * 3 + q];
+      const double yv = imp ? xv : acc[s];
+      yout[node * 3 + q] = yv;
+      if (DOT) dot = fma(yv, xv, dot);
+    }
+    __syncthreads();
+  }
+  if (DOT) {
+    for (int o = 32; o > 0; o >>= 1) dot += __shfl_xor(dot, o, 64);
+    if ((tid & 63) == 0) smd[tid >> 6] = dot;
+    __syncthreads();
+    if (tid == 0) part[blockIdx.x] = smd[0] + smd[1] + smd[2] + smd[3];
+  }
+}
+
 
 template <int TX, int TY, int TZ, bool RW, int A0>
 __device__ __forceinline__ void kle_lat_rows(const KleLatArgs& T, const double (&Ji)[3][3], double det, int lx, int ly, int lz,
@@ -1117,6 +1338,61 @@ int pyn_lattice_matfree_spmv(pyn_ctx* c, const double* x, double* y, bool dot, i
     case 4: PYN_TRY((launch_matfree<32, 4, 4>(c, T, affine, x, y, dot, grid_out))); break;
     case 5: PYN_TRY((launch_matfree<12, 6, 6>(c, T, affine, x, y, dot, grid_out))); break;
     default: PYN_TRY((launch_matfree<16, 8, 8>(c, T, affine, x, y, dot, grid_out))); break;
+  }
+  return PYN_OK;
+}
+
+template <int TX, int TY, int TZ>
+static int launch_matfree_kle(pyn_ctx* c, KleLatArgs& K, bool affine, const double* x, double* y, bool dot, int* grid_out) {
+  using MT = MfTile<TX, TY, TZ>;
+  LatArgs& T = K.L;
+  T.ntx = (T.nx + TX - 1) / TX;
+  T.nty = (T.ny + TY - 1) / TY;
+  const int ntz = (T.n_own + TZ - 1) / TZ;
+  const int n_tiles = T.ntx * T.nty * ntz;
+  const int grid = std::min(n_tiles, PYN_MAX_PARTIALS);
+  const size_t lds = (size_t)(MT::NB + MT::NR) * 3 * sizeof(double) + ((MT::NB + 7) & ~7);
+  const int* flag = dot ? c->d_flag : nullptr;
+  double* part = dot ? c->d_part : nullptr;
+  hipStream_t s = c->stream;
+  if (affine) {
+    if (dot)
+      lattice_matfree_kle_kernel<TX, TY, TZ, true, true><<<grid, 256, lds, s>>>(K, x, y, flag, part, n_tiles);
+    else
+      lattice_matfree_kle_kernel<TX, TY, TZ, true, false><<<grid, 256, lds, s>>>(K, x, y, flag, part, n_tiles);
+  } else {
+    if (dot)
+      lattice_matfree_kle_kernel<TX, TY, TZ, false, true><<<grid, 256, lds, s>>>(K, x, y, flag, part, n_tiles);
+    else
+      lattice_matfree_kle_kernel<TX, TY, TZ, false, false><<<grid, 256, lds, s>>>(K, x, y, flag, part, n_tiles);
+  }
+  PYN_HIP(hipGetLastError());
+  if (grid_out) *grid_out = grid;
+  return PYN_OK;
+}
+
+// y = K x with K = the KLE stiffness under the current per-DOF Dirichlet mask (pyn_matfree_kle_set supplied alpha_d, alpha_w)
+int pyn_lattice_matfree_kle_spmv(pyn_ctx* c, const double* x, double* y, bool dot, int* grid_out) {
+  PYN_CHECK(pyn_lattice_matfree_supported(c) && c->quad[1].ngp == 1,
+            "matrix-free operator: needs a Q1 hexahedral mesh with structured topology and the full- and reduced-rule tables");
+  PYN_CHECK(c->mf_kle_set, "matrix-free KLE operator: pyn_matfree_kle_set first");
+  PYN_CHECK(!c->d_bcmask || c->bc_ndof == 3, "matrix-free KLE operator: the Dirichlet mask must have three DOFs per node");
+  KleLatArgs K;
+  int mesh_aff = 0;
+  PYN_TRY(lat_fill_args(c, K.L, nullptr, nullptr, &mesh_aff));
+  K.alpha_d = c->mf_alpha_d;
+  K.alpha_w = c->mf_alpha_w;
+  K.wr = c->quad[1].w;
+  K.hrsr = c->quad[1].Hrs;
+  K.Hr = c->quad[1].H;
+  K.hcoor = c->quad[1].HrsCoo;
+  const bool affine = mesh_aff == 1 && K.L.q.aff != nullptr && c->aff_standard;
+  const char* tl = getenv("PYNAMA_MATFREE_TILE");
+  switch (tl ? atoi(tl) : 0) {
+    case 1: PYN_TRY((launch_matfree_kle<16, 8, 4>(c, K, affine, x, y, dot, grid_out))); break;
+    case 2: PYN_TRY((launch_matfree_kle<6, 6, 6>(c, K, affine, x, y, dot, grid_out))); break;
+    case 3: PYN_TRY((launch_matfree_kle<16, 4, 4>(c, K, affine, x, y, dot, grid_out))); break;
+    default: PYN_TRY((launch_matfree_kle<8, 8, 8>(c, K, affine, x, y, dot, grid_out))); break;
   }
   return PYN_OK;
 }

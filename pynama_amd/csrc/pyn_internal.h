@@ -155,6 +155,8 @@ struct pyn_ctx {
 
   // boundary condition
   int bc_ndof = 0;
+  bool mf_kle_set = false;     // matrix-free KLE operator parameters (pyn_matfree_kle_set)
+  double mf_alpha_d = 0.0, mf_alpha_w = 0.0;
   int64_t bc_stamp = 0;  // bumped by every pyn_bc_set
   uint8_t* d_bcmask = nullptr;
 
@@ -218,5 +220,6 @@ int pyn_lattice_symbolic(pyn_ctx* c, bool* done);
 int pyn_assemble_lattice(pyn_ctx* c, double* A, double* Arhs, bool* handled);   // pyn_assemble_lattice.hip
 bool pyn_lattice_matfree_supported(const pyn_ctx* c);
 int pyn_lattice_matfree_spmv(pyn_ctx* c, const double* x, double* y, bool dot, int* grid_out);  // matrix-free Laplacian
+int pyn_lattice_matfree_kle_spmv(pyn_ctx* c, const double* x, double* y, bool dot, int* grid_out);  // matrix-free KLE stiffness
 int pyn_assemble_kle_lattice(pyn_ctx* c, double alpha_d, double alpha_w, double* K, double* Krhs, double* Rw, bool* handled);
 bool pyn_q1_mixed_tables_standard(const double* w, const double* H, const double* Hrs);

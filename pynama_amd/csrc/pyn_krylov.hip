@@ -497,17 +497,30 @@ extern "C" int pyn_spmv(pyn_ctx* c, int mat_id, int xv, int yv) {
 }
 
 // -----------------------------------------------------------------------------------------------
+static int matfree_product(pyn_ctx* c, int op, const double* x, double* y, bool dot, int* grid_out) {
+  return op == PYN_MATFREE_KLE ? pyn_lattice_matfree_kle_spmv(c, x, y, dot, grid_out) : pyn_lattice_matfree_spmv(c, x, y, dot, grid_out);
+}
+
+extern "C" int pyn_matfree_kle_set(pyn_ctx* c, double alpha_d, double alpha_w) {
+  PYN_CHECK(c, "NULL context");
+  c->mf_alpha_d = alpha_d;
+  c->mf_alpha_w = alpha_w;
+  c->mf_kle_set = true;
+  return PYN_OK;
+}
+
 extern "C" int pyn_matfree_apply(pyn_ctx* c, int op, int xv, int yv) {
   PYN_CHECK(c, "NULL context");
-  PYN_CHECK(op == PYN_MATFREE_LAPLACE, "unknown matrix-free operator %d", op);
+  PYN_CHECK(op == PYN_MATFREE_LAPLACE || op == PYN_MATFREE_KLE, "unknown matrix-free operator %d", op);
   PYN_TRY(pyn_check_vec(c, xv, "pyn_matfree_apply x"));
   PYN_TRY(pyn_check_vec(c, yv, "pyn_matfree_apply y"));
   PYN_CHECK(xv != yv, "x and y must differ");
-  PYN_CHECK(c->vecs[xv].bs == 1 && c->vecs[yv].bs == 1, "the matrix-free Laplacian acts on scalar vectors");
+  const int bs = op == PYN_MATFREE_KLE ? 3 : 1;
+  PYN_CHECK(c->vecs[xv].bs == bs && c->vecs[yv].bs == bs, "this matrix-free operator acts on vectors of block size %d", bs);
   PYN_HIP(hipSetDevice(c->device));
-  PYN_TRY(pyn_halo_exchange(c, c->vecs[xv].d, 1));
+  PYN_TRY(pyn_halo_exchange(c, c->vecs[xv].d, bs));
   PYN_HIP(hipEventRecord(c->ev0, c->stream));
-  PYN_TRY(pyn_lattice_matfree_spmv(c, c->vecs[xv].d, c->vecs[yv].d, false, nullptr));
+  PYN_TRY(matfree_product(c, op, c->vecs[xv].d, c->vecs[yv].d, false, nullptr));
   PYN_HIP(hipEventRecord(c->ev1, c->stream));
   PYN_HIP(hipStreamSynchronize(c->stream));
   float ms = 0;
@@ -523,7 +536,7 @@ static int allreduce_tmp(pyn_ctx* c, int n) {
 }
 
 static int solve_cg(pyn_ctx* c, DMat& A, const double* b, double* x, const pyn_solve_opts& o, pyn_solve_info* info) {
-  const bool mf = o.matfree == PYN_MATFREE_LAPLACE;
+  const bool mf = o.matfree != PYN_MATFREE_OFF;
   const bool sell = !mf && pyn_sell_supported(A) && !getenv("PYNAMA_NO_SELL");
   if (sell) PYN_TRY(pyn_sell_ensure(c, A));
   const int64_t n = c->n_owned * A.br;
@@ -575,7 +588,7 @@ static int solve_cg(pyn_ctx* c, DMat& A, const double* b, double* x, const pyn_s
       if (prof) PYN_HIP(hipEventRecord(c->prof_ev[2 * prof_n], s));
       int gsp = gs;
       if (mf)
-        PYN_TRY(pyn_lattice_matfree_spmv(c, p, Ap, true, &gsp));
+        PYN_TRY(matfree_product(c, o.matfree, p, Ap, true, &gsp));
       else if (sell)
         PYN_TRY(pyn_sell_spmv(c, A, p, Ap, true, &gsp));
       else
@@ -620,7 +633,7 @@ static int solve_cg(pyn_ctx* c, DMat& A, const double* b, double* x, const pyn_s
 }
 
 static int solve_cg_sr(pyn_ctx* c, DMat& A, const double* b, double* x, const pyn_solve_opts& o, pyn_solve_info* info) {
-  const bool mf = o.matfree == PYN_MATFREE_LAPLACE;
+  const bool mf = o.matfree != PYN_MATFREE_OFF;
   const bool sell = !mf && pyn_sell_supported(A) && !getenv("PYNAMA_NO_SELL");
   if (sell) PYN_TRY(pyn_sell_ensure(c, A));
   const int64_t n = c->n_owned * A.br;
@@ -685,7 +698,7 @@ static int solve_cg_sr(pyn_ctx* c, DMat& A, const double* b, double* x, const py
         PYN_TRY(pyn_halo_exchange(c, u, A.bc));
         if (prof) PYN_HIP(hipEventRecord(c->prof_ev[2 * prof_n], s));
         if (mf)
-          PYN_TRY(pyn_lattice_matfree_spmv(c, u, w, true, &gsp));
+          PYN_TRY(matfree_product(c, o.matfree, u, w, true, &gsp));
         else if (sell)
           PYN_TRY(pyn_sell_spmv(c, A, u, w, true, &gsp));
         else
@@ -929,7 +942,7 @@ extern "C" int pyn_solve(pyn_ctx* c, int mat_id, int bv, int xv, const pyn_solve
   PYN_CHECK(opts->pc == PYN_PC_NONE || opts->pc == PYN_PC_JACOBI, "unknown preconditioner %d", opts->pc);
   PYN_CHECK(opts->maxit > 0 || opts->fixed_iters > 0, "maxit must be positive");
   PYN_CHECK(!(c->nranks > 1 && c->detached), "detached communicator: the Krylov solve needs collectives");
-  PYN_CHECK(opts->matfree == PYN_MATFREE_OFF || opts->matfree == PYN_MATFREE_LAPLACE, "unknown matrix-free operator %d", opts->matfree);
+  PYN_CHECK(opts->matfree >= PYN_MATFREE_OFF && opts->matfree <= PYN_MATFREE_KLE, "unknown matrix-free operator %d", opts->matfree);
   PYN_HIP(hipSetDevice(c->device));
   double* b = c->vecs[bv].d;
   double* x = c->vecs[xv].d;
@@ -938,19 +951,19 @@ extern "C" int pyn_solve(pyn_ctx* c, int mat_id, int bv, int xv, const pyn_solve
     // the shell operator must BE the assembled matrix (which keeps supplying the Jacobi diagonal and the exit check):
     // compare both products on b before iterating
     PYN_CHECK(opts->method == PYN_KSP_CG, "matrix-free operator: CG only");
-    PYN_CHECK(A.br == 1, "matrix-free Laplacian: scalar matrix expected");
-    const int64_t n1 = c->n_owned;
+    PYN_CHECK(A.br == (opts->matfree == PYN_MATFREE_KLE ? 3 : 1), "matrix-free operator: block size of the matrix does not match");
+    const int64_t n1 = c->n_owned * A.br;
     PYN_TRY(pyn_ensure_work(c, (size_t)2 * n1 * sizeof(double)));
     double *w0 = c->d_work, *w1 = c->d_work + n1;
-    PYN_TRY(pyn_halo_exchange(c, b, 1));
+    PYN_TRY(pyn_halo_exchange(c, b, A.bc));
     PYN_TRY(pyn_spmv_raw(c, A, b, w0));
-    PYN_TRY(pyn_lattice_matfree_spmv(c, b, w1, false, nullptr));
+    PYN_TRY(matfree_product(c, opts->matfree, b, w1, false, nullptr));
     waxpby_kernel<<<vgrid(n1), 256, 0, c->stream>>>(w1, 1.0, w0, -1.0, w1, n1);
     double dd = 0, aa = 0;
     PYN_TRY(dev_dot(c, w1, w1, n1, &dd));
     PYN_TRY(dev_dot(c, w0, w0, n1, &aa));
     PYN_CHECK(dd <= 1e-20 * aa, "matrix-free operator differs from the assembled matrix (relative %.3e): was the matrix "
-                                "assembled as the Laplacian with the current Dirichlet mask?", sqrt(dd / (aa > 0 ? aa : 1.0)));
+                                "assembled as this operator with the current Dirichlet mask?", sqrt(dd / (aa > 0 ? aa : 1.0)));
   }
   if (opts->method == PYN_KSP_CG) {
     // cg_variant: 0 auto (standard on one GPU, single-reduction across ranks), 1 standard, 2 single-reduction

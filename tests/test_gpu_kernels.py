@@ -1077,3 +1077,67 @@ def test_matfree_on_rank_slabs(lib, size):
             ctx.matfree_apply(vx, vy)
             assert rel_err(ctx.vec_get(vy, 1), yg[dom.rStart:dom.rEnd]) < FP_TOL
             ctx.close()
+
+
+@pytest.mark.parametrize("nelem,geom,bc", [
+    ([11, 9, 10], "uniform", "boundary"), ([11, 9, 10], "shear", "mixed"), ([11, 9, 10], "jitter", "boundary"),
+    ([5, 4, 3], "jitter", "none"), ([19, 5, 5], "shear", "none")])
+@pytest.mark.parametrize("tile", [0, 1, 2, 3])
+def test_matfree_kle_vs_oracle(lib, monkeypatch, nelem, geom, bc, tile):
+    """y = K x for the KLE stiffness without the matrix == the oracle's assembled K (per-DOF Dirichlet elimination)
+    applied to x; "mixed": different components imposed on different faces"""
+    monkeypatch.setenv("PYNAMA_MATFREE_TILE", str(tile))
+    mesh = fo.box_mesh(nelem, [0.0] * 3, [1.0, 0.8, 1.2], 2, jitter=0.2 if geom == "jitter" else 0.0)
+    if geom == "shear":
+        _shear(mesh)
+    mask = np.zeros((mesh.n_node, 3), np.uint8)
+    if bc == "boundary":
+        mask[mesh.boundary] = 1
+    elif bc == "mixed":
+        mask[mesh.borders["left"], 0] = 1
+        mask[mesh.borders["up"], 1] = 1
+        mask[mesh.borders["front"], :] = 1
+    ctx = make_ctx(lib, mesh, 2)
+    ctx.bc_set(3, mask)
+    K = ctx.mat_create(3, 3)
+    ctx.assemble_kle(1e3, 1e2, K)
+    Ks = mat_to_scipy(ctx, K, 3, 3)
+    if bc == "boundary":   # the oracle's free-slip assembly imposes the boundary nodes; other masks: the assembled K
+        assert sp_rel_err(Ks, fo.assemble_kle_freeslip(mesh, fo.Tables(2, 3))["K"]) < FP_TOL
+    x = np.random.default_rng(6).standard_normal(mesh.n_node * 3)
+    vx, vy = ctx.vec_create(3), ctx.vec_create(3)
+    ctx.vec_set(vx, x)
+    with pytest.raises(lib.PynamaHipError, match="pyn_matfree_kle_set first"):
+        ctx.matfree_apply(vx, vy, op=lib.MATFREE_KLE)
+    ctx.matfree_kle_set(1e3, 1e2)
+    ctx.matfree_apply(vx, vy, op=lib.MATFREE_KLE)
+    assert rel_err(ctx.vec_get(vy, 3), Ks @ x) < FP_TOL
+    ctx.close()
+
+
+@pytest.mark.parametrize("geom", ["uniform", "jitter"])
+def test_matfree_kle_cg_equals_assembled_cg(lib, geom):
+    """the reference's solveKLE system (uniform-flow boundary data) solved with the matrix-free K: same iterates"""
+    mesh = fo.box_mesh([10, 9, 8], [0.0] * 3, [1.0] * 3, 2, jitter=0.2 if geom == "jitter" else 0.0)
+    ctx = make_ctx(lib, mesh, 2, bc_ndof=3, bc_nodes=mesh.boundary)
+    K, Krhs = ctx.mat_create(3, 3), ctx.mat_create(3, 3)
+    ctx.assemble_kle(1e3, 1e2, K, Krhs)
+    vel = np.zeros((mesh.n_node, 3))
+    vel[mesh.boundary] = [1.0, 0.5, -0.25]
+    vv, vb, vx = ctx.vec_create(3), ctx.vec_create(3), ctx.vec_create(3)
+    ctx.vec_set(vv, vel.ravel())
+    ctx.spmv(Krhs, vv, vb)
+    kw = dict(rtol=1e-10, norm_type=lib.NORM_UNPRECONDITIONED)
+    i0 = ctx.solve(K, vb, vx, **kw)
+    x0 = ctx.vec_get(vx, 3)
+    ctx.matfree_kle_set(1e3, 1e2)
+    i1 = ctx.solve(K, vb, vx, matfree=lib.MATFREE_KLE, **kw)
+    x1 = ctx.vec_get(vx, 3)
+    # penalty-weighted system (cond ~ 1e3 x Laplacian): the products differ in summation order, the stopping iteration by 2-3
+    assert i0.reason == 2 and i1.reason == 2 and abs(i0.iters - i1.iters) <= max(3, i0.iters // 50)
+    assert i1.true_resid < 2e-10 and rel_err(x1, x0) < 1e-8
+    assert np.abs(x1.reshape(-1, 3) - [1.0, 0.5, -0.25]).max() < 1e-7       # uniform flow is the exact solution
+    ctx.matfree_kle_set(1e3, 5e1)                                            # not the assembled operator
+    with pytest.raises(lib.PynamaHipError, match="differs from the assembled matrix"):
+        ctx.solve(K, vb, vx, matfree=lib.MATFREE_KLE, **kw)
+    ctx.close()

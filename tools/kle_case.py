@@ -40,6 +40,19 @@ print("spmv 3x3 ms", ctx.timers()["spmv_ms"])
 info = ctx.solve(K, vr, vx, fixed_iters=iters, profile=1)
 print("cg ms/iter", info.solve_ms / info.iters, "spmv_ms", info.spmv_ms)
 info = ctx.solve(K, vr, vx, rtol=1e-10, norm_type=_lib.NORM_UNPRECONDITIONED, maxit=20000)
+ctx.matfree_kle_set(1e3, 1e2)
+vy = ctx.vec_create(3)
+for _ in range(3):
+    ctx.matfree_apply(vr, vy, op=_lib.MATFREE_KLE)
+print("matrix-free K product ms", ctx.timers()["spmv_ms"])
+ctx.spmv(K, vr, vv)
+y0, y1 = ctx.vec_get(vv, 3), ctx.vec_get(vy, 3)
+print("  vs assembled K product", ctx.timers()["spmv_ms"], "ms, max rel diff", np.abs(y0 - y1).max() / np.abs(y0).max())
+for _ in range(2):
+    im = ctx.solve(K, vr, vy, fixed_iters=iters, profile=1, matfree=_lib.MATFREE_KLE)
+print("matrix-free cg ms/iter", im.solve_ms / im.iters, "product ms", im.spmv_ms)
+im = ctx.solve(K, vr, vy, rtol=1e-10, norm_type=_lib.NORM_UNPRECONDITIONED, maxit=20000, matfree=_lib.MATFREE_KLE)
+print("matrix-free solve its", im.iters, "reason", im.reason, "true_resid (assembled K)", im.true_resid, "ms", im.solve_ms)
 x = ctx.vec_get(vx, 3).reshape(-1, 3)
 print("solve its", info.iters, "reason", info.reason, "true_resid", info.true_resid, "ms", info.solve_ms,
       "max err vs exact", np.abs(x - [1.0, 0.0, 0.0]).max())
