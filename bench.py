@@ -168,6 +168,7 @@ def main():
     mfree = None
     if not args.no_matfree:
         try:
+            ctx.matfree_set(_lib.MATFREE_LAPLACE)
             for _ in range(2):
                 mi = ctx.solve(A, vb, vx, method=_lib.KSP_CG, pc=_lib.PC_JACOBI, fixed_iters=args.cg_iters,
                                norm_type=_lib.NORM_UNPRECONDITIONED, profile=1, matfree=_lib.MATFREE_LAPLACE)

@@ -200,16 +200,18 @@ int pyn_elem_operator_local(pyn_ctx* ctx, int rule, int br, int bc, int nterms, 
  * y = A x with halo exchange of x over RCCL when nranks > 1 (PETSc MatMult,
  * base_problem.py:481 "Rw*vort + Krhs*vel"). */
 int pyn_spmv(pyn_ctx* ctx, int mat_id, int x_vec, int y_vec);
-/* y = A x WITHOUT an assembled matrix (PETSc analogue: a MATSHELL operator): A is the scalar Laplacian that
- * pyn_assemble_scalar(PYN_FORM_LAPLACE) would build from the mesh, the full-rule tables and the current Dirichlet mask
- * (imposed rows identity, imposed columns eliminated, base_problem.py:531-549).  Element matrices are recomputed on
- * the fly (Spectral.getElemKLEMatrices' scalar block, spectral.py:120-131) and applied per element; needs a Q1
- * hexahedral mesh with structured topology (pyn_mesh_topology == lattice), errors otherwise. */
+/* Matrix-free operators: y = A x WITHOUT an assembled matrix (PETSc analogue: a MATSHELL).  Element matrices are recomputed
+ * on the fly (Spectral.getElemKLEMatrices, spectral.py:120-153) and applied per element; needs a Q1 hexahedral mesh with
+ * structured topology (pyn_mesh_topology == lattice), errors otherwise.
+ *   PYN_MATFREE_LAPLACE  the scalar Laplacian pyn_assemble_scalar(PYN_FORM_LAPLACE) builds (1 DOF per node)
+ *   PYN_MATFREE_KLE      the K of pyn_assemble_kle (3 DOFs per node); alpha_d / alpha_w are that call's penalty weights
+ *                        (1e3 / 1e2 in the reference, spectral.py:152-153)
+ * pyn_matfree_set defines the operator from the mesh, the element tables and a SNAPSHOT of the current Dirichlet mask
+ * (imposed rows identity, imposed columns eliminated, base_problem.py:531-549): call it next to the assembly it mirrors;
+ * later pyn_bc_set calls do not change it. */
 enum { PYN_MATFREE_OFF = 0, PYN_MATFREE_LAPLACE = 1, PYN_MATFREE_KLE = 2 };
+int pyn_matfree_set(pyn_ctx* ctx, int op, double alpha_d, double alpha_w);
 int pyn_matfree_apply(pyn_ctx* ctx, int op, int x_vec, int y_vec);
-/* PYN_MATFREE_KLE: A is the K of pyn_assemble_kle (3 DOFs per node, per-DOF Dirichlet mask; spectral.py:131,152-153);
- * alpha_d / alpha_w are the penalty weights of that call (1e3 / 1e2 in the reference, spectral.py:152-153). */
-int pyn_matfree_kle_set(pyn_ctx* ctx, double alpha_d, double alpha_w);
 typedef struct pyn_solve_opts {
   int method;        /* PYN_KSP_*  */
   int pc;            /* PYN_PC_*   */

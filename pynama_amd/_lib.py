@@ -96,7 +96,7 @@ SIGNATURES = {
     "pyn_elem_operator_local": [_P, _I, _I, _I, _I, _pi32, _pf64, _pf64, _pf64],
     "pyn_spmv": [_P, _I, _I, _I],
     "pyn_matfree_apply": [_P, _I, _I, _I],
-    "pyn_matfree_kle_set": [_P, _D, _D],
+    "pyn_matfree_set": [_P, _I, _D, _D],
     "pyn_solve": [_P, _I, _I, _I, C.POINTER(SolveOpts), C.POINTER(SolveInfo)],
     "pyn_timers_get": [_P, _pf64, _I],
 }
@@ -387,8 +387,12 @@ class Context:
         hex meshes)"""
         _check(self.lib.pyn_matfree_apply(self.h, op, x, y))
 
+    def matfree_set(self, op=1, alpha_d=0.0, alpha_w=0.0):
+        """define the matrix-free operator from the mesh, the tables and a snapshot of the CURRENT Dirichlet mask"""
+        _check(self.lib.pyn_matfree_set(self.h, op, alpha_d, alpha_w))
+
     def matfree_kle_set(self, alpha_d, alpha_w):
-        _check(self.lib.pyn_matfree_kle_set(self.h, alpha_d, alpha_w))
+        self.matfree_set(MATFREE_KLE, alpha_d, alpha_w)
 
     def solve(self, mid, b, x, method=KSP_CG, pc=PC_JACOBI, rtol=1e-5, atol=1e-50, dtol=1e5, maxit=10000,
               restart=30, norm_type=NORM_PRECONDITIONED, fixed_iters=0, profile=0, cg_variant=0, gmres_orthog=0,

@@ -1325,10 +1325,11 @@ bool pyn_lattice_matfree_supported(const pyn_ctx* c) {
 int pyn_lattice_matfree_spmv(pyn_ctx* c, const double* x, double* y, bool dot, int* grid_out) {
   PYN_CHECK(pyn_lattice_matfree_supported(c), "matrix-free operator: needs a Q1 hexahedral mesh with structured topology and the "
                                                "full-rule tables");
-  PYN_CHECK(!c->d_bcmask || c->bc_ndof == 1, "matrix-free Laplacian: the Dirichlet mask must have one DOF per node");
+  PYN_CHECK(c->mf_set[PYN_MATFREE_LAPLACE], "matrix-free Laplacian: pyn_matfree_set first");
   LatArgs T;
   int mesh_aff = 0;
   PYN_TRY(lat_fill_args(c, T, nullptr, nullptr, &mesh_aff));
+  T.bcmask = c->mf_mask[PYN_MATFREE_LAPLACE];
   const bool affine = mesh_aff == 1 && T.q.aff != nullptr && c->aff_standard;
   const char* tl = getenv("PYNAMA_MATFREE_TILE");
   switch (tl ? atoi(tl) : 0) {
@@ -1371,15 +1372,15 @@ static int launch_matfree_kle(pyn_ctx* c, KleLatArgs& K, bool affine, const doub
   return PYN_OK;
 }
 
-// y = K x with K = the KLE stiffness under the current per-DOF Dirichlet mask (pyn_matfree_kle_set supplied alpha_d, alpha_w)
+// y = K x with K = the KLE stiffness under the current per-DOF Dirichlet mask (pyn_matfree_set supplied alpha_d, alpha_w and took the mask)
 int pyn_lattice_matfree_kle_spmv(pyn_ctx* c, const double* x, double* y, bool dot, int* grid_out) {
   PYN_CHECK(pyn_lattice_matfree_supported(c) && c->quad[1].ngp == 1,
             "matrix-free operator: needs a Q1 hexahedral mesh with structured topology and the full- and reduced-rule tables");
-  PYN_CHECK(c->mf_kle_set, "matrix-free KLE operator: pyn_matfree_kle_set first");
-  PYN_CHECK(!c->d_bcmask || c->bc_ndof == 3, "matrix-free KLE operator: the Dirichlet mask must have three DOFs per node");
+  PYN_CHECK(c->mf_set[PYN_MATFREE_KLE], "matrix-free KLE operator: pyn_matfree_set first");
   KleLatArgs K;
   int mesh_aff = 0;
   PYN_TRY(lat_fill_args(c, K.L, nullptr, nullptr, &mesh_aff));
+  K.L.bcmask = c->mf_mask[PYN_MATFREE_KLE];
   K.alpha_d = c->mf_alpha_d;
   K.alpha_w = c->mf_alpha_w;
   K.wr = c->quad[1].w;

@@ -95,6 +95,7 @@ extern "C" int pyn_ctx_destroy(pyn_ctx* c) {
   }
   pyn_sell_drop_structure(c);
   for (auto& v : c->vecs) (void)hipFree(v.d);
+  for (int k = 0; k < 3; ++k) (void)hipFree(c->mf_mask[k]);
   for (auto& q : c->quad) free_quad(q);
   (void)hipFree(c->d_conn);
   (void)hipFree(c->d_xyz);
@@ -280,6 +281,11 @@ extern "C" int pyn_mesh_set(pyn_ctx* c, int dim, int nn, int64_t n_elem, int64_t
   PYN_TRY(dev_upload(&c->d_xyz, xyz, (size_t)n_node * dim, c->stream));
   PYN_HIP(hipStreamSynchronize(c->stream));
   c->mesh_affine = -1;
+  for (int k = 0; k < 3; ++k) {   // matrix-free operators belong to the mesh
+    (void)hipFree(c->mf_mask[k]);
+    c->mf_mask[k] = nullptr;
+    c->mf_set[k] = false;
+  }
   PYN_TRY(pyn_lattice_detect(c, conn));
   // graph + matrices depend on the mesh
   (void)hipFree(c->d_rowptr);

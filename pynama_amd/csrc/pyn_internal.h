@@ -155,7 +155,10 @@ struct pyn_ctx {
 
   // boundary condition
   int bc_ndof = 0;
-  bool mf_kle_set = false;     // matrix-free KLE operator parameters (pyn_matfree_kle_set)
+  // matrix-free operators (pyn_matfree_set), slot = PYN_MATFREE_*: the Dirichlet mask is SNAPSHOT at set time, so later
+  // pyn_bc_set calls (operator assembly, other matrices) do not change the operator
+  bool mf_set[3] = {false, false, false};
+  uint8_t* mf_mask[3] = {nullptr, nullptr, nullptr};   // null = no imposed DOF
   double mf_alpha_d = 0.0, mf_alpha_w = 0.0;
   int64_t bc_stamp = 0;  // bumped by every pyn_bc_set
   uint8_t* d_bcmask = nullptr;

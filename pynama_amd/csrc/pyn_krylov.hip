@@ -501,11 +501,28 @@ static int matfree_product(pyn_ctx* c, int op, const double* x, double* y, bool 
   return op == PYN_MATFREE_KLE ? pyn_lattice_matfree_kle_spmv(c, x, y, dot, grid_out) : pyn_lattice_matfree_spmv(c, x, y, dot, grid_out);
 }
 
-extern "C" int pyn_matfree_kle_set(pyn_ctx* c, double alpha_d, double alpha_w) {
+extern "C" int pyn_matfree_set(pyn_ctx* c, int op, double alpha_d, double alpha_w) {
   PYN_CHECK(c, "NULL context");
-  c->mf_alpha_d = alpha_d;
-  c->mf_alpha_w = alpha_w;
-  c->mf_kle_set = true;
+  PYN_CHECK(op == PYN_MATFREE_LAPLACE || op == PYN_MATFREE_KLE, "unknown matrix-free operator %d", op);
+  PYN_CHECK(pyn_lattice_matfree_supported(c), "matrix-free operator: needs a Q1 hexahedral mesh with structured topology and the "
+                                               "full-rule tables");
+  const int bs = op == PYN_MATFREE_KLE ? 3 : 1;
+  PYN_CHECK(!c->d_bcmask || c->bc_ndof == bs, "matrix-free operator %d: the current Dirichlet mask must have %d DOF(s) per node", op, bs);
+  PYN_HIP(hipSetDevice(c->device));
+  (void)hipFree(c->mf_mask[op]);
+  c->mf_mask[op] = nullptr;
+  c->mf_set[op] = false;
+  if (c->d_bcmask) {
+    const size_t nb = (size_t)c->n_node * bs;
+    PYN_HIP(hipMalloc((void**)&c->mf_mask[op], nb));
+    PYN_HIP(hipMemcpyAsync(c->mf_mask[op], c->d_bcmask, nb, hipMemcpyDeviceToDevice, c->stream));
+    PYN_HIP(hipStreamSynchronize(c->stream));
+  }
+  if (op == PYN_MATFREE_KLE) {
+    c->mf_alpha_d = alpha_d;
+    c->mf_alpha_w = alpha_w;
+  }
+  c->mf_set[op] = true;
   return PYN_OK;
 }
 

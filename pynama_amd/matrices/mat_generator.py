@@ -159,6 +159,11 @@ class Mat:
         # (the library picks the kernel: plan-free on lattices of parallelepipeds, 3x3x3-node patch plans otherwise)
         self.ctx.assemble_kle(alpha_d, alpha_w, self.K.id, self.Krhs.id, self.Rw.id,
                               self.Rd.id if with_rd else -1, variant)
+        # K also exists in matrix-free form on structured Q1 hex meshes (KspSolver -pynama_mat_free)
+        self.K.matfree = None
+        if self.dim == 3 and elem.nnode == 8 and self.ctx.mesh_topology()[0] == "lattice":
+            self.ctx.matfree_set(_lib.MATFREE_KLE, alpha_d, alpha_w)      # snapshot of THIS assembly's Dirichlet mask
+            self.K.matfree = _lib.MATFREE_KLE
 
     def createNonZeroIndex(self, d_nnz, o_nnz, dim1, dim2):
         di_nnz = [x * dim1 for x in d_nnz for d in range(dim2)]

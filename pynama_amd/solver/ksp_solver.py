@@ -7,6 +7,9 @@ Mirrors ``src/solver/ksp_solver.py:6-19`` (``KspSolver(KSP)``: ``createSolver(ma
 -ksp_max_it -ksp_gmres_restart -ksp_norm_type preconditioned|unpreconditioned|natural
 -ksp_gmres_modifiedgramschmidt -ksp_gmres_cgs_refinement_type refine_never|refine_ifneeded|refine_always``
 (GMRES orthogonalisation; default as in PETSc: classical Gram-Schmidt without refinement).
+``-pynama_mat_free`` (not a PETSc name; PETSc's analogue is KSPSetOperators(Amat = MATSHELL, Pmat = assembled)): CG multiplies
+with the matrix-free form of the operator when the matrix carries one (``Mat.K`` on structured Q1 hex meshes) -- the
+assembled matrix then only supplies the Jacobi diagonal and the exit check; the library verifies that both agree.
 
 The reference's hard-wired default is ``preonly`` + ``lu`` (:13-16).  There is no sparse direct
 solver on the device path: that combination is served by Jacobi-PCG driven to round-off
@@ -31,6 +34,7 @@ class KspSolver(object):
         self.restart = 30
         self.gmres_orthog = 1            # KSPGMRES default: classical Gram-Schmidt, refine_never
         self.norm_type = "preconditioned"
+        self.mat_free = False
         self.info = None
 
     # -- PETSc-style setters the reference (or its users) may call
@@ -60,6 +64,7 @@ class KspSolver(object):
         self.max_it = o.getInt('ksp_max_it', self.max_it)
         self.restart = o.getInt('ksp_gmres_restart', self.restart)
         self.norm_type = o.getString('ksp_norm_type', self.norm_type)
+        self.mat_free = o.hasName('pynama_mat_free') and str(o.getString('pynama_mat_free', '1')).lower() not in ('0', 'false', 'no')
         if o.hasName('ksp_gmres_modifiedgramschmidt'):
             self.gmres_orthog = 2
         else:
@@ -92,16 +97,25 @@ class KspSolver(object):
     def solve(self, b, x):
         A = self.mat
         ctx = A.ctx
+        mf = _lib.MATFREE_OFF
+        if self.mat_free:
+            tag = getattr(A, 'matfree', None)          # set by the assembly that built the matrix (Mat.assembleKLE)
+            if tag is None:
+                raise ValueError("-pynama_mat_free: this operator has no matrix-free form (structured Q1 hex meshes only)")
+            if self.ksp_type == 'gmres':
+                raise ValueError("-pynama_mat_free: CG only")
+            mf = tag
         if self.ksp_type == 'preonly':
             self.logger and self.logger.info("preonly/lu requested: device path uses Jacobi-PCG to round-off")
             info = ctx.solve(A.id, b.id, x.id, method=_lib.KSP_CG, pc=_lib.PC_JACOBI, rtol=1e-14, atol=1e-300,
-                             dtol=1e8, maxit=200000, norm_type=_lib.NORM_UNPRECONDITIONED)
+                             dtol=1e8, maxit=200000, norm_type=_lib.NORM_UNPRECONDITIONED, matfree=mf)
         else:
             info = ctx.solve(A.id, b.id, x.id,
                              method=_lib.KSP_CG if self.ksp_type == 'cg' else _lib.KSP_GMRES,
                              pc=_lib.PC_JACOBI if self.pc_type == 'jacobi' else _lib.PC_NONE,
                              rtol=self.rtol, atol=self.atol, dtol=self.divtol, maxit=self.max_it,
-                             restart=self.restart, norm_type=_NORMS[self.norm_type], gmres_orthog=self.gmres_orthog)
+                             restart=self.restart, norm_type=_NORMS[self.norm_type], gmres_orthog=self.gmres_orthog,
+                             matfree=mf)
         self.info = info
         return info
 

@@ -64,6 +64,35 @@ def test_solveKLE_with_cg_options():
         Options([])
 
 
+@pytest.mark.parametrize("jitter", [0.0, 0.2])
+def test_solveKLE_matrix_free_option(jitter):
+    """-pynama_mat_free: FreeSlip.solveKLE with the matrix-free K (the assembled K keeps the Jacobi diagonal and the exit
+    check) gives the assembled-matrix answer; 2-D / high-order problems, which have no matrix-free form, refuse it"""
+    from common.options import Options
+    base = ["-ksp_type", "cg", "-pc_type", "jacobi", "-ksp_rtol", "1e-11", "-ksp_norm_type", "unpreconditioned"]
+    try:
+        Options(base)
+        kw = dict(lower=[0, 0, 0], upper=[1, 1, 1], nelem=[9, 8, 7], ngl=2, jitter=jitter)
+        fem = setFemProblem('uniform', **kw)
+        exactVel, exactVort = fem.generateExactVecs()
+        fem.solveKLE(time=0.0, vort=exactVort)
+        v0, it0 = fem.vel.getArray().copy(), fem.solver.getIterationNumber()
+        Options(base + ["-pynama_mat_free"])
+        fem = setFemProblem('uniform', **kw)
+        assert fem.solver.mat_free and fem.mat.K.matfree is not None
+        exactVel, exactVort = fem.generateExactVecs()
+        fem.solveKLE(time=0.0, vort=exactVort)
+        assert fem.solver.getConvergedReason() == 2 and abs(fem.solver.getIterationNumber() - it0) <= 3
+        assert fem.solver.info.true_resid <= 1e-10
+        assert np.abs(fem.vel.getArray() - v0).max() < 1e-9
+        assert (exactVel - fem.vel).norm(norm_type=3) < 1e-8
+        fem2d = setFemProblem('uniform')
+        with pytest.raises(ValueError, match="no matrix-free form"):
+            fem2d.solveKLE(time=0.0, vort=fem2d.generateExactVecs()[1])
+    finally:
+        Options([])
+
+
 def test_VtensV_eval():                            # test_solver.py:66-86
     fem = setFemProblem('uniform', lower=[0, 0], upper=[1, 1], nelem=[2, 2], ngl=2)
     from pynama_amd.vectors import Vec

@@ -1001,6 +1001,10 @@ def test_matfree_laplace_vs_oracle(lib, monkeypatch, nelem, geom, bc, tile):
     x = np.random.default_rng(5).standard_normal(mesh.n_node)
     vx, vy = ctx.vec_create(1), ctx.vec_create(1)
     ctx.vec_set(vx, x)
+    with pytest.raises(lib.PynamaHipError, match="pyn_matfree_set first"):
+        ctx.matfree_apply(vx, vy)
+    ctx.matfree_set(lib.MATFREE_LAPLACE)
+    ctx.bc_set(1, None)                       # the operator keeps the mask it was defined with
     ctx.matfree_apply(vx, vy)
     assert rel_err(ctx.vec_get(vy, 1), ref["A"] @ x) < FP_TOL
     ctx.close()
@@ -1018,6 +1022,7 @@ def test_matfree_cg_equals_assembled_cg(lib, geom, variant):
     A, M = ctx.mat_create(1, 1), ctx.mat_create(1, 1)
     ctx.assemble_scalar(lib.FORM_LAPLACE, A)
     ctx.assemble_scalar(lib.FORM_MASS_NODAL, M)
+    ctx.matfree_set(lib.MATFREE_LAPLACE)
     b = np.random.default_rng(9).standard_normal(mesh.n_node)
     b[mesh.boundary] = 0.0
     vb, vx = ctx.vec_create(1), ctx.vec_create(1)
@@ -1044,7 +1049,7 @@ def test_matfree_needs_structured_topology(lib):
     ctx = make_ctx(lib, mesh, 2)
     vx, vy = ctx.vec_create(1), ctx.vec_create(1)
     with pytest.raises(lib.PynamaHipError, match="structured topology"):
-        ctx.matfree_apply(vx, vy)
+        ctx.matfree_set(lib.MATFREE_LAPLACE)
     ctx.close()
 
 
@@ -1074,6 +1079,7 @@ def test_matfree_on_rank_slabs(lib, size):
             cols = dom._local2global(np.arange(dom.nLocal))
             vx, vy = ctx.vec_create(1), ctx.vec_create(1)
             ctx.vec_set_local(vx, xg[cols])
+            ctx.matfree_set(lib.MATFREE_LAPLACE)
             ctx.matfree_apply(vx, vy)
             assert rel_err(ctx.vec_get(vy, 1), yg[dom.rStart:dom.rEnd]) < FP_TOL
             ctx.close()
@@ -1107,7 +1113,7 @@ def test_matfree_kle_vs_oracle(lib, monkeypatch, nelem, geom, bc, tile):
     x = np.random.default_rng(6).standard_normal(mesh.n_node * 3)
     vx, vy = ctx.vec_create(3), ctx.vec_create(3)
     ctx.vec_set(vx, x)
-    with pytest.raises(lib.PynamaHipError, match="pyn_matfree_kle_set first"):
+    with pytest.raises(lib.PynamaHipError, match="pyn_matfree_set first"):
         ctx.matfree_apply(vx, vy, op=lib.MATFREE_KLE)
     ctx.matfree_kle_set(1e3, 1e2)
     ctx.matfree_apply(vx, vy, op=lib.MATFREE_KLE)

@@ -24,6 +24,7 @@ ctx.bc_set(1, bm)
 n_rows, nnz = ctx.csr_symbolic()
 A = ctx.mat_create(1, 1)
 ctx.assemble_scalar(_lib.FORM_LAPLACE, A)
+ctx.matfree_set(_lib.MATFREE_LAPLACE)
 f = np.random.default_rng(0).standard_normal(n_rows) / n ** 3
 f[bm != 0] = 0
 vb, vx, vy, vz = (ctx.vec_create(1) for _ in range(4))
