@@ -174,7 +174,7 @@ def main():
                                norm_type=_lib.NORM_UNPRECONDITIONED, profile=1, matfree=_lib.MATFREE_LAPLACE)
             mf_red = ctx.allreduce([mi.solve_ms, mi.spmv_ms], op="max") if world.size > 1 else [mi.solve_ms, mi.spmv_ms]
             mf_bytes = 41.0 * n_node_global / world.size        # x 8 + y 8 + xyz 24 + Dirichlet flag 1 per row
-            mfree = {"kernel": "lattice_matfree_laplace_kernel (element matrices recomputed per product)",
+            mfree = {"kernel": "lattice_matfree_laplace_march_kernel (element products recomputed from the node coordinates, no matrix values)",
                      "cg_iters_per_s": args.cg_iters / (float(mf_red[0]) * 1e-3), "product_ms": float(mf_red[1]),
                      "bytes_per_launch": mf_bytes, "achieved_GBs": mf_bytes / (float(mf_red[1]) * 1e-3) / 1e9,
                      "bound": "FP64 VALU / latency (not HBM)"}

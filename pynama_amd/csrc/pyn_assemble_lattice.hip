@@ -285,18 +285,8 @@ __device__ __forceinline__ bool lat_tile_plain(const LatArgs& T, int x0, int y0,
 // and store latencies.  lat_affine_L: the 36 upper-triangle entries of L_e for the element whose lowest corner is
 // node n00 of plane gl (shared with the matrix-free operator below).
 // inverse Jacobian and determinant of the parallelepiped element whose lowest corner is node n00 of plane gl
-__device__ __forceinline__ double lat_affine_geom(const LatArgs& T, const double* __restrict__ S, int n00, int gl, double (&Ji)[3][3]) {
-  const int nx = T.nx;
-  const double* q0 = T.xyz + (int64_t)(lat_plane(T, gl) + n00) * 3;
-  const double* qz = T.xyz + (int64_t)(lat_plane(T, gl + 1) + n00) * 3;
-  double E[3][3];  // edge vectors along the lattice x, y, z directions
-#pragma unroll
-  for (int x = 0; x < 3; ++x) {
-    const double o = q0[x];
-    E[0][x] = q0[3 + x] - o;
-    E[1][x] = q0[3 * nx + x] - o;
-    E[2][x] = qz[x] - o;
-  }
+// J = S.E from the three edge vectors of a parallelepiped, its inverse and determinant
+__device__ __forceinline__ double lat_affine_inv(const double* __restrict__ S, const double (&E)[3][3], double (&Ji)[3][3]) {
   double J[3][3];
 #pragma unroll
   for (int d = 0; d < 3; ++d)
@@ -317,6 +307,21 @@ __device__ __forceinline__ double lat_affine_geom(const LatArgs& T, const double
   Ji[2][1] = (J[0][1] * J[2][0] - J[0][0] * J[2][1]) * r;
   Ji[2][2] = (J[0][0] * J[1][1] - J[0][1] * J[1][0]) * r;
   return det;
+}
+
+__device__ __forceinline__ double lat_affine_geom(const LatArgs& T, const double* __restrict__ S, int n00, int gl, double (&Ji)[3][3]) {
+  const int nx = T.nx;
+  const double* q0 = T.xyz + (int64_t)(lat_plane(T, gl) + n00) * 3;
+  const double* qz = T.xyz + (int64_t)(lat_plane(T, gl + 1) + n00) * 3;
+  double E[3][3];  // edge vectors along the lattice x, y, z directions
+#pragma unroll
+  for (int x = 0; x < 3; ++x) {
+    const double o = q0[x];
+    E[0][x] = q0[3 + x] - o;
+    E[1][x] = q0[3 * nx + x] - o;
+    E[2][x] = qz[x] - o;
+  }
+  return lat_affine_inv(S, E, Ji);
 }
 
 __device__ __forceinline__ void lat_affine_L_from(const double (&Ji)[3][3], const double det, double (&L)[36]) {
@@ -441,13 +446,93 @@ __global__ void __launch_bounds__(TILE_THREADS, AFF ? 3 : 2) assemble_q1_hex_lat
     lat_store<TX, TY, TZ>(T, x0, y0, acc, rlo, zrd, nbc, tid, TILE_THREADS);
 }
 
+// y_e = L_e x_e for a parallelepiped WITHOUT forming L_e: in the Haar basis of each axis ((v0, v1) -> (s, d) = (v0 + v1,
+// v1 - v0)) the 1-D factors of the trilinear element are monomial -- mass 2/3 [[1, 1/2], [1/2, 1]] -> diag(3, 1)/3... i.e.
+// int N N -> (s, d) |-> (3 s, d)/3, int N' N' -> (0, d), int N' N -> s |-> d', its transpose d |-> s' -- so
+//   L_e = H^-1 [ diagonal from Q_xx, Q_yy, Q_zz  +  12 symmetric couplings from Q_xy, Q_xz, Q_yz ] H,   Q = detJ J^-1 J^-T:
+// 24 + 24 additions for H and H^-1, 7 products + 12 FMAs in between (~85 FP64 operations instead of ~280 for the 36
+// entries + 64 for the product).  Corner a sits at (i, j, k) = (CX, CY, CZ)[a] (checked by aff_standard).
+__device__ __forceinline__ void lat_affine_apply(const double (&Ji)[3][3], const double det, const double (&xe)[8], double (&ye)[8]) {
+  constexpr int A[2][2][2] = {{{0, 4}, {1, 7}}, {{3, 5}, {2, 6}}};   // A[i][j][k] = local node
+  const double d8 = 0.125 * det;                                        // the 1/8 of the three inverse transforms
+  const double qxx = d8 * (Ji[0][0] * Ji[0][0] + Ji[1][0] * Ji[1][0] + Ji[2][0] * Ji[2][0]);
+  const double qyy = d8 * (Ji[0][1] * Ji[0][1] + Ji[1][1] * Ji[1][1] + Ji[2][1] * Ji[2][1]);
+  const double qzz = d8 * (Ji[0][2] * Ji[0][2] + Ji[1][2] * Ji[1][2] + Ji[2][2] * Ji[2][2]);
+  const double qxy = d8 * (Ji[0][0] * Ji[0][1] + Ji[1][0] * Ji[1][1] + Ji[2][0] * Ji[2][1]);
+  const double qxz = d8 * (Ji[0][0] * Ji[0][2] + Ji[1][0] * Ji[1][2] + Ji[2][0] * Ji[2][2]);
+  const double qyz = d8 * (Ji[0][1] * Ji[0][2] + Ji[1][1] * Ji[1][2] + Ji[2][1] * Ji[2][2]);
+  double h[2][2][2], g[2][2][2];
+  // forward transform, x then y then z (index 0 = s, 1 = d)
+#pragma unroll
+  for (int j = 0; j < 2; ++j)
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+      const double v0 = xe[A[0][j][k]], v1 = xe[A[1][j][k]];
+      g[0][j][k] = v0 + v1;
+      g[1][j][k] = v1 - v0;
+    }
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+      const double v0 = g[i][0][k], v1 = g[i][1][k];
+      h[i][0][k] = v0 + v1;
+      h[i][1][k] = v1 - v0;
+    }
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const double v0 = h[i][j][0], v1 = h[i][j][1];
+      g[i][j][0] = v0 + v1;
+      g[i][j][1] = v1 - v0;
+    }
+  // Haar-domain operator (g -> h)
+  const double third = 1.0 / 3.0;
+  const double sxy = (qxx + qyy) * third, sxz = (qxx + qzz) * third, syz = (qyy + qzz) * third;
+  const double sall = (qxx + qyy + qzz) * (1.0 / 9.0);
+  const double pxy = qxy * third, pxz = qxz * third, pyz = qyz * third;
+  h[0][0][0] = 0.0;
+  h[1][0][0] = fma(qxz, g[0][0][1], fma(qxy, g[0][1][0], qxx * g[1][0][0]));
+  h[0][1][0] = fma(qyz, g[0][0][1], fma(qxy, g[1][0][0], qyy * g[0][1][0]));
+  h[0][0][1] = fma(qyz, g[0][1][0], fma(qxz, g[1][0][0], qzz * g[0][0][1]));
+  h[1][1][0] = fma(pyz, g[1][0][1], fma(pxz, g[0][1][1], sxy * g[1][1][0]));
+  h[1][0][1] = fma(pyz, g[1][1][0], fma(pxy, g[0][1][1], sxz * g[1][0][1]));
+  h[0][1][1] = fma(pxz, g[1][1][0], fma(pxy, g[1][0][1], syz * g[0][1][1]));
+  h[1][1][1] = sall * g[1][1][1];
+  // inverse transform: o0 = s' - d', o1 = s' + d' per axis (the halves are in d8)
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const double s0 = h[i][j][0], d0 = h[i][j][1];
+      g[i][j][0] = s0 - d0;
+      g[i][j][1] = s0 + d0;
+    }
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+      const double s0 = g[i][0][k], d0 = g[i][1][k];
+      h[i][0][k] = s0 - d0;
+      h[i][1][k] = s0 + d0;
+    }
+#pragma unroll
+  for (int j = 0; j < 2; ++j)
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+      const double s0 = h[0][j][k], d0 = h[1][j][k];
+      ye[A[0][j][k]] = s0 - d0;
+      ye[A[1][j][k]] = s0 + d0;
+    }
+}
+
 // ---- matrix-free operator: y = A x for the scalar Laplacian WITHOUT the assembled matrix -------------------------
 // A is the matrix pyn_assemble_scalar(LAPLACE) builds with the current Dirichlet mask (imposed rows = identity,
 // imposed columns eliminated; base_problem.py:531-549 semantics): y_i = x_i on imposed rows, else
 // y_i = sum_e sum_c L_e[a_i, c] x_c over free nodes c.  Same tile scheme as the assembly: a workgroup owns
 // TX x TY x TZ rows, loads the (TX+2)(TY+2)(TZ+2) node box of x once into LDS (imposed nodes as 0), lets one lane
-// per element form y_e = L_e x_e (parallelepipeds: the closed-form L_e of lat_affine_L, i.e. bit-identical element
-// matrices to the assembly; general geometry: c G^T (G x_e) per Gauss point, no L_e at all) and adds the rows the
+// per element form y_e = L_e x_e (parallelepipeds: lat_affine_apply, L_e never formed; general geometry: c G^T (G x_e) per Gauss point, no L_e at all) and adds the rows the
 // tile owns with ds_add_f64; every y is written once, p.Ap partials fused.  HBM traffic per row: x 8 B + y 8 B +
 // xyz 24 B + flag 1 B instead of the 27 x 8 B of matrix values the SELL kernel streams.
 template <int TX, int TY, int TZ>
@@ -551,15 +636,9 @@ __global__ void __launch_bounds__(256) lattice_matfree_laplace_kernel(LatArgs T,
 #pragma unroll
       for (int a = 0; a < 8; ++a) xe[a] = xs[((lz + CZ[a]) * MT::BY + ly + CY[a]) * MT::BX + lx + CX[a]];
       if (AFF) {
-        double L[36];
-        lat_affine_L(T, S, n00, gl, L);
-#pragma unroll
-        for (int a = 0; a < 8; ++a) {
-          double sacc = 0.0;
-#pragma unroll
-          for (int c = 0; c < 8; ++c) sacc = fma(L[tri(a, c)], xe[c], sacc);
-          ye[a] = sacc;
-        }
+        double Ji[3][3];
+        const double det = lat_affine_geom(T, S, n00, gl, Ji);
+        lat_affine_apply(Ji, det, xe, ye);
       } else {
         const int pb = lat_plane(T, gl) + n00, pt = lat_plane(T, gl + 1) + n00;
         double X[8][3];
@@ -586,6 +665,127 @@ __global__ void __launch_bounds__(256) lattice_matfree_laplace_kernel(LatArgs T,
     // ---- rows of the tile: each y written once
     for (int s = tid; s < MT::NR; s += 256) {
       const int rx = s % TX, ry = (s / TX) % TY, rz = s / (TX * TY);
+      const int x = x0 + rx, y = y0 + ry, zo = z0 + rz;
+      if (x >= nx || y >= ny || zo >= T.n_own) continue;
+      const int64_t node = lat_plane(T, T.p_own0 + zo) + y * nx + x;
+      const int bi = ((rz + 1) * MT::BY + ry + 1) * MT::BX + rx + 1;
+      const double xv = nbc[bi] ? xin[node] : xs[bi];
+      const double yv = nbc[bi] ? xv : acc[s];
+      yout[node] = yv;
+      if (DOT) dot = fma(yv, xv, dot);
+    }
+    __syncthreads();
+  }
+  if (DOT) {
+    for (int o = 32; o > 0; o >>= 1) dot += __shfl_xor(dot, o, 64);
+    if ((tid & 63) == 0) smd[tid >> 6] = dot;
+    __syncthreads();
+    if (tid == 0) part[blockIdx.x] = smd[0] + smd[1] + smd[2] + smd[3];
+  }
+}
+
+// Column-marching variant for parallelepipeds: 15 x 15 x TZ rows per tile, so the 16 x 16 element columns of the tile are
+// exactly the 256 threads; a thread walks its column upwards.  Per element: 4 LDS reads (the top face; the bottom face is
+// the previous element's top), 4 ds_add_f64 (a plane of rows is complete for this column once the element above it has been
+// added: the top contributions are carried in registers), and all x / y index work is loop-invariant.
+template <int TZ, bool DOT>
+__global__ void __launch_bounds__(256) lattice_matfree_laplace_march_kernel(LatArgs T, const double* __restrict__ xin,
+                                                                             double* __restrict__ yout, const int* __restrict__ flag,
+                                                                             double* __restrict__ part, int n_tiles) {
+  using MT = MfTile<15, 15, TZ>;
+  extern __shared__ __align__(16) double lds[];
+  __shared__ double smd[4];
+  if (flag && flag[0]) return;
+  double* xs = lds;
+  double* acc = xs + MT::NB;
+  unsigned char* nbc = reinterpret_cast<unsigned char*>(acc + MT::NR);
+  const int tid = threadIdx.x;
+  const int nx = T.nx, ny = T.ny;
+  const double* __restrict__ S = T.q.aff + 248;
+  const int lx = tid & 15, ly = tid >> 4;
+  // bottom-face corners in closure order: (0,0) (0,1) (1,1) (1,0); the top-face corner above bottom corner c is TOP[c]
+  constexpr int BXo[4] = {0, 0, 1, 1}, BYo[4] = {0, 1, 1, 0}, TOP[4] = {4, 7, 6, 5};
+  int boff[4], roff[4];
+  bool rok[4];
+#pragma unroll
+  for (int c = 0; c < 4; ++c) {
+    boff[c] = (ly + BYo[c]) * MT::BX + lx + BXo[c];
+    const int rx = lx - 1 + BXo[c], ry = ly - 1 + BYo[c];
+    rok[c] = rx >= 0 && rx < 15 && ry >= 0 && ry < 15;
+    roff[c] = ry * 15 + rx;
+  }
+  double dot = 0.0;
+  for (int tb = blockIdx.x; tb < n_tiles; tb += gridDim.x) {
+    const int b = xcd_contiguous_tile(tb, n_tiles);
+    const int bx = b % T.ntx, by = (b / T.ntx) % T.nty, bz = b / (T.ntx * T.nty);
+    const int x0 = bx * 15, y0 = by * 15, z0 = bz * TZ;
+    {   // node box: all loads of a thread issued before the first LDS write
+      constexpr int NJ = (MT::NB + 255) / 256;
+      double v[NJ];
+      unsigned char f[NJ];
+#pragma unroll
+      for (int j = 0; j < NJ; ++j) {
+        const int i = tid + 256 * j;
+        const int qx = i % MT::BX, qy = (i / MT::BX) % MT::BY, qz = i / (MT::BX * MT::BY);
+        const int x = x0 - 1 + qx, y = y0 - 1 + qy, pl = T.p_own0 + z0 - 1 + qz;
+        v[j] = 0.0;
+        f[j] = 0;
+        if (i < MT::NB && x >= 0 && x < nx && y >= 0 && y < ny && pl >= 0 && pl < T.npl) {
+          const int64_t node = lat_plane(T, pl) + y * nx + x;
+          f[j] = T.bcmask ? T.bcmask[node] : 0;
+          v[j] = xin[node];
+        }
+      }
+#pragma unroll
+      for (int j = 0; j < NJ; ++j) {
+        const int i = tid + 256 * j;
+        if (i < MT::NB) {
+          xs[i] = f[j] ? 0.0 : v[j];
+          nbc[i] = f[j];
+        }
+      }
+    }
+    for (int i = tid; i < MT::NR; i += 256) acc[i] = 0.0;
+    __syncthreads();
+    {
+      const int gx = x0 - 1 + lx, gy = y0 - 1 + ly;
+      const bool col_ok = gx >= 0 && gx < nx - 1 && gy >= 0 && gy < ny - 1;
+      const int n00 = gy * nx + gx;
+      double xb[4], carry[4] = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+      for (int c = 0; c < 4; ++c) xb[c] = xs[boff[c]];
+#pragma nounroll
+      for (int lz = 0; lz <= TZ; ++lz) {
+        const int gl = T.p_own0 + z0 - 1 + lz;
+        double xe[8], ye[8];
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+          xe[c] = xb[c];
+          xe[TOP[c]] = xs[(lz + 1) * (MT::BX * MT::BY) + boff[c]];
+        }
+        if (col_ok && gl >= 0 && gl < T.npl - 1 && T.ablate != 1) {
+          double Ji[3][3];
+          const double det = lat_affine_geom(T, S, n00, gl, Ji);
+          lat_affine_apply(Ji, det, xe, ye);
+        } else {
+#pragma unroll
+          for (int a = 0; a < 8; ++a) ye[a] = 0.0;
+        }
+        if (lz >= 1) {   // row plane lz - 1 is complete for this column
+#pragma unroll
+          for (int c = 0; c < 4; ++c)
+            if (rok[c]) atomicAdd(&acc[(lz - 1) * 225 + roff[c]], carry[c] + ye[c]);
+        }
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+          carry[c] = ye[TOP[c]];
+          xb[c] = xe[TOP[c]];
+        }
+      }
+    }
+    __syncthreads();
+    for (int s = tid; s < MT::NR; s += 256) {
+      const int rx = s % 15, ry = (s / 15) % 15, rz = s / 225;
       const int x = x0 + rx, y = y0 + ry, zo = z0 + rz;
       if (x >= nx || y >= ny || zo >= T.n_own) continue;
       const int64_t node = lat_plane(T, T.p_own0 + zo) + y * nx + x;
@@ -741,18 +941,17 @@ __global__ void __launch_bounds__(256) lattice_matfree_kle_kernel(KleLatArgs K, 
         xe[a][2] = q[2];
       }
       if (AFF) {
-        double Ji[3][3], L[36];
+        double Ji[3][3];
         const double det = lat_affine_geom(T, S, n00, gl, Ji);
-        lat_affine_L_from(Ji, det, L);
 #pragma unroll
-        for (int a = 0; a < 8; ++a)
+        for (int pp = 0; pp < 3; ++pp) {   // the Laplacian on every component
+          double xc[8], yc[8];
 #pragma unroll
-          for (int pp = 0; pp < 3; ++pp) {
-            double sacc = 0.0;
+          for (int a = 0; a < 8; ++a) xc[a] = xe[a][pp];
+          lat_affine_apply(Ji, det, xc, yc);
 #pragma unroll
-            for (int c = 0; c < 8; ++c) sacc = fma(L[tri(a, c)], xe[c][pp], sacc);
-            ye[a][pp] = sacc;
-          }
+          for (int a = 0; a < 8; ++a) ye[a][pp] = yc[a];
+        }
         kle_reduced_apply(K, Ji, det, xe, ye);
       } else {
         const int pb = lat_plane(T, gl) + n00, pt = lat_plane(T, gl + 1) + n00;
@@ -1317,6 +1516,23 @@ static int launch_matfree(pyn_ctx* c, LatArgs& T, bool affine, const double* x, 
   return PYN_OK;
 }
 
+template <int TZ>
+static int launch_matfree_march(pyn_ctx* c, LatArgs& T, const double* x, double* y, bool dot, int* grid_out) {
+  using MT = MfTile<15, 15, TZ>;
+  T.ntx = (T.nx + 14) / 15;
+  T.nty = (T.ny + 14) / 15;
+  const int ntz = (T.n_own + TZ - 1) / TZ;
+  const int n_tiles = T.ntx * T.nty * ntz;
+  const int grid = std::min(n_tiles, PYN_MAX_PARTIALS);
+  if (dot)
+    lattice_matfree_laplace_march_kernel<TZ, true><<<grid, 256, MT::BYTES, c->stream>>>(T, x, y, c->d_flag, c->d_part, n_tiles);
+  else
+    lattice_matfree_laplace_march_kernel<TZ, false><<<grid, 256, MT::BYTES, c->stream>>>(T, x, y, nullptr, nullptr, n_tiles);
+  PYN_HIP(hipGetLastError());
+  if (grid_out) *grid_out = grid;
+  return PYN_OK;
+}
+
 bool pyn_lattice_matfree_supported(const pyn_ctx* c) {
   return c->lat.valid && c->dim == 3 && c->nn == 8 && c->quad[0].ngp == 8;
 }
@@ -1332,7 +1548,16 @@ int pyn_lattice_matfree_spmv(pyn_ctx* c, const double* x, double* y, bool dot, i
   T.bcmask = c->mf_mask[PYN_MATFREE_LAPLACE];
   const bool affine = mesh_aff == 1 && T.q.aff != nullptr && c->aff_standard;
   const char* tl = getenv("PYNAMA_MATFREE_TILE");
-  switch (tl ? atoi(tl) : 0) {
+  const int sel = tl ? atoi(tl) : (affine ? 6 : 0);
+  if (affine && sel >= 6) {   // parallelepipeds: column-marching kernel, 15 x 15 x TZ rows per tile
+    switch (sel) {
+      case 7: return launch_matfree_march<4>(c, T, x, y, dot, grid_out);
+      case 8: return launch_matfree_march<6>(c, T, x, y, dot, grid_out);
+      case 9: return launch_matfree_march<12>(c, T, x, y, dot, grid_out);
+      default: return launch_matfree_march<8>(c, T, x, y, dot, grid_out);
+    }
+  }
+  switch (sel) {
     case 1: PYN_TRY((launch_matfree<16, 8, 4>(c, T, affine, x, y, dot, grid_out))); break;
     case 2: PYN_TRY((launch_matfree<8, 8, 8>(c, T, affine, x, y, dot, grid_out))); break;
     case 3: PYN_TRY((launch_matfree<16, 4, 4>(c, T, affine, x, y, dot, grid_out))); break;

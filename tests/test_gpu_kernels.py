@@ -985,11 +985,11 @@ def _shear(mesh):
 @pytest.mark.parametrize("nelem,geom,bc", [
     ([20, 11, 13], "uniform", "boundary"), ([20, 11, 13], "shear", "left"), ([20, 11, 13], "jitter", "boundary"),
     ([5, 4, 3], "jitter", "none"), ([33, 9, 9], "uniform", "none"), ([17, 18, 10], "shear", "boundary")])
-@pytest.mark.parametrize("tile", [0, 1, 2, 3, 4, 5])
+@pytest.mark.parametrize("tile", [0, 1, 2, 3, 4, 5, 6, 7, 8, 9])
 def test_matfree_laplace_vs_oracle(lib, monkeypatch, nelem, geom, bc, tile):
     """y = A x without the matrix == the oracle's assembled Laplacian (Dirichlet rows identity, columns eliminated)
-    applied to x; parallelepiped (closed-form L_e) and general (per-Gauss-point apply) paths, all tile shapes,
-    tiles that overhang the lattice, masks on all / one / no face"""
+    applied to x; parallelepiped (closed-form L_e) and general (per-Gauss-point apply) paths, all tile shapes (6-9: the
+    column-marching kernel on parallelepipeds), tiles that overhang the lattice, masks on all / one / no face"""
     monkeypatch.setenv("PYNAMA_MATFREE_TILE", str(tile))
     mesh = fo.box_mesh(nelem, [0.0] * 3, [1.0, 0.8, 1.2], 2, jitter=0.2 if geom == "jitter" else 0.0)
     if geom == "shear":
