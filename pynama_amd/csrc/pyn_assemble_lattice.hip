@@ -452,22 +452,31 @@ __global__ void __launch_bounds__(TILE_THREADS, AFF ? 3 : 2) assemble_q1_hex_lat
 //   L_e = H^-1 [ diagonal from Q_xx, Q_yy, Q_zz  +  12 symmetric couplings from Q_xy, Q_xz, Q_yz ] H,   Q = detJ J^-1 J^-T:
 // 24 + 24 additions for H and H^-1, 7 products + 12 FMAs in between (~85 FP64 operations instead of ~280 for the 36
 // entries + 64 for the product).  Corner a sits at (i, j, k) = (CX, CY, CZ)[a] (checked by aff_standard).
-__device__ __forceinline__ void lat_affine_apply(const double (&Ji)[3][3], const double det, const double (&xe)[8], double (&ye)[8]) {
-  constexpr int A[2][2][2] = {{{0, 4}, {1, 7}}, {{3, 5}, {2, 6}}};   // A[i][j][k] = local node
-  const double d8 = 0.125 * det;                                        // the 1/8 of the three inverse transforms
-  const double qxx = d8 * (Ji[0][0] * Ji[0][0] + Ji[1][0] * Ji[1][0] + Ji[2][0] * Ji[2][0]);
-  const double qyy = d8 * (Ji[0][1] * Ji[0][1] + Ji[1][1] * Ji[1][1] + Ji[2][1] * Ji[2][1]);
-  const double qzz = d8 * (Ji[0][2] * Ji[0][2] + Ji[1][2] * Ji[1][2] + Ji[2][2] * Ji[2][2]);
-  const double qxy = d8 * (Ji[0][0] * Ji[0][1] + Ji[1][0] * Ji[1][1] + Ji[2][0] * Ji[2][1]);
-  const double qxz = d8 * (Ji[0][0] * Ji[0][2] + Ji[1][0] * Ji[1][2] + Ji[2][0] * Ji[2][2]);
-  const double qyz = d8 * (Ji[0][1] * Ji[0][2] + Ji[1][1] * Ji[1][2] + Ji[2][1] * Ji[2][2]);
-  double h[2][2][2], g[2][2][2];
-  // forward transform, x then y then z (index 0 = s, 1 = d)
+struct HaarQ {   // detJ J^-1 J^-T / 8 (the 1/8 of the three inverse transforms)
+  double xx, yy, zz, xy, xz, yz;
+};
+__device__ __forceinline__ HaarQ haar_q(const double (&Ji)[3][3], const double det) {
+  const double d8 = 0.125 * det;
+  HaarQ q;
+  q.xx = d8 * (Ji[0][0] * Ji[0][0] + Ji[1][0] * Ji[1][0] + Ji[2][0] * Ji[2][0]);
+  q.yy = d8 * (Ji[0][1] * Ji[0][1] + Ji[1][1] * Ji[1][1] + Ji[2][1] * Ji[2][1]);
+  q.zz = d8 * (Ji[0][2] * Ji[0][2] + Ji[1][2] * Ji[1][2] + Ji[2][2] * Ji[2][2]);
+  q.xy = d8 * (Ji[0][0] * Ji[0][1] + Ji[1][0] * Ji[1][1] + Ji[2][0] * Ji[2][1]);
+  q.xz = d8 * (Ji[0][0] * Ji[0][2] + Ji[1][0] * Ji[1][2] + Ji[2][0] * Ji[2][2]);
+  q.yz = d8 * (Ji[0][1] * Ji[0][2] + Ji[1][1] * Ji[1][2] + Ji[2][1] * Ji[2][2]);
+  return q;
+}
+constexpr int HAAR_NODE[2][2][2] = {{{0, 4}, {1, 7}}, {{3, 5}, {2, 6}}};   // [i][j][k] -> local node
+
+// forward transform x, y, z: g[a][b][c], index 0 = s, 1 = d;  stride S between the 8 inputs (1: scalar, 3: component of a vector)
+template <int S>
+__device__ __forceinline__ void haar_fwd(const double* xe, double (&g)[2][2][2]) {
+  double h[2][2][2];
 #pragma unroll
   for (int j = 0; j < 2; ++j)
 #pragma unroll
     for (int k = 0; k < 2; ++k) {
-      const double v0 = xe[A[0][j][k]], v1 = xe[A[1][j][k]];
+      const double v0 = xe[HAAR_NODE[0][j][k] * S], v1 = xe[HAAR_NODE[1][j][k] * S];
       g[0][j][k] = v0 + v1;
       g[1][j][k] = v1 - v0;
     }
@@ -487,20 +496,28 @@ __device__ __forceinline__ void lat_affine_apply(const double (&Ji)[3][3], const
       g[i][j][0] = v0 + v1;
       g[i][j][1] = v1 - v0;
     }
-  // Haar-domain operator (g -> h)
+}
+
+// the Laplacian in the Haar domain: 7 diagonal terms + 12 symmetric couplings
+__device__ __forceinline__ void haar_laplace(const HaarQ& q, const double (&g)[2][2][2], double (&h)[2][2][2]) {
   const double third = 1.0 / 3.0;
-  const double sxy = (qxx + qyy) * third, sxz = (qxx + qzz) * third, syz = (qyy + qzz) * third;
-  const double sall = (qxx + qyy + qzz) * (1.0 / 9.0);
-  const double pxy = qxy * third, pxz = qxz * third, pyz = qyz * third;
+  const double sxy = (q.xx + q.yy) * third, sxz = (q.xx + q.zz) * third, syz = (q.yy + q.zz) * third;
+  const double sall = (q.xx + q.yy + q.zz) * (1.0 / 9.0);
+  const double pxy = q.xy * third, pxz = q.xz * third, pyz = q.yz * third;
   h[0][0][0] = 0.0;
-  h[1][0][0] = fma(qxz, g[0][0][1], fma(qxy, g[0][1][0], qxx * g[1][0][0]));
-  h[0][1][0] = fma(qyz, g[0][0][1], fma(qxy, g[1][0][0], qyy * g[0][1][0]));
-  h[0][0][1] = fma(qyz, g[0][1][0], fma(qxz, g[1][0][0], qzz * g[0][0][1]));
+  h[1][0][0] = fma(q.xz, g[0][0][1], fma(q.xy, g[0][1][0], q.xx * g[1][0][0]));
+  h[0][1][0] = fma(q.yz, g[0][0][1], fma(q.xy, g[1][0][0], q.yy * g[0][1][0]));
+  h[0][0][1] = fma(q.yz, g[0][1][0], fma(q.xz, g[1][0][0], q.zz * g[0][0][1]));
   h[1][1][0] = fma(pyz, g[1][0][1], fma(pxz, g[0][1][1], sxy * g[1][1][0]));
   h[1][0][1] = fma(pyz, g[1][1][0], fma(pxy, g[0][1][1], sxz * g[1][0][1]));
   h[0][1][1] = fma(pxz, g[1][1][0], fma(pxy, g[1][0][1], syz * g[0][1][1]));
   h[1][1][1] = sall * g[1][1][1];
-  // inverse transform: o0 = s' - d', o1 = s' + d' per axis (the halves are in d8)
+}
+
+// inverse transform: o0 = s' - d', o1 = s' + d' per axis (the halves are in HaarQ); h is clobbered
+template <int S>
+__device__ __forceinline__ void haar_inv(double (&h)[2][2][2], double* ye) {
+  double g[2][2][2];
 #pragma unroll
   for (int i = 0; i < 2; ++i)
 #pragma unroll
@@ -522,9 +539,56 @@ __device__ __forceinline__ void lat_affine_apply(const double (&Ji)[3][3], const
 #pragma unroll
     for (int k = 0; k < 2; ++k) {
       const double s0 = h[0][j][k], d0 = h[1][j][k];
-      ye[A[0][j][k]] = s0 - d0;
-      ye[A[1][j][k]] = s0 + d0;
+      ye[HAAR_NODE[0][j][k] * S] = s0 - d0;
+      ye[HAAR_NODE[1][j][k] * S] = s0 + d0;
     }
+}
+
+__device__ __forceinline__ void lat_affine_apply(const double (&Ji)[3][3], const double det, const double (&xe)[8], double (&ye)[8]) {
+  const HaarQ q = haar_q(Ji, det);
+  double g[2][2][2], h[2][2][2];
+  haar_fwd<1>(xe, g);
+  haar_laplace(q, g, h);
+  haar_inv<1>(h, ye);
+}
+
+// KLE element product on a parallelepiped, everything in the Haar domain: the reduced (centroid) rule sees only the
+// first-order coefficients -- the reference gradient of component q at the centroid is g_q[d along r] / 8 -- so
+//   D = J^-1 gref (velocity gradient), W = c aw (D - D^T) + c ad tr(D) I, V = J^-T W, and h_p[d along r] += V[r][p] / 8
+// adds the div/curl penalty terms to the Laplacian of component p before the inverse transform.
+__device__ __forceinline__ void lat_affine_apply_kle(const double (&Ji)[3][3], const double det, const double cr, const double alpha_d,
+                                                     const double alpha_w, const double (&xe)[8][3], double (&ye)[8][3]) {
+  const HaarQ q = haar_q(Ji, det);
+  double g[3][2][2][2];
+#pragma unroll
+  for (int p = 0; p < 3; ++p) haar_fwd<3>(&xe[0][p], g[p]);
+  double gref[3][3];   // [r][q]
+#pragma unroll
+  for (int p = 0; p < 3; ++p) {
+    gref[0][p] = 0.125 * g[p][1][0][0];
+    gref[1][p] = 0.125 * g[p][0][1][0];
+    gref[2][p] = 0.125 * g[p][0][0][1];
+  }
+  double D[3][3];
+#pragma unroll
+  for (int d = 0; d < 3; ++d)
+#pragma unroll
+    for (int p = 0; p < 3; ++p) D[d][p] = fma(Ji[d][2], gref[2][p], fma(Ji[d][1], gref[1][p], Ji[d][0] * gref[0][p]));
+  const double caw = cr * alpha_w, tr = cr * alpha_d * (D[0][0] + D[1][1] + D[2][2]);
+  double W[3][3];
+#pragma unroll
+  for (int d = 0; d < 3; ++d)
+#pragma unroll
+    for (int p = 0; p < 3; ++p) W[d][p] = d == p ? tr : caw * (D[d][p] - D[p][d]);
+#pragma unroll
+  for (int p = 0; p < 3; ++p) {
+    double h[2][2][2];
+    haar_laplace(q, g[p], h);
+    h[1][0][0] = fma(0.125, fma(Ji[2][0], W[2][p], fma(Ji[1][0], W[1][p], Ji[0][0] * W[0][p])), h[1][0][0]);
+    h[0][1][0] = fma(0.125, fma(Ji[2][1], W[2][p], fma(Ji[1][1], W[1][p], Ji[0][1] * W[0][p])), h[0][1][0]);
+    h[0][0][1] = fma(0.125, fma(Ji[2][2], W[2][p], fma(Ji[1][2], W[1][p], Ji[0][2] * W[0][p])), h[0][0][1]);
+    haar_inv<3>(h, &ye[0][p]);
+  }
 }
 
 // ---- matrix-free operator: y = A x for the scalar Laplacian WITHOUT the assembled matrix -------------------------
@@ -943,16 +1007,7 @@ __global__ void __launch_bounds__(256) lattice_matfree_kle_kernel(KleLatArgs K, 
       if (AFF) {
         double Ji[3][3];
         const double det = lat_affine_geom(T, S, n00, gl, Ji);
-#pragma unroll
-        for (int pp = 0; pp < 3; ++pp) {   // the Laplacian on every component
-          double xc[8], yc[8];
-#pragma unroll
-          for (int a = 0; a < 8; ++a) xc[a] = xe[a][pp];
-          lat_affine_apply(Ji, det, xc, yc);
-#pragma unroll
-          for (int a = 0; a < 8; ++a) ye[a][pp] = yc[a];
-        }
-        kle_reduced_apply(K, Ji, det, xe, ye);
+        lat_affine_apply_kle(Ji, det, K.wr[0] * det, K.alpha_d, K.alpha_w, xe, ye);
       } else {
         const int pb = lat_plane(T, gl) + n00, pt = lat_plane(T, gl + 1) + n00;
         double X[8][3];
