@@ -198,8 +198,9 @@ def main():
         traffic = {}
         try:
             if world.size == 1 and n == 215:
-                with open(os.path.join(ROOT, "profiles", "r01c_pmc_traffic.json")) as fh:
-                    traffic = {k: v["hbm_bytes_per_launch"] for k, v in json.load(fh)["kernels"].items()}
+                for fn in ("r01d_pmc_traffic.json", "r01d_pmc_assembly.json"):    # the assembly entry comes from its own passes
+                    with open(os.path.join(ROOT, "profiles", fn)) as fh:
+                        traffic.update({k: v["hbm_bytes_per_launch"] for k, v in json.load(fh)["kernels"].items()})
         except (OSError, KeyError, ValueError):
             traffic = {}
         asm_kernel = ("assemble_q1_hex_lattice_kernel" if args.variant == 1 and ctx.mesh_topology()[0] == "lattice"
@@ -235,7 +236,7 @@ def main():
             "roofline_cg_iteration": {"bound": "hbm", "achieved": cg_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                       "frac": cg_gbs / HBM_PEAK_GBS, "algorithmic_bytes_per_iteration": B_cg * share},
             "check": check,
-            "matrix_free": mfree,
+            "matrix_free": dict(mfree, traffic=traffic.get("lattice_matfree_laplace_march_kernel")) if mfree and "error" not in mfree else mfree,
             "cpu_baseline": cpu,
         }
         print(json.dumps(out))

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Small driver for rocprofv3 counter passes: the bench workload, a few launches of one phase.
-usage: prof_case.py [asm|cg] [nel] [reps]"""
+usage: prof_case.py [asm|cg|kle] [nel] [reps]"""
 import os
 import sys
 
@@ -38,4 +38,24 @@ if what == "cg":
     ctx.vec_set(vb, b)
     info = ctx.solve(A, vb, vx, fixed_iters=reps * 10, profile=1, cg_variant=int(os.environ.get('PYNAMA_CG_VARIANT', '0')))
     print("cg ms/iter", info.solve_ms / info.iters, "spmv_ms", info.spmv_ms)
+    if os.environ.get("PYNAMA_MATFREE", "1") != "0" and ctx.mesh_topology()[0] == "lattice":
+        ctx.matfree_set(_lib.MATFREE_LAPLACE)
+        info = ctx.solve(A, vb, vx, fixed_iters=reps * 10, profile=1, matfree=_lib.MATFREE_LAPLACE)
+        print("matrix-free cg ms/iter", info.solve_ms / info.iters, "product_ms", info.spmv_ms)
+if what == "kle":     # C3: 3 DOFs per node, assembled block SpMV and the matrix-free K product
+    mask = np.repeat(bm[:, None], 3, axis=1)
+    ctx.bc_set(3, mask)
+    K, Krhs, Rw = ctx.mat_create(3, 3), ctx.mat_create(3, 3), ctx.mat_create(3, 3)
+    for _ in range(reps):
+        ctx.assemble_kle(1e3, 1e2, K, Krhs, Rw, -1)
+        print("assemble_kle_ms", ctx.timers()["assemble_ms"])
+    ctx.matfree_set(_lib.MATFREE_KLE, 1e3, 1e2)
+    vel = np.zeros((dom.nOwned, 3))
+    vel[bm != 0] = [1.0, 0.0, 0.0]
+    vv, vr, vx = ctx.vec_create(3), ctx.vec_create(3), ctx.vec_create(3)
+    ctx.vec_set(vv, vel.ravel())
+    ctx.spmv(Krhs, vv, vr)
+    for mf in (0, _lib.MATFREE_KLE):
+        info = ctx.solve(K, vr, vx, fixed_iters=reps * 10, profile=1, matfree=mf)
+        print("kle cg matfree", mf, "ms/iter", info.solve_ms / info.iters, "product_ms", info.spmv_ms)
 ctx.close()
