@@ -224,7 +224,7 @@ typedef struct pyn_solve_opts {
   int gmres_orthog;  /* 0 classical Gram-Schmidt + one refinement pass (-ksp_gmres_cgs_refinement_type refine_always),
                         1 classical without refinement (refine_never, PETSc's own default), 2 modified Gram-Schmidt
                         (-ksp_gmres_modifiedgramschmidt) */
-  int matfree;       /* PYN_MATFREE_*: CG multiplies with the matrix-free operator instead of the assembled matrix, which
+  int matfree;       /* PYN_MATFREE_*: CG / GMRES multiply with the matrix-free operator instead of the assembled matrix, which
                         then only supplies the Jacobi diagonal and the exit check (KSPSetOperators(Amat = shell, Pmat =
                         assembled)); pyn_solve first verifies on b that both operators agree */
   double rtol, atol, dtol;   /* PETSc defaults 1e-5, 1e-50, 1e5 */

@@ -822,7 +822,7 @@ __global__ void __launch_bounds__(256) scale_rsqrt_kernel(double* __restrict__ v
 // Gram-Schmidt with one refinement pass (two fused projection + update sweeps, ONE host synchronisation per
 // iteration; as stable as modified Gram-Schmidt) -- PETSc's KSPGMRES default is the classical variant too.
 // PYNAMA_GMRES_MGS=1 selects the step-by-step modified Gram-Schmidt (k+2 synchronisations per iteration).
-static int solve_gmres(pyn_ctx* c, const DMat& A, const double* b, double* x, const pyn_solve_opts& o, pyn_solve_info* info) {
+static int solve_gmres(pyn_ctx* c, DMat& A, const double* b, double* x, const pyn_solve_opts& o, pyn_solve_info* info) {
   const int64_t n = c->n_owned * A.br;
   const int64_t nl = n_local(c) * A.br;
   const int m = std::max(1, o.restart);
@@ -838,6 +838,14 @@ static int solve_gmres(pyn_ctx* c, const DMat& A, const double* b, double* x, co
   std::vector<double> hh_host((size_t)3 * mh);
   const bool mgs = o.gmres_orthog == 2 || getenv("PYNAMA_GMRES_MGS") != nullptr;
   const int npass = o.gmres_orthog == 1 ? 1 : 2;
+  // the product: matrix-free operator, the SELL-64 image, or block CSR
+  const bool sell = !o.matfree && pyn_sell_supported(A) && !getenv("PYNAMA_NO_SELL");
+  if (sell) PYN_TRY(pyn_sell_ensure(c, A));
+  auto product = [&](const double* xin, double* yout) -> int {
+    if (o.matfree) return matfree_product(c, o.matfree, xin, yout, false, nullptr);
+    if (sell) return pyn_sell_spmv(c, A, xin, yout, false, nullptr);
+    return pyn_spmv_raw(c, A, xin, yout);
+  };
   const int mdg = (int)std::max<int64_t>(1, std::min<int64_t>((n + 255) / 256, MD_GRID));
   const bool jac = o.pc == PYN_PC_JACOBI;
   if (jac) PYN_TRY(pyn_extract_diag_inv(c, A, dinv, true));
@@ -855,7 +863,7 @@ static int solve_gmres(pyn_ctx* c, const DMat& A, const double* b, double* x, co
     // r = dinv (b - A x)
     PYN_HIP(hipMemcpyAsync(t, x, n * sizeof(double), hipMemcpyDeviceToDevice, s));
     PYN_TRY(pyn_halo_exchange(c, t, A.bc));
-    PYN_TRY(pyn_spmv_raw(c, A, t, w));
+    PYN_TRY(product(t, w));
     waxpby_kernel<<<g, 256, 0, s>>>(w, 1.0, b, -1.0, w, n);
     wmul_kernel<<<g, 256, 0, s>>>(V, dv, w, n);
     double bb = 0;
@@ -877,7 +885,7 @@ static int solve_gmres(pyn_ctx* c, const DMat& A, const double* b, double* x, co
       double* vk = V + (int64_t)k * nl;
       double* vn = V + (int64_t)(k + 1) * nl;
       PYN_TRY(pyn_halo_exchange(c, vk, A.bc));
-      PYN_TRY(pyn_spmv_raw(c, A, vk, w));
+      PYN_TRY(product(vk, w));
       wmul_kernel<<<g, 256, 0, s>>>(vn, dv, w, n);
       double hh = 0;
       if (mgs) {
@@ -967,7 +975,6 @@ extern "C" int pyn_solve(pyn_ctx* c, int mat_id, int bv, int xv, const pyn_solve
   if (opts->matfree) {
     // the shell operator must BE the assembled matrix (which keeps supplying the Jacobi diagonal and the exit check):
     // compare both products on b before iterating
-    PYN_CHECK(opts->method == PYN_KSP_CG, "matrix-free operator: CG only");
     PYN_CHECK(A.br == (opts->matfree == PYN_MATFREE_KLE ? 3 : 1), "matrix-free operator: block size of the matrix does not match");
     const int64_t n1 = c->n_owned * A.br;
     PYN_TRY(pyn_ensure_work(c, (size_t)2 * n1 * sizeof(double)));

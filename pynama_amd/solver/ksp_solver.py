@@ -102,8 +102,6 @@ class KspSolver(object):
             tag = getattr(A, 'matfree', None)          # set by the assembly that built the matrix (Mat.assembleKLE)
             if tag is None:
                 raise ValueError("-pynama_mat_free: this operator has no matrix-free form (structured Q1 hex meshes only)")
-            if self.ksp_type == 'gmres':
-                raise ValueError("-pynama_mat_free: CG only")
             mf = tag
         if self.ksp_type == 'preonly':
             self.logger and self.logger.info("preonly/lu requested: device path uses Jacobi-PCG to round-off")

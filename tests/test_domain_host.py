@@ -113,3 +113,20 @@ def test_slab_partition_and_halo_plan(nelem, ngl, size):
             k2 = list(n2[2]).index(r)
             ghosts = doms[nb]._local2global(np.arange(n2[0] + n2[5][k2], n2[0] + n2[5][k2 + 1]))
             assert np.array_equal(sent_global, ghosts)
+
+
+def test_ksp_solver_options_host():
+    """PETSc option names reach the solver facade; -pynama_mat_free is a flag (no GPU needed: nothing is solved)"""
+    from pynama_amd.common.options import Options
+    from pynama_amd.solver.ksp_solver import KspSolver
+    try:
+        Options(["-ksp_type", "cg", "-pc_type", "jacobi", "-ksp_rtol", "1e-9", "-pynama_mat_free"])
+        k = KspSolver()
+        k.createSolver(None, None)
+        assert (k.ksp_type, k.pc_type, k.rtol, k.mat_free) == ("cg", "jacobi", 1e-9, True)
+        Options(["-ksp_type", "gmres", "-pc_type", "none", "-pynama_mat_free", "0"])
+        k = KspSolver()
+        k.createSolver(None, None)
+        assert (k.ksp_type, k.pc_type, k.mat_free) == ("gmres", "none", False)
+    finally:
+        Options([])
