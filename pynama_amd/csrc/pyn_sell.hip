@@ -60,6 +60,53 @@ __global__ void __launch_bounds__(256) sell_fill_block_kernel(const int32_t* __r
   }
 }
 
+// block matrices through LDS: the 64 scalar rows of a slice are ONE contiguous chunk of the block-CSR values (rows (i, p)
+// follow each other: (rowptr[i] br + p len_i) bc), read with coalesced loads by the whole workgroup and written back as
+// 512-B k-columns.  (The strided variant above touches a different cache line per lane and load: 8x the traffic.)
+template <bool WITH_COLS>
+__global__ void __launch_bounds__(256) sell_fill_block_lds_kernel(const int32_t* __restrict__ rowptr, const int32_t* __restrict__ colidx,
+                                                                  const double* __restrict__ val, int64_t n_rows, int br, int bc,
+                                                                  int64_t n_slices, const int64_t* __restrict__ sptr,
+                                                                  const int* __restrict__ sw, double* __restrict__ sval,
+                                                                  int32_t* __restrict__ scol) {
+  extern __shared__ __align__(16) double lv[];   // [64 * maxw]
+  __shared__ int roff[SH + 1];                   // chunk-relative first entry of every scalar row of the slice
+  __shared__ int rlo[SH];                        // rowptr of the row's node (columns)
+  __shared__ int64_t base0;
+  const int tid = threadIdx.x;
+  const int64_t n_nodes = n_rows / br;
+  for (int64_t s = blockIdx.x; s < n_slices; s += gridDim.x) {
+    const int64_t r0 = s * SH;
+    auto row_off = [&](int64_t row) -> int64_t {
+      if (row >= n_rows) return (int64_t)rowptr[n_nodes] * br * bc;
+      const int64_t i = row / br;
+      const int p = (int)(row - i * br);
+      const int lo = rowptr[i];
+      return ((int64_t)lo * br + (int64_t)p * (rowptr[i + 1] - lo)) * bc;
+    };
+    const int64_t b0 = row_off(r0);
+    if (tid <= SH) {
+      roff[tid] = (int)(row_off(r0 + tid) - b0);
+      if (tid < SH) rlo[tid] = r0 + tid < n_rows ? rowptr[(r0 + tid) / br] : 0;
+    }
+    if (tid == 0) base0 = b0;
+    __syncthreads();
+    const int total = roff[SH];
+    const double* __restrict__ src = val + base0;
+    for (int e = tid; e < total; e += 256) lv[e] = src[e];
+    __syncthreads();
+    const int wd = sw[s];
+    const int64_t ob = sptr[s];
+    for (int idx = tid; idx < wd * SH; idx += 256) {
+      const int k = idx >> 6, ln = idx & 63;
+      const int st = roff[ln], len = roff[ln + 1] - st;
+      sval[ob + idx] = k < len ? lv[st + k] : 0.0;
+      if (WITH_COLS) scol[ob + idx] = k < len ? colidx[rlo[ln] + k / bc] * bc + k % bc : 0;
+    }
+    __syncthreads();
+  }
+}
+
 // one single-wave workgroup per slice (many small workgroups keep every CU busy); the slice's CSR
 // chunk is contiguous -> staged through LDS with coalesced loads, written back as 512-B k-columns
 template <bool WITH_COLS>
@@ -445,6 +492,15 @@ int pyn_sell_ensure(pyn_ctx* c, DMat& A) {
         sell_fill_kernel<true><<<grid, 64, lds, s>>>(c->d_rowptr, c->d_colidx, A.val, n, ns, S->ptr, S->w, S->maxw, A.sell_val, S->col);
       else
         sell_fill_kernel<false><<<grid, 64, lds, s>>>(c->d_rowptr, c->d_colidx, A.val, n, ns, S->ptr, S->w, S->maxw, A.sell_val, nullptr);
+    } else if ((size_t)SH * S->maxw * sizeof(double) <= 96 * 1024 && !getenv("PYNAMA_SELL_FILL_STRIDED")) {
+      const size_t lds = (size_t)SH * S->maxw * sizeof(double);
+      const int grid = (int)std::min<int64_t>(ns, 256 * 8);
+      PYN_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(sell_fill_block_lds_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+      PYN_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(sell_fill_block_lds_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+      if (cols)
+        sell_fill_block_lds_kernel<true><<<grid, 256, lds, s>>>(c->d_rowptr, c->d_colidx, A.val, n, A.br, A.bc, ns, S->ptr, S->w, A.sell_val, S->col);
+      else
+        sell_fill_block_lds_kernel<false><<<grid, 256, lds, s>>>(c->d_rowptr, c->d_colidx, A.val, n, A.br, A.bc, ns, S->ptr, S->w, A.sell_val, nullptr);
     } else {
       const int grid = (int)std::min<int64_t>((ns + 3) / 4, 256 * 16);
       if (cols)
