@@ -242,3 +242,55 @@ def test_c4_poisson_256cubed_single_gpu_properties():
     info = ctx.solve(A, u, v, rtol=1e-10, norm_type=_lib.NORM_UNPRECONDITIONED, maxit=5000)
     assert info.reason == 2 and info.true_resid <= 1e-10
     ctx.close()
+
+
+@pytest.mark.parametrize("jitter", [0.0, 0.2])
+def test_matrix_free_at_full_size(jitter):
+    """10 M-DOF Poisson and 128^3 KLE: the matrix-free products equal the assembled ones row by row (two independent
+    kernels: SELL/CSR values vs element products recomputed from the coordinates), constants are annihilated, and the
+    matrix-free CG reaches the 1e-10 bar of BASELINE.json measured with the ASSEMBLED matrix"""
+    from pynama_amd import _lib
+    n = 215 if jitter == 0.0 else 128
+    dom, ctx = _domain([n, n, n], jitter=jitter)
+    bm = dom.boundaryMaskLocal()
+    n_rows, _ = ctx.csr_symbolic()
+    rng = np.random.default_rng(3)
+    vx, vy, vz = ctx.vec_create(1), ctx.vec_create(1), ctx.vec_create(1)
+    # no mask: the Laplacian annihilates constants
+    ctx.bc_set(1, None)
+    ctx.matfree_set(_lib.MATFREE_LAPLACE)
+    ctx.vec_set(vx, np.ones(n_rows))
+    ctx.matfree_apply(vx, vy)
+    assert np.abs(ctx.vec_get(vy, 1)).max() < 1e-12 / n
+    # Dirichlet boundary: product and solve
+    ctx.bc_set(1, bm)
+    A = ctx.mat_create(1, 1)
+    ctx.assemble_scalar(_lib.FORM_LAPLACE, A)
+    ctx.matfree_set(_lib.MATFREE_LAPLACE)
+    x = rng.standard_normal(n_rows)
+    ctx.vec_set(vx, x)
+    ctx.spmv(A, vx, vy)
+    ctx.matfree_apply(vx, vz)
+    assert rel_err(ctx.vec_get(vz, 1), ctx.vec_get(vy, 1)) < 2e-13
+    b = rng.standard_normal(n_rows) / n ** 3
+    b[bm != 0] = 0.0
+    ctx.vec_set(vx, b)
+    i0 = ctx.solve(A, vx, vy, rtol=1e-10, maxit=20000, norm_type=_lib.NORM_UNPRECONDITIONED)
+    i1 = ctx.solve(A, vx, vz, rtol=1e-10, maxit=20000, norm_type=_lib.NORM_UNPRECONDITIONED, matfree=_lib.MATFREE_LAPLACE)
+    assert i0.reason == 2 and i1.reason == 2 and abs(i0.iters - i1.iters) <= 2 and i1.true_resid <= 1e-10
+    assert rel_err(ctx.vec_get(vz, 1), ctx.vec_get(vy, 1)) < 1e-7
+    ctx.close()
+    # KLE, 128^3 (configs[2])
+    dom, ctx = _domain([128, 128, 128], jitter=jitter)
+    bm = dom.boundaryMaskLocal()
+    ctx.bc_set(3, np.repeat(bm[:, None], 3, axis=1))
+    n_rows, _ = ctx.csr_symbolic()
+    K = ctx.mat_create(3, 3)
+    ctx.assemble_kle(1e3, 1e2, K)
+    ctx.matfree_set(_lib.MATFREE_KLE, 1e3, 1e2)
+    vx, vy, vz = ctx.vec_create(3), ctx.vec_create(3), ctx.vec_create(3)
+    ctx.vec_set(vx, rng.standard_normal(3 * n_rows))
+    ctx.spmv(K, vx, vy)
+    ctx.matfree_apply(vx, vz, op=_lib.MATFREE_KLE)
+    assert rel_err(ctx.vec_get(vz, 3), ctx.vec_get(vy, 3)) < 2e-13
+    ctx.close()
