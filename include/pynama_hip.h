@@ -76,6 +76,11 @@ int pyn_comm_unique_id(void* out, int nbytes);    /* rank 0: nbytes >= 128 */
  * real one-rank RCCL communicator, so the collective code paths (and a halo plan whose neighbour is
  * the rank itself) run exactly as they do at nranks > 1. */
 int pyn_comm_init(pyn_ctx* ctx, int rank, int nranks, const void* unique_id, int nbytes);
+/* TEST transport: the same collectives staged through a POSIX shared-memory file (device -> host, process barrier,
+ * host -> device), so that world_size > 1 can be exercised end to end by processes sharing ONE GPU, which RCCL refuses
+ * (duplicate device).  `path` names a zero-filled file of at least 4096 + nranks*512 + nranks*nranks*16 + nranks*cap_bytes
+ * bytes created by the launcher; cap_bytes bounds one rank's packed halo.  Never used by bench.py or the cases. */
+int pyn_comm_init_shm(pyn_ctx* ctx, int rank, int nranks, const char* path, int64_t cap_bytes);
 int pyn_comm_barrier(pyn_ctx* ctx);               /* device + host barrier over all ranks */
 int pyn_comm_allreduce_f64(pyn_ctx* ctx, double* inout, int n, int op /*0 sum, 1 max*/);
 /* Row partition + halo plan of this rank.  Local node numbering: owned nodes

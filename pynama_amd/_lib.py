@@ -57,6 +57,7 @@ SIGNATURES = {
     "pyn_sync": [_P],
     "pyn_comm_unique_id": [C.c_char_p, _I],
     "pyn_comm_init": [_P, _I, _I, C.c_char_p, _I],
+    "pyn_comm_init_shm": [_P, _I, _I, C.c_char_p, _L],
     "pyn_comm_barrier": [_P],
     "pyn_comm_allreduce_f64": [_P, _pf64, _I, _I],
     "pyn_halo_set": [_P, _L, _L, _I, _pi32, _pi64, _pi32, _pi64],
@@ -193,6 +194,15 @@ class Context:
 
     def comm_init(self, rank, nranks, uid: bytes | None):
         _check(self.lib.pyn_comm_init(self.h, rank, nranks, uid, len(uid) if uid else 0))
+        self.rank, self.nranks = rank, nranks
+
+    @staticmethod
+    def shm_size(nranks, cap_bytes):
+        return 4096 + nranks * 512 + nranks * nranks * 16 + nranks * cap_bytes
+
+    def comm_init_shm(self, rank, nranks, path, cap_bytes):
+        """TEST transport (several ranks on one GPU): collectives staged through the shared-memory file `path`"""
+        _check(self.lib.pyn_comm_init_shm(self.h, rank, nranks, path.encode(), cap_bytes))
         self.rank, self.nranks = rank, nranks
 
     def barrier(self):

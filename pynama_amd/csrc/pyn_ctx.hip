@@ -1,8 +1,35 @@
 // Context, communicator, mesh/table upload, device vectors and matrices of libpynama_hip.so.
+#include <fcntl.h>
+#include <sched.h>
+#include <sys/mman.h>
+#include <sys/stat.h>
+#include <unistd.h>
+
+#include <atomic>
+#include <chrono>
 #include <cstdarg>
 #include <cstring>
 
 #include "pyn_internal.h"
+
+// layout of the shared-memory TEST transport (see pyn_comm_init_shm below)
+struct pyn_shm_hdr {
+  std::atomic<int> count;
+  std::atomic<int> sense;
+  int nranks;
+  int64_t cap;   // outbox capacity per rank, bytes
+};
+struct pyn_shm_comm {
+  unsigned char* base = nullptr;
+  size_t size = 0;
+  int rank = 0, nranks = 1, local_sense = 0;
+  int64_t cap = 0;
+  pyn_shm_hdr* hdr() const { return reinterpret_cast<pyn_shm_hdr*>(base); }
+  double* ar(int r) const { return reinterpret_cast<double*>(base + 4096) + (size_t)r * 64; }
+  int64_t* dir(int src) const { return reinterpret_cast<int64_t*>(base + 4096 + (size_t)nranks * 512) + (size_t)src * nranks * 2; }
+  unsigned char* outbox(int r) const { return base + 4096 + (size_t)nranks * 512 + (size_t)nranks * nranks * 16 + (size_t)r * cap; }
+};
+
 
 // ---------------------------------------------------------------------------------------------
 static thread_local char g_err[1024] = "";
@@ -89,6 +116,11 @@ extern "C" int pyn_ctx_destroy(pyn_ctx* c) {
   (void)hipSetDevice(c->device);
   (void)hipStreamSynchronize(c->stream);
   if (c->comm) ncclCommDestroy(c->comm);
+  if (c->shm) {
+    munmap(c->shm->base, c->shm->size);
+    delete c->shm;
+    c->shm = nullptr;
+  }
   for (auto& m : c->mats) {
     (void)hipFree(m.val);
     (void)hipFree(m.sell_val);
@@ -144,6 +176,73 @@ int pyn_ensure_work(pyn_ctx* c, size_t bytes) {
 
 // ---------------------------------------------------------------------------------------------
 // communicator
+// Shared-memory TEST transport: ranks are processes that may share one GPU; every exchange is staged through a POSIX
+// shared-memory file (device -> host copy, process barrier, host -> device copy).  Slow by construction; it exists so that
+// the distributed solver can be run end to end with world_size > 1 on a one-GPU box, where RCCL refuses duplicate devices.
+static int shm_barrier(pyn_shm_comm* m) {
+  pyn_shm_hdr* h = m->hdr();
+  m->local_sense ^= 1;
+  if (h->count.fetch_add(1, std::memory_order_acq_rel) == m->nranks - 1) {
+    h->count.store(0, std::memory_order_relaxed);
+    h->sense.store(m->local_sense, std::memory_order_release);
+    return PYN_OK;
+  }
+  const auto t0 = std::chrono::steady_clock::now();
+  while (h->sense.load(std::memory_order_acquire) != m->local_sense) {
+    if (std::chrono::steady_clock::now() - t0 > std::chrono::seconds(120)) PYN_CHECK(false, "shared-memory barrier: a rank did not arrive within 120 s");
+    sched_yield();
+  }
+  return PYN_OK;
+}
+
+extern "C" int pyn_comm_init_shm(pyn_ctx* c, int rank, int nranks, const char* path, int64_t cap_bytes) {
+  PYN_CHECK(c && path, "NULL argument");
+  PYN_CHECK(nranks >= 1 && rank >= 0 && rank < nranks && nranks <= 16, "bad rank %d / %d", rank, nranks);
+  PYN_CHECK(cap_bytes > 0, "outbox capacity must be positive");
+  const size_t size = 4096 + (size_t)nranks * 512 + (size_t)nranks * nranks * 16 + (size_t)nranks * cap_bytes;
+  const int fd = open(path, O_RDWR);
+  PYN_CHECK(fd >= 0, "cannot open %s (rank 0's launcher creates and sizes it)", path);
+  struct stat st;
+  PYN_CHECK(fstat(fd, &st) == 0 && (size_t)st.st_size >= size, "%s is smaller than %zu bytes", path, size);
+  void* base = mmap(nullptr, size, PROT_READ | PROT_WRITE, MAP_SHARED, fd, 0);
+  close(fd);
+  PYN_CHECK(base != MAP_FAILED, "mmap of %s failed", path);
+  auto* m = new pyn_shm_comm();
+  m->base = static_cast<unsigned char*>(base);
+  m->size = size;
+  m->rank = rank;
+  m->nranks = nranks;
+  m->cap = cap_bytes;
+  c->shm = m;
+  c->rank = rank;
+  c->nranks = nranks;
+  return shm_barrier(m);   // the file arrives zero-filled: count = sense = 0
+}
+
+int pyn_allreduce_dev(pyn_ctx* c, double* dbuf, int n, int op, hipStream_t st) {
+  if (c->comm) {
+    PYN_NCCL(ncclAllReduce(dbuf, dbuf, n, ncclDouble, op == 1 ? ncclMax : ncclSum, c->comm, st));
+    return PYN_OK;
+  }
+  if (!c->shm) return PYN_OK;
+  pyn_shm_comm* m = c->shm;
+  PYN_CHECK(n <= 64, "shared-memory all-reduce: at most 64 values");
+  double loc[64];
+  PYN_HIP(hipMemcpyAsync(loc, dbuf, n * sizeof(double), hipMemcpyDeviceToHost, st));
+  PYN_HIP(hipStreamSynchronize(st));
+  memcpy(m->ar(m->rank), loc, n * sizeof(double));
+  PYN_TRY(shm_barrier(m));
+  for (int i = 0; i < n; ++i) {   // same order on every rank: identical results
+    double r = m->ar(0)[i];
+    for (int k = 1; k < m->nranks; ++k) r = op == 1 ? fmax(r, m->ar(k)[i]) : r + m->ar(k)[i];
+    loc[i] = r;
+  }
+  PYN_TRY(shm_barrier(m));
+  PYN_HIP(hipMemcpyAsync(dbuf, loc, n * sizeof(double), hipMemcpyHostToDevice, st));
+  PYN_HIP(hipStreamSynchronize(st));
+  return PYN_OK;
+}
+
 extern "C" int pyn_comm_unique_id(void* out, int nbytes) {
   PYN_CHECK(out && nbytes >= (int)sizeof(ncclUniqueId), "need >= %d bytes", (int)sizeof(ncclUniqueId));
   ncclUniqueId id;
@@ -172,11 +271,10 @@ extern "C" int pyn_comm_init(pyn_ctx* c, int rank, int nranks, const void* uid, 
 
 extern "C" int pyn_comm_allreduce_f64(pyn_ctx* c, double* inout, int n, int op) {
   PYN_CHECK(c && inout && n > 0 && n <= 32, "bad arguments");
-  if (c->nranks == 1 && !c->comm) return PYN_OK;
+  if (c->nranks == 1 && !pyn_has_comm(c)) return PYN_OK;
   PYN_CHECK(!c->detached, "detached communicator: no collectives");
   PYN_HIP(hipMemcpyAsync(c->d_scal + 32, inout, n * sizeof(double), hipMemcpyHostToDevice, c->stream));
-  PYN_NCCL(ncclAllReduce(c->d_scal + 32, c->d_scal + 32, n, ncclDouble, op == 1 ? ncclMax : ncclSum, c->comm,
-                         c->stream));
+  PYN_TRY(pyn_allreduce_dev(c, c->d_scal + 32, n, op, c->stream));
   PYN_HIP(hipMemcpyAsync(inout, c->d_scal + 32, n * sizeof(double), hipMemcpyDeviceToHost, c->stream));
   PYN_HIP(hipStreamSynchronize(c->stream));
   return PYN_OK;
@@ -228,12 +326,36 @@ int pyn_halo_exchange(pyn_ctx* c, double* x, int bs) { return pyn_halo_exchange_
 int pyn_halo_exchange_on(pyn_ctx* c, double* x, int bs, hipStream_t st) {
   if (c->neigh.empty()) return PYN_OK;
   if (c->detached) return PYN_OK;  // ghost entries were written by the caller (pyn_vec_set_local_host)
-  PYN_CHECK(c->comm, "halo exchange needs a communicator (pyn_comm_init with a unique id)");
+  PYN_CHECK(pyn_has_comm(c), "halo exchange needs a communicator (pyn_comm_init with a unique id)");
   PYN_CHECK(bs <= 6, "block size too large for the halo buffer");
   if (c->n_send) {
     int64_t tot = c->n_send * bs;
     int grid = (int)std::min<int64_t>((tot + 255) / 256, 1024);
     pack_send_kernel<<<grid, 256, 0, st>>>(x, c->d_send_idx, c->d_send_buf, c->n_send, bs);
+  }
+  if (c->shm) {   // test transport: outbox in shared memory, directory entry (offset, count) per destination
+    pyn_shm_comm* m = c->shm;
+    const size_t bytes = (size_t)c->n_send * bs * sizeof(double);
+    PYN_CHECK((int64_t)bytes <= m->cap, "halo (%zu bytes) exceeds the shared-memory outbox", bytes);
+    if (bytes) PYN_HIP(hipMemcpyAsync(m->outbox(m->rank), c->d_send_buf, bytes, hipMemcpyDeviceToHost, st));
+    PYN_HIP(hipStreamSynchronize(st));
+    for (size_t k = 0; k < c->neigh.size(); ++k) {
+      int64_t* d = m->dir(m->rank) + (size_t)c->neigh[k] * 2;
+      d[0] = c->send_ptr[k] * bs;
+      d[1] = (c->send_ptr[k + 1] - c->send_ptr[k]) * bs;
+    }
+    PYN_TRY(shm_barrier(m));
+    for (size_t k = 0; k < c->neigh.size(); ++k) {
+      const int src = c->neigh[k];
+      const int64_t* d = m->dir(src) + (size_t)m->rank * 2;
+      const int64_t nr = (c->recv_ptr[k + 1] - c->recv_ptr[k]) * bs;
+      PYN_CHECK(d[1] == nr, "halo plan mismatch with rank %d: it sends %lld values, %lld expected", src, (long long)d[1], (long long)nr);
+      if (nr)
+        PYN_HIP(hipMemcpyAsync(x + (c->n_owned + c->recv_ptr[k]) * bs, reinterpret_cast<const double*>(m->outbox(src)) + d[0],
+                               (size_t)nr * sizeof(double), hipMemcpyHostToDevice, st));
+    }
+    PYN_HIP(hipStreamSynchronize(st));
+    return shm_barrier(m);   // outboxes may be rewritten
   }
   PYN_NCCL(ncclGroupStart());
   for (size_t k = 0; k < c->neigh.size(); ++k) {
@@ -665,8 +787,7 @@ __global__ void __launch_bounds__(256) finish_kernel(const double* __restrict__ 
 
 int pyn_reduce_host(pyn_ctx* c, int nslots, int nblocks, int op, double* out) {
   finish_kernel<<<1, 256, 0, c->stream>>>(c->d_part, nslots, nblocks, op, c->d_scal + 40);
-  if (c->comm)
-    PYN_NCCL(ncclAllReduce(c->d_scal + 40, c->d_scal + 40, nslots, ncclDouble, op == 1 ? ncclMax : ncclSum, c->comm, c->stream));
+  PYN_TRY(pyn_allreduce_dev(c, c->d_scal + 40, nslots, op, c->stream));
   PYN_HIP(hipMemcpyAsync(c->h_scal, c->d_scal + 40, nslots * sizeof(double), hipMemcpyDeviceToHost, c->stream));
   PYN_HIP(hipStreamSynchronize(c->stream));
   for (int s = 0; s < nslots; ++s) out[s] = c->h_scal[s];

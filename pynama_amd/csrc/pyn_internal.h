@@ -132,6 +132,8 @@ struct pyn_ctx {
   // communicator
   int rank = 0, nranks = 1;
   ncclComm_t comm = nullptr;
+  struct pyn_shm_comm* shm = nullptr;   // TEST transport (pyn_comm_init_shm): host-staged exchange through POSIX shared memory, so
+                                        // that several ranks can share ONE GPU (RCCL refuses that); never used by bench / product runs
   bool detached = false;  // ranks declared without a transport: ghosts are supplied by the caller
   // halo plan
   int64_t n_owned = 0, n_ghost = 0;
@@ -219,6 +221,9 @@ int pyn_sell_spmv_range(pyn_ctx* c, const DMat& A, const double* x, double* y, b
 int pyn_lattice_detect(pyn_ctx* c, const int32_t* conn_host);  // pyn_assemble_tiled.hip
 bool pyn_q1_affine_tables_standard(const double* aff);
 int pyn_mesh_all_affine(pyn_ctx* c, int* out);                        // pyn_assemble_tiled.hip
+// collectives behind one switch: RCCL (product) or the shared-memory test transport
+inline bool pyn_has_comm(const pyn_ctx* c) { return c->comm != nullptr || c->shm != nullptr; }
+int pyn_allreduce_dev(pyn_ctx* c, double* dbuf, int n, int op, hipStream_t st);   // op 0 sum, 1 max; in place, device buffer
 int pyn_lattice_symbolic(pyn_ctx* c, bool* done);
 int pyn_assemble_lattice(pyn_ctx* c, double* A, double* Arhs, bool* handled);   // pyn_assemble_lattice.hip
 bool pyn_lattice_matfree_supported(const pyn_ctx* c);

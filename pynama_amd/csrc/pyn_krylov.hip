@@ -547,9 +547,7 @@ extern "C" int pyn_matfree_apply(pyn_ctx* c, int op, int xv, int yv) {
 }
 
 static int allreduce_tmp(pyn_ctx* c, int n) {
-  if (c->comm)
-    PYN_NCCL(ncclAllReduce(c->d_scal + S_TMP0, c->d_scal + S_TMP0, n, ncclDouble, ncclSum, c->comm, c->stream));
-  return PYN_OK;
+  return pyn_allreduce_dev(c, c->d_scal + S_TMP0, n, 0, c->stream);
 }
 
 static int solve_cg(pyn_ctx* c, DMat& A, const double* b, double* x, const pyn_solve_opts& o, pyn_solve_info* info) {
@@ -674,7 +672,7 @@ static int solve_cg_sr(pyn_ctx* c, DMat& A, const double* b, double* x, const py
   hipStream_t s = c->stream;
   const int maxit = o.fixed_iters > 0 ? o.fixed_iters : o.maxit;
   const int check = o.fixed_iters > 0 ? 0 : 1;
-  const bool multi = c->comm != nullptr;
+  const bool multi = pyn_has_comm(c);
   const SellShape* S = sell ? pyn_sell_shape(c, A) : nullptr;
   const bool overlap = multi && !c->neigh.empty() && !c->detached && S && S->int_begin >= 0 && !getenv("PYNAMA_NO_OVERLAP");
   if (getenv("PYNAMA_OVERLAP_REQUIRE")) PYN_CHECK(overlap, "halo/SpMV overlap not engaged (tests)");
@@ -903,12 +901,12 @@ static int solve_gmres(pyn_ctx* c, DMat& A, const double* b, double* x, const py
         for (int pass = 0; pass < npass; ++pass) {      // projection + update (, then once more: refinement)
           multi_dot_kernel<<<mdg, 256, 0, s>>>(V, nl, k1, vn, n, mpart);
           multi_finish_kernel<<<k1, 256, 0, s>>>(mpart, mdg, dh + pass * mh);
-          if (c->comm) PYN_NCCL(ncclAllReduce(dh + pass * mh, dh + pass * mh, k1, ncclDouble, ncclSum, c->comm, s));
+          PYN_TRY(pyn_allreduce_dev(c, dh + pass * mh, k1, 0, s));
           multi_axpy_kernel<<<g, 256, 0, s>>>(vn, V, nl, k1, dh + pass * mh, n);
         }
         multi_dot_kernel<<<mdg, 256, 0, s>>>(vn, nl, 1, vn, n, mpart);
         multi_finish_kernel<<<1, 256, 0, s>>>(mpart, mdg, dh + 2 * mh);
-        if (c->comm) PYN_NCCL(ncclAllReduce(dh + 2 * mh, dh + 2 * mh, 1, ncclDouble, ncclSum, c->comm, s));
+        PYN_TRY(pyn_allreduce_dev(c, dh + 2 * mh, 1, 0, s));
         scale_rsqrt_kernel<<<g, 256, 0, s>>>(vn, dh + 2 * mh, n);
         PYN_HIP(hipMemcpyAsync(hh_host.data(), dh, 3 * mh * sizeof(double), hipMemcpyDeviceToHost, s));
         PYN_HIP(hipStreamSynchronize(s));
@@ -991,7 +989,7 @@ extern "C" int pyn_solve(pyn_ctx* c, int mat_id, int bv, int xv, const pyn_solve
   }
   if (opts->method == PYN_KSP_CG) {
     // cg_variant: 0 auto (standard on one GPU, single-reduction across ranks), 1 standard, 2 single-reduction
-    const int v = opts->cg_variant ? opts->cg_variant : (c->comm ? 2 : 1);
+    const int v = opts->cg_variant ? opts->cg_variant : (pyn_has_comm(c) ? 2 : 1);
     PYN_CHECK(v == 1 || v == 2, "cg_variant must be 0, 1 or 2");
     if (v == 2)
       PYN_TRY(solve_cg_sr(c, A, b, x, *opts, info));

@@ -158,7 +158,12 @@ class DMPlexDom(object):
             if not hasattr(self, "conn"):
                 raise RuntimeError("setFemIndexing(ngl) first")
             ctx = _lib.Context(_lib.default_device())
-            if self.comm.size > 1:
+            if self.comm.size > 1 and os.environ.get("PYNAMA_SHM_TRANSPORT"):
+                # TEST transport: ranks share one GPU, collectives go through the shared-memory file (tests/test_gpu_dist.py)
+                ctx.comm_init_shm(self.comm.rank, self.comm.size, os.environ["PYNAMA_SHM_TRANSPORT"],
+                                  int(os.environ.get("PYNAMA_SHM_CAP", str(8 << 20))))
+                ctx.halo_set(*self._halo_plan())
+            elif self.comm.size > 1:
                 uid = self.comm.unique_id(_lib.Context.unique_id)
                 ctx.comm_init(self.comm.rank, self.comm.size, uid)
                 ctx.halo_set(*self._halo_plan())
