@@ -1149,3 +1149,64 @@ def test_matfree_kle_cg_equals_assembled_cg(lib, geom):
     with pytest.raises(lib.PynamaHipError, match="differs from the assembled matrix"):
         ctx.solve(K, vb, vx, matfree=lib.MATFREE_KLE, **kw)
     ctx.close()
+
+
+def test_matfree_fuzz_against_assembled(lib):
+    """seeded sweep over box sizes (down to one element), geometry, random per-DOF Dirichlet masks, tile shapes and slab
+    partitions (detached ranks, ghost values supplied): the matrix-free scalar and KLE products equal the products with the
+    matrices assembled by the generic atomics kernel (an independent data path, itself checked against the oracle)"""
+    import os
+    from pynama_amd.common.comm import Comm
+    from pynama_amd.domain.dmplex import DMPlexDom
+    from pynama_amd.elements.spectral import Spectral
+    rng = np.random.default_rng(20241004)
+    tables = Spectral(2, 3).deviceTables()
+    for case in range(28):
+        nelem = [int(v) for v in rng.integers(1, 20, size=3)]
+        size = int(rng.choice([1, 1, 2, 3]))
+        if nelem[2] + 1 < size:
+            size = 1
+        geom = rng.choice(["uniform", "sheared", "jitter"])
+        rank = int(rng.integers(0, size))
+        dom = DMPlexDom(boxMesh={'nelem': nelem, 'lower': [0, 0, 0], 'upper': [1.0, 0.7, 1.3]}, comm=Comm(rank, size),
+                        jitter=0.2 if geom == "jitter" else 0.0)
+        dom.setFemIndexing(2)
+        xyz = dom.xyz
+        if geom == "sheared":
+            xyz = xyz @ np.array([[1.0, 0.3, -0.2], [0.1, 0.9, 0.25], [-0.15, 0.2, 1.1]]).T
+        os.environ["PYNAMA_MATFREE_TILE"] = str(int(rng.integers(0, 10)))
+        try:
+            ctx = lib.Context(0)
+            if size > 1:
+                ctx.comm_init(rank, size, None)
+                ctx.halo_set(*dom._halo_plan())
+            ctx.mesh_set(3, dom.conn, xyz)
+            for t in tables:
+                ctx.tables_set(*t)
+            ctx.csr_symbolic()
+            tag = (case, nelem, size, rank, str(geom), os.environ["PYNAMA_MATFREE_TILE"])
+            # scalar Laplacian
+            mask = (rng.random(dom.nLocal) < rng.choice([0.0, 0.1, 0.5])).astype(np.uint8)
+            ctx.bc_set(1, mask if mask.any() else None)
+            A = ctx.mat_create(1, 1)
+            ctx.assemble_scalar(lib.FORM_LAPLACE, A, variant=0)
+            ctx.matfree_set(lib.MATFREE_LAPLACE)
+            vx, vy, vz = ctx.vec_create(1), ctx.vec_create(1), ctx.vec_create(1)
+            ctx.vec_set_local(vx, rng.standard_normal(dom.nLocal))
+            ctx.spmv(A, vx, vy)
+            ctx.matfree_apply(vx, vz)
+            assert rel_err(ctx.vec_get(vz, 1), ctx.vec_get(vy, 1)) < FP_TOL, tag
+            # KLE stiffness, random per-DOF mask
+            mask3 = (rng.random((dom.nLocal, 3)) < rng.choice([0.0, 0.15, 0.6])).astype(np.uint8)
+            ctx.bc_set(3, mask3 if mask3.any() else None)
+            K = ctx.mat_create(3, 3)
+            ctx.assemble_kle(1e3, 1e2, K, variant=0)
+            ctx.matfree_set(lib.MATFREE_KLE, 1e3, 1e2)
+            wx, wy, wz = ctx.vec_create(3), ctx.vec_create(3), ctx.vec_create(3)
+            ctx.vec_set_local(wx, rng.standard_normal(dom.nLocal * 3))
+            ctx.spmv(K, wx, wy)
+            ctx.matfree_apply(wx, wz, op=lib.MATFREE_KLE)
+            assert rel_err(ctx.vec_get(wz, 3), ctx.vec_get(wy, 3)) < FP_TOL, tag + ("kle",)
+            ctx.close()
+        finally:
+            del os.environ["PYNAMA_MATFREE_TILE"]
