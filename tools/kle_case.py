@@ -14,7 +14,7 @@ from pynama_amd.elements.spectral import Spectral  # noqa: E402
 
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 128
 iters = int(sys.argv[2]) if len(sys.argv) > 2 else 50
-dom = DMPlexDom(boxMesh={"nelem": [n, n, n], "lower": [0, 0, 0], "upper": [1, 1, 1]})
+dom = DMPlexDom(boxMesh={"nelem": [n, n, n], "lower": [0, 0, 0], "upper": [1, 1, 1]}, jitter=float(os.environ.get("PYNAMA_JITTER", "0")))
 dom.setFemIndexing(2)
 ctx = dom.ctx
 for t in Spectral(2, 3).deviceTables():
