@@ -134,26 +134,28 @@ def main():
         t_asm = ctx.timers()["assemble_ms"]
         info = ctx.solve(A, vb, vx, method=_lib.KSP_CG, pc=_lib.PC_JACOBI, fixed_iters=args.cg_iters,
                          norm_type=_lib.NORM_UNPRECONDITIONED, profile=1 if profile else 0)
-        return t_asm, info.solve_ms, info.spmv_ms
+        return t_asm, info.solve_ms, info.spmv_ms, info.reduce_ms, info.halo_ms
 
     for _ in range(args.warmup):
         step(False)
     ctx.barrier()
     ctx.sync()
     t0 = time.perf_counter()
-    asm_ms, cg_ms, spmv_ms = [], [], []
+    asm_ms, cg_ms, spmv_ms, red_ms, halo_ms = [], [], [], [], []
     for _ in range(args.steps):
-        a, c, s = step(True)
+        a, c, s, rd, hl = step(True)
+        halo_ms.append(hl)
         asm_ms.append(a)
         cg_ms.append(c)
         spmv_ms.append(s)
+        red_ms.append(rd)
     ctx.sync()
     ctx.barrier()
     wall = time.perf_counter() - t0
     # max over ranks
-    red = ctx.allreduce([wall, np.mean(asm_ms), np.mean(cg_ms), np.mean(spmv_ms)], op="max") if world.size > 1 \
-        else np.array([wall, np.mean(asm_ms), np.mean(cg_ms), np.mean(spmv_ms)])
-    wall, asm_mean, cg_mean, spmv_mean = [float(v) for v in red]
+    loc = [wall, np.mean(asm_ms), np.mean(cg_ms), np.mean(spmv_ms), np.mean(red_ms), np.mean(halo_ms)]
+    red = ctx.allreduce(loc, op="max") if world.size > 1 else np.array(loc)
+    wall, asm_mean, cg_mean, spmv_mean, red_mean, halo_mean = [float(v) for v in red]
 
     # ---- correctness on the SAME workload (outside the timed region): solve to 1e-10
     check = None
@@ -219,7 +221,12 @@ def main():
             "n_gpus": world.size, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": wall / args.steps * 1e3,
             "breakdown_ms": {"assembly": asm_mean, "cg": cg_mean, "cg_iters": args.cg_iters,
-                             "spmv_kernel": spmv_mean, "symbolic_once": symbolic_ms},
+                             "spmv_kernel": spmv_mean, "symbolic_once": symbolic_ms,
+                             # N > 1 (single-reduction CG): end of the product -> scalars ready = partial sums + the one
+                             # all-reduce + scalar step, per iteration (0 on one GPU: standard PCG is not bracketed)
+                             "cg_reduction_per_iter": red_mean,
+                             # overlapped halo exchange (pack + grouped send/recv on the communication stream), per iteration
+                             "cg_halo_per_iter": halo_mean},
             "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
             "dtype": "f64", "data": "synthetic",
             "config": {"workload": f"3D Poisson, {n}^3 Q1 hex elements, {n_node_global} DOFs, nnz {nnz_global}, "

@@ -243,6 +243,10 @@ typedef struct pyn_solve_info {
   double solve_ms;    /* device time of the iteration loop (HIP events) */
   double spmv_ms;     /* mean device time of one SpMV launch (profile != 0), else 0 */
   int spmv_launches;  /* launches averaged in spmv_ms */
+  double reduce_ms;   /* single-reduction CG with profile != 0: mean device time from the end of the product to the scalars being
+                         ready (partial sums + all-reduce + scalar step), else 0 */
+  double halo_ms;     /* same runs, overlapped exchange: mean device time of pack + grouped send/recv on the communication
+                         stream (hidden behind the interior rows when shorter than their product), else 0 */
 } pyn_solve_info;
 /* Solve A x = b (x0 = 0).  Takes over KspSolver.createSolver + KSP.__call__
  * (src/solver/ksp_solver.py:9-19, call site base_problem.py:481). */

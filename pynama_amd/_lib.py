@@ -8,6 +8,7 @@ from __future__ import annotations
 import ctypes as C
 import os
 import subprocess
+import sys
 
 import numpy as np
 
@@ -38,7 +39,7 @@ class SolveOpts(C.Structure):
 class SolveInfo(C.Structure):
     _fields_ = [("iters", C.c_int), ("reason", C.c_int), ("rnorm", C.c_double), ("rnorm0", C.c_double),
                 ("true_resid", C.c_double), ("solve_ms", C.c_double), ("spmv_ms", C.c_double),
-                ("spmv_launches", C.c_int)]
+                ("spmv_launches", C.c_int), ("reduce_ms", C.c_double), ("halo_ms", C.c_double)]
 
 
 _P = C.c_void_p
@@ -145,6 +146,25 @@ def device_count() -> int:
     return n.value
 
 
+class _stdout_to_stderr:
+    """File descriptor 1 points at stderr inside the block: keeps C-level chatter of third-party libraries (RCCL's version
+    banner) out of a program's stdout, which callers such as bench.py reserve for their own output."""
+
+    def __enter__(self):
+        sys.stdout.flush()
+        self._saved = os.dup(1)
+        os.dup2(2, 1)
+
+    def __exit__(self, *exc):
+        try:
+            C.CDLL(None).fflush(None)       # C stdio buffers of the library must drain while fd 1 is still redirected
+        except OSError:
+            pass
+        os.dup2(self._saved, 1)
+        os.close(self._saved)
+        return False
+
+
 def default_device() -> int:
     """GPU of this process: LOCAL_RANK under a one-process-per-GPU launcher, else 0."""
     n = device_count()
@@ -189,11 +209,13 @@ class Context:
     def unique_id() -> bytes:
         lib = load_library()
         buf = C.create_string_buffer(128)
-        _check(lib.pyn_comm_unique_id(buf, 128))
+        with _stdout_to_stderr():
+            _check(lib.pyn_comm_unique_id(buf, 128))
         return buf.raw
 
     def comm_init(self, rank, nranks, uid: bytes | None):
-        _check(self.lib.pyn_comm_init(self.h, rank, nranks, uid, len(uid) if uid else 0))
+        with _stdout_to_stderr():       # RCCL prints a version banner on stdout when a communicator comes up
+            _check(self.lib.pyn_comm_init(self.h, rank, nranks, uid, len(uid) if uid else 0))
         self.rank, self.nranks = rank, nranks
 
     @staticmethod

@@ -681,7 +681,7 @@ static int solve_cg_sr(pyn_ctx* c, DMat& A, const double* b, double* x, const py
   cgsr_init_kernel<<<g, 256, 0, s>>>(b, dv, x, r, u, p, sv, n, o.norm_type, c->d_part);
   PYN_HIP(hipEventRecord(c->ev0, s));
   const int prof_max = o.profile ? 256 : 0;
-  while ((int)c->prof_ev.size() < 2 * prof_max) {
+  while ((int)c->prof_ev.size() < 6 * prof_max) {   // [0, 2 P): product brackets, [2 P, 3 P): reduction end, [4 P, 6 P): halo brackets
     hipEvent_t e;
     PYN_HIP(hipEventCreate(&e));
     c->prof_ev.push_back(e);
@@ -700,7 +700,9 @@ static int solve_cg_sr(pyn_ctx* c, DMat& A, const double* b, double* x, const py
         // communication stream wait for it.
         PYN_HIP(hipEventRecord(c->ev_vec, s));
         PYN_HIP(hipStreamWaitEvent(c->comm_stream, c->ev_vec, 0));
+        if (prof) PYN_HIP(hipEventRecord(c->prof_ev[4 * prof_max + 2 * prof_n], c->comm_stream));
         PYN_TRY(pyn_halo_exchange_on(c, u, A.bc, c->comm_stream));
+        if (prof) PYN_HIP(hipEventRecord(c->prof_ev[4 * prof_max + 2 * prof_n + 1], c->comm_stream));
         PYN_HIP(hipEventRecord(c->ev_halo, c->comm_stream));
         if (prof) PYN_HIP(hipEventRecord(c->prof_ev[2 * prof_n], s));
         int g0 = 0, g1 = 0, g2 = 0;
@@ -719,7 +721,7 @@ static int solve_cg_sr(pyn_ctx* c, DMat& A, const double* b, double* x, const py
         else
           spmv_kernel<32, true><<<gs, 256, 0, s>>>(c->d_rowptr, c->d_colidx, A.val, u, w, rows, A.br, A.bc, c->d_flag, c->d_part);
       }
-      if (prof) PYN_HIP(hipEventRecord(c->prof_ev[2 * prof_n++ + 1], s));
+      if (prof) PYN_HIP(hipEventRecord(c->prof_ev[2 * prof_n + 1], s));
       const int first = (issued + k) == 0;
       if (multi) {
         cgsr_reduce_kernel<false><<<1, 256, 0, s>>>(c->d_part, gsp, g, c->d_scal, c->d_flag, o.norm_type, maxit, check, hist, hist_cap, first);
@@ -727,6 +729,10 @@ static int solve_cg_sr(pyn_ctx* c, DMat& A, const double* b, double* x, const py
         cgsr_scalar_kernel<<<1, 1, 0, s>>>(c->d_scal, c->d_flag, o.norm_type, maxit, check, hist, hist_cap, first);
       } else {
         cgsr_reduce_kernel<true><<<1, 256, 0, s>>>(c->d_part, gsp, g, c->d_scal, c->d_flag, o.norm_type, maxit, check, hist, hist_cap, first);
+      }
+      if (prof) {   // product end -> scalars ready: partial sums + all-reduce + scalar step (the latency-bound part across ranks)
+        PYN_HIP(hipEventRecord(c->prof_ev[2 * prof_max + prof_n], s));
+        ++prof_n;
       }
       cgsr_update_kernel<<<g, 256, 0, s>>>(c->d_scal, c->d_flag, dv, w, u, p, sv, x, r, n, o.norm_type, c->d_part);
     }
@@ -751,6 +757,22 @@ static int solve_cg_sr(pyn_ctx* c, DMat& A, const double* b, double* x, const py
     }
     info->spmv_ms = acc / prof_n;
     info->spmv_launches = prof_n;
+    acc = 0;
+    for (int k = 0; k < prof_n; ++k) {
+      float t = 0;
+      PYN_HIP(hipEventElapsedTime(&t, c->prof_ev[2 * k + 1], c->prof_ev[2 * prof_max + k]));
+      acc += t;
+    }
+    info->reduce_ms = acc / prof_n;
+    if (overlap) {
+      acc = 0;
+      for (int k = 0; k < prof_n; ++k) {
+        float t = 0;
+        PYN_HIP(hipEventElapsedTime(&t, c->prof_ev[4 * prof_max + 2 * k], c->prof_ev[4 * prof_max + 2 * k + 1]));
+        acc += t;
+      }
+      info->halo_ms = acc / prof_n;
+    }
   }
   info->iters = c->h_flag[F_ITERS];
   info->reason = c->h_flag[F_REASON] ? c->h_flag[F_REASON] : PYN_DIVERGED_ITS;
