@@ -235,13 +235,8 @@ __device__ __forceinline__ void lat_store(const LatArgs& T, int x0, int y0, cons
       const double va = fr[u] ? (diag[u] ? 1.0 : 0.0) : (fc[u] ? 0.0 : v[u]);
       const double vr = fr[u] ? (diag[u] ? 1.0 : 0.0) : (fc[u] ? -v[u] : 0.0);
       if (lo[u] >= 0) {
-        if (T.ablate == 7) {   // experiment: streaming (non-temporal) stores
-          __builtin_nontemporal_store(va, &outA[lo[u]]);
-          if (outR) __builtin_nontemporal_store(vr, &outR[lo[u]]);
-        } else {
-          outA[lo[u]] = va;
-          if (outR) outR[lo[u]] = vr;
-        }
+        outA[lo[u]] = va;
+        if (outR) outR[lo[u]] = vr;
       }
     }
   }
@@ -269,13 +264,8 @@ __device__ __forceinline__ void lat_store_plain(const LatArgs& T, const double* 
     for (int j = 0; j < PER; ++j) {
       const int i = lane + 64 * j;
       if (i < LINE) {
-        if (T.ablate == 7) {
-          __builtin_nontemporal_store(v[j], &outA[base + i]);
-          if (outR) __builtin_nontemporal_store(0.0, &outR[base + i]);
-        } else {
-          outA[base + i] = v[j];
-          if (outR) outR[base + i] = 0.0;
-        }
+        outA[base + i] = v[j];
+        if (outR) outR[base + i] = 0.0;
       }
     }
   }
