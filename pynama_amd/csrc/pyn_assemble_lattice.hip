@@ -24,6 +24,7 @@ struct LatArgs {
   const int32_t* zord;     // [npl]
   int nx, ny, npl, p_own0, n_own;
   int ntx, nty;            // tiles per direction
+  int bz0, bzs;            // matrix-free products over a subset of the z-tiles: tile layer = bz0 + k * bzs
   int std_lat;             // P[j] == j*nx*ny, all planes owned, standard z order: plane bases, z codes AND row offsets
                            // come from arithmetic (no index loads at all)
   int ablate;              // diagnostics (PYNAMA_LATTICE_ABLATE): 1 no element phase, 4 no plain-tile store path,
@@ -672,7 +673,7 @@ __global__ void __launch_bounds__(256) lattice_matfree_laplace_kernel(LatArgs T,
   double dot = 0.0;
   for (int tb = blockIdx.x; tb < n_tiles; tb += gridDim.x) {   // gridDim.x is a multiple of 8 or >= n_tiles: XCD kept
     const int b = xcd_contiguous_tile(tb, n_tiles);
-    const int bx = b % T.ntx, by = (b / T.ntx) % T.nty, bz = b / (T.ntx * T.nty);
+    const int bx = b % T.ntx, by = (b / T.ntx) % T.nty, bz = T.bz0 + (b / (T.ntx * T.nty)) * T.bzs;
     const int x0 = bx * TX, y0 = by * TY, z0 = bz * TZ;
     // ---- node box
     for (int i = tid; i < MT::NB; i += 256) {
@@ -781,7 +782,7 @@ __global__ void __launch_bounds__(256) lattice_matfree_laplace_march_kernel(LatA
   double dot = 0.0;
   for (int tb = blockIdx.x; tb < n_tiles; tb += gridDim.x) {
     const int b = xcd_contiguous_tile(tb, n_tiles);
-    const int bx = b % T.ntx, by = (b / T.ntx) % T.nty, bz = b / (T.ntx * T.nty);
+    const int bx = b % T.ntx, by = (b / T.ntx) % T.nty, bz = T.bz0 + (b / (T.ntx * T.nty)) * T.bzs;
     const int x0 = bx * 15, y0 = by * 15, z0 = bz * TZ;
     {   // node box: all loads of a thread issued before the first LDS write
       constexpr int NJ = (MT::NB + 255) / 256;
@@ -968,7 +969,7 @@ __global__ void __launch_bounds__(256) lattice_matfree_kle_kernel(KleLatArgs K, 
   double dot = 0.0;
   for (int tb = blockIdx.x; tb < n_tiles; tb += gridDim.x) {
     const int b = xcd_contiguous_tile(tb, n_tiles);
-    const int bx = b % T.ntx, by = (b / T.ntx) % T.nty, bz = b / (T.ntx * T.nty);
+    const int bx = b % T.ntx, by = (b / T.ntx) % T.nty, bz = T.bz0 + (b / (T.ntx * T.nty)) * T.bzs;
     const int x0 = bx * TX, y0 = by * TY, z0 = bz * TZ;
     for (int i = tid; i < MT::NB; i += 256) {
       const int qx = i % MT::BX, qy = (i / MT::BX) % MT::BY, qz = i / (MT::BX * MT::BY);
@@ -1429,6 +1430,8 @@ static int lat_fill_args(pyn_ctx* c, LatArgs& T, double* A, double* Arhs, int* m
   T.p_own0 = L.p_own0;
   T.n_own = L.n_own;
   T.ntx = T.nty = 0;
+  T.bz0 = 0;
+  T.bzs = 1;
   T.std_lat = 0;
   T.q = TileArgs();
   T.q.w = c->quad[0].w;
@@ -1543,18 +1546,46 @@ int pyn_assemble_lattice(pyn_ctx* c, double* A, double* Arhs, bool* handled) {
 }
 
 
+// z-tile subset of a matrix-free product (halo / compute overlap across ranks): 0 = every tile; 1 = the tiles that read no
+// ghost plane (they can run while the halo exchange is in flight); 2 = the others (bottom and / or top layer of tiles of a
+// z-slab).  Returns the number of tile layers and fills T.bz0 / T.bzs.
+static int mf_select_layers(LatArgs& T, int ntz, int zsel) {
+  const int lo = T.p_own0 > 0 ? 1 : 0, hi = T.p_own0 + T.n_own < T.npl ? 1 : 0;   // ghost plane below / above
+  T.bz0 = 0;
+  T.bzs = 1;
+  if (zsel == 0) return ntz;
+  const int n_int = std::max(0, ntz - lo - hi);
+  if (zsel == 1) {
+    T.bz0 = lo;
+    return n_int;
+  }
+  if (n_int == 0) return ntz;                    // no interior layer: the "boundary" product is the whole product
+  if (lo && hi) {
+    T.bzs = ntz - 1;
+    return 2;
+  }
+  T.bz0 = hi ? ntz - 1 : 0;
+  return lo + hi;
+}
+
+struct MfLaunch {   // where a (partial) product runs and where its dot partials go
+  int zsel = 0, part_off = 0, max_grid = PYN_MAX_PARTIALS;
+  hipStream_t st = nullptr;
+};
+
 // ---- matrix-free Laplacian (see lattice_matfree_laplace_kernel)
 template <int TX, int TY, int TZ>
-static int launch_matfree(pyn_ctx* c, LatArgs& T, bool affine, const double* x, double* y, bool dot, int* grid_out) {
+static int launch_matfree(pyn_ctx* c, LatArgs& T, bool affine, const double* x, double* y, bool dot, const MfLaunch& L, int* grid_out) {
   using MT = MfTile<TX, TY, TZ>;
   T.ntx = (T.nx + TX - 1) / TX;
   T.nty = (T.ny + TY - 1) / TY;
-  const int ntz = (T.n_own + TZ - 1) / TZ;
-  const int n_tiles = T.ntx * T.nty * ntz;
-  const int grid = std::min(n_tiles, PYN_MAX_PARTIALS);   // 2048: a multiple of 8, the XCD mapping survives the stride
+  const int n_tiles = T.ntx * T.nty * mf_select_layers(T, (T.n_own + TZ - 1) / TZ, L.zsel);
+  const int grid = std::min(n_tiles, L.max_grid);   // a multiple of 8 whenever it is smaller than n_tiles: the XCD mapping survives
+  if (grid_out) *grid_out = grid;
+  if (grid == 0) return PYN_OK;
   const int* flag = dot ? c->d_flag : nullptr;
-  double* part = dot ? c->d_part : nullptr;
-  hipStream_t s = c->stream;
+  double* part = dot ? c->d_part + L.part_off : nullptr;
+  hipStream_t s = L.st;
   if (affine) {
     if (dot)
       lattice_matfree_laplace_kernel<TX, TY, TZ, true, true><<<grid, 256, MT::BYTES, s>>>(T, x, y, flag, part, n_tiles);
@@ -1567,24 +1598,23 @@ static int launch_matfree(pyn_ctx* c, LatArgs& T, bool affine, const double* x, 
       lattice_matfree_laplace_kernel<TX, TY, TZ, false, false><<<grid, 256, MT::BYTES, s>>>(T, x, y, flag, part, n_tiles);
   }
   PYN_HIP(hipGetLastError());
-  if (grid_out) *grid_out = grid;
   return PYN_OK;
 }
 
 template <int TZ>
-static int launch_matfree_march(pyn_ctx* c, LatArgs& T, const double* x, double* y, bool dot, int* grid_out) {
+static int launch_matfree_march(pyn_ctx* c, LatArgs& T, const double* x, double* y, bool dot, const MfLaunch& L, int* grid_out) {
   using MT = MfTile<15, 15, TZ>;
   T.ntx = (T.nx + 14) / 15;
   T.nty = (T.ny + 14) / 15;
-  const int ntz = (T.n_own + TZ - 1) / TZ;
-  const int n_tiles = T.ntx * T.nty * ntz;
-  const int grid = std::min(n_tiles, PYN_MAX_PARTIALS);
-  if (dot)
-    lattice_matfree_laplace_march_kernel<TZ, true><<<grid, 256, MT::BYTES, c->stream>>>(T, x, y, c->d_flag, c->d_part, n_tiles);
-  else
-    lattice_matfree_laplace_march_kernel<TZ, false><<<grid, 256, MT::BYTES, c->stream>>>(T, x, y, nullptr, nullptr, n_tiles);
-  PYN_HIP(hipGetLastError());
+  const int n_tiles = T.ntx * T.nty * mf_select_layers(T, (T.n_own + TZ - 1) / TZ, L.zsel);
+  const int grid = std::min(n_tiles, L.max_grid);
   if (grid_out) *grid_out = grid;
+  if (grid == 0) return PYN_OK;
+  if (dot)
+    lattice_matfree_laplace_march_kernel<TZ, true><<<grid, 256, MT::BYTES, L.st>>>(T, x, y, c->d_flag, c->d_part + L.part_off, n_tiles);
+  else
+    lattice_matfree_laplace_march_kernel<TZ, false><<<grid, 256, MT::BYTES, L.st>>>(T, x, y, nullptr, nullptr, n_tiles);
+  PYN_HIP(hipGetLastError());
   return PYN_OK;
 }
 
@@ -1592,8 +1622,9 @@ bool pyn_lattice_matfree_supported(const pyn_ctx* c) {
   return c->lat.valid && c->dim == 3 && c->nn == 8 && c->quad[0].ngp == 8;
 }
 
-// y = A x with A = the scalar Laplacian under the current Dirichlet mask (bc block size 1); x carries the ghost tail
-int pyn_lattice_matfree_spmv(pyn_ctx* c, const double* x, double* y, bool dot, int* grid_out) {
+// y = A x with A = the scalar Laplacian under the mask snapshot of pyn_matfree_set; x carries the ghost tail.
+// zsel / part_off / max_grid / st: see MfLaunch (whole product on the context stream by default).
+static int matfree_laplace_launch(pyn_ctx* c, const double* x, double* y, bool dot, const MfLaunch& L, int* grid_out) {
   PYN_CHECK(pyn_lattice_matfree_supported(c), "matrix-free operator: needs a Q1 hexahedral mesh with structured topology and the "
                                                "full-rule tables");
   PYN_CHECK(c->mf_set[PYN_MATFREE_LAPLACE], "matrix-free Laplacian: pyn_matfree_set first");
@@ -1606,36 +1637,37 @@ int pyn_lattice_matfree_spmv(pyn_ctx* c, const double* x, double* y, bool dot, i
   const int sel = tl ? atoi(tl) : (affine ? 6 : 0);
   if (affine && sel >= 6) {   // parallelepipeds: column-marching kernel, 15 x 15 x TZ rows per tile
     switch (sel) {
-      case 7: return launch_matfree_march<4>(c, T, x, y, dot, grid_out);
-      case 8: return launch_matfree_march<6>(c, T, x, y, dot, grid_out);
-      case 9: return launch_matfree_march<12>(c, T, x, y, dot, grid_out);
-      default: return launch_matfree_march<8>(c, T, x, y, dot, grid_out);
+      case 7: return launch_matfree_march<4>(c, T, x, y, dot, L, grid_out);
+      case 8: return launch_matfree_march<6>(c, T, x, y, dot, L, grid_out);
+      case 9: return launch_matfree_march<12>(c, T, x, y, dot, L, grid_out);
+      default: return launch_matfree_march<8>(c, T, x, y, dot, L, grid_out);
     }
   }
   switch (sel) {
-    case 1: PYN_TRY((launch_matfree<16, 8, 4>(c, T, affine, x, y, dot, grid_out))); break;
-    case 2: PYN_TRY((launch_matfree<8, 8, 8>(c, T, affine, x, y, dot, grid_out))); break;
-    case 3: PYN_TRY((launch_matfree<16, 4, 4>(c, T, affine, x, y, dot, grid_out))); break;
-    case 4: PYN_TRY((launch_matfree<32, 4, 4>(c, T, affine, x, y, dot, grid_out))); break;
-    case 5: PYN_TRY((launch_matfree<12, 6, 6>(c, T, affine, x, y, dot, grid_out))); break;
-    default: PYN_TRY((launch_matfree<16, 8, 8>(c, T, affine, x, y, dot, grid_out))); break;
+    case 1: PYN_TRY((launch_matfree<16, 8, 4>(c, T, affine, x, y, dot, L, grid_out))); break;
+    case 2: PYN_TRY((launch_matfree<8, 8, 8>(c, T, affine, x, y, dot, L, grid_out))); break;
+    case 3: PYN_TRY((launch_matfree<16, 4, 4>(c, T, affine, x, y, dot, L, grid_out))); break;
+    case 4: PYN_TRY((launch_matfree<32, 4, 4>(c, T, affine, x, y, dot, L, grid_out))); break;
+    case 5: PYN_TRY((launch_matfree<12, 6, 6>(c, T, affine, x, y, dot, L, grid_out))); break;
+    default: PYN_TRY((launch_matfree<16, 8, 8>(c, T, affine, x, y, dot, L, grid_out))); break;
   }
   return PYN_OK;
 }
 
 template <int TX, int TY, int TZ>
-static int launch_matfree_kle(pyn_ctx* c, KleLatArgs& K, bool affine, const double* x, double* y, bool dot, int* grid_out) {
+static int launch_matfree_kle(pyn_ctx* c, KleLatArgs& K, bool affine, const double* x, double* y, bool dot, const MfLaunch& L, int* grid_out) {
   using MT = MfTile<TX, TY, TZ>;
   LatArgs& T = K.L;
   T.ntx = (T.nx + TX - 1) / TX;
   T.nty = (T.ny + TY - 1) / TY;
-  const int ntz = (T.n_own + TZ - 1) / TZ;
-  const int n_tiles = T.ntx * T.nty * ntz;
-  const int grid = std::min(n_tiles, PYN_MAX_PARTIALS);
+  const int n_tiles = T.ntx * T.nty * mf_select_layers(T, (T.n_own + TZ - 1) / TZ, L.zsel);
+  const int grid = std::min(n_tiles, L.max_grid);
+  if (grid_out) *grid_out = grid;
+  if (grid == 0) return PYN_OK;
   const size_t lds = (size_t)(MT::NB + MT::NR) * 3 * sizeof(double) + ((MT::NB + 7) & ~7);
   const int* flag = dot ? c->d_flag : nullptr;
-  double* part = dot ? c->d_part : nullptr;
-  hipStream_t s = c->stream;
+  double* part = dot ? c->d_part + L.part_off : nullptr;
+  hipStream_t s = L.st;
   if (affine) {
     if (dot)
       lattice_matfree_kle_kernel<TX, TY, TZ, true, true><<<grid, 256, lds, s>>>(K, x, y, flag, part, n_tiles);
@@ -1648,12 +1680,11 @@ static int launch_matfree_kle(pyn_ctx* c, KleLatArgs& K, bool affine, const doub
       lattice_matfree_kle_kernel<TX, TY, TZ, false, false><<<grid, 256, lds, s>>>(K, x, y, flag, part, n_tiles);
   }
   PYN_HIP(hipGetLastError());
-  if (grid_out) *grid_out = grid;
   return PYN_OK;
 }
 
-// y = K x with K = the KLE stiffness under the current per-DOF Dirichlet mask (pyn_matfree_set supplied alpha_d, alpha_w and took the mask)
-int pyn_lattice_matfree_kle_spmv(pyn_ctx* c, const double* x, double* y, bool dot, int* grid_out) {
+// y = K x with K = the KLE stiffness under the per-DOF mask snapshot (pyn_matfree_set supplied alpha_d, alpha_w and took the mask)
+static int matfree_kle_launch(pyn_ctx* c, const double* x, double* y, bool dot, const MfLaunch& L, int* grid_out) {
   PYN_CHECK(pyn_lattice_matfree_supported(c) && c->quad[1].ngp == 1,
             "matrix-free operator: needs a Q1 hexahedral mesh with structured topology and the full- and reduced-rule tables");
   PYN_CHECK(c->mf_set[PYN_MATFREE_KLE], "matrix-free KLE operator: pyn_matfree_set first");
@@ -1670,12 +1701,35 @@ int pyn_lattice_matfree_kle_spmv(pyn_ctx* c, const double* x, double* y, bool do
   const bool affine = mesh_aff == 1 && K.L.q.aff != nullptr && c->aff_standard;
   const char* tl = getenv("PYNAMA_MATFREE_TILE");
   switch (tl ? atoi(tl) : 0) {
-    case 1: PYN_TRY((launch_matfree_kle<16, 8, 4>(c, K, affine, x, y, dot, grid_out))); break;
-    case 2: PYN_TRY((launch_matfree_kle<6, 6, 6>(c, K, affine, x, y, dot, grid_out))); break;
-    case 3: PYN_TRY((launch_matfree_kle<16, 4, 4>(c, K, affine, x, y, dot, grid_out))); break;
-    default: PYN_TRY((launch_matfree_kle<8, 8, 8>(c, K, affine, x, y, dot, grid_out))); break;
+    case 1: PYN_TRY((launch_matfree_kle<16, 8, 4>(c, K, affine, x, y, dot, L, grid_out))); break;
+    case 2: PYN_TRY((launch_matfree_kle<6, 6, 6>(c, K, affine, x, y, dot, L, grid_out))); break;
+    case 3: PYN_TRY((launch_matfree_kle<16, 4, 4>(c, K, affine, x, y, dot, L, grid_out))); break;
+    default: PYN_TRY((launch_matfree_kle<8, 8, 8>(c, K, affine, x, y, dot, L, grid_out))); break;
   }
   return PYN_OK;
+}
+
+int pyn_lattice_matfree_spmv(pyn_ctx* c, const double* x, double* y, bool dot, int* grid_out) {
+  MfLaunch L;
+  L.st = c->stream;
+  return matfree_laplace_launch(c, x, y, dot, L, grid_out);
+}
+
+int pyn_lattice_matfree_kle_spmv(pyn_ctx* c, const double* x, double* y, bool dot, int* grid_out) {
+  MfLaunch L;
+  L.st = c->stream;
+  return matfree_kle_launch(c, x, y, dot, L, grid_out);
+}
+
+// part of a product (op = PYN_MATFREE_*): zsel 1 = the tiles that read no ghost plane, 2 = the others (see mf_select_layers)
+int pyn_lattice_matfree_part(pyn_ctx* c, int op, const double* x, double* y, bool dot, int zsel, int part_off, int max_grid, hipStream_t st,
+                             int* grid_out) {
+  MfLaunch L;
+  L.zsel = zsel;
+  L.part_off = part_off;
+  L.max_grid = max_grid;
+  L.st = st;
+  return op == PYN_MATFREE_KLE ? matfree_kle_launch(c, x, y, dot, L, grid_out) : matfree_laplace_launch(c, x, y, dot, L, grid_out);
 }
 
 // Node graph of a lattice whose numbering has the arithmetic shape (one rank, or a rank's z-slab): built directly,

@@ -229,5 +229,7 @@ int pyn_assemble_lattice(pyn_ctx* c, double* A, double* Arhs, bool* handled);   
 bool pyn_lattice_matfree_supported(const pyn_ctx* c);
 int pyn_lattice_matfree_spmv(pyn_ctx* c, const double* x, double* y, bool dot, int* grid_out);  // matrix-free Laplacian
 int pyn_lattice_matfree_kle_spmv(pyn_ctx* c, const double* x, double* y, bool dot, int* grid_out);  // matrix-free KLE stiffness
+int pyn_lattice_matfree_part(pyn_ctx* c, int op, const double* x, double* y, bool dot, int zsel, int part_off, int max_grid, hipStream_t st,
+                             int* grid_out);   // tiles without (zsel 1) / with (zsel 2) ghost planes: halo overlap
 int pyn_assemble_kle_lattice(pyn_ctx* c, double alpha_d, double alpha_w, double* K, double* Krhs, double* Rw, bool* handled);
 bool pyn_q1_mixed_tables_standard(const double* w, const double* H, const double* Hrs);

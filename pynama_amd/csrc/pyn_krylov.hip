@@ -674,7 +674,7 @@ static int solve_cg_sr(pyn_ctx* c, DMat& A, const double* b, double* x, const py
   const int check = o.fixed_iters > 0 ? 0 : 1;
   const bool multi = pyn_has_comm(c);
   const SellShape* S = sell ? pyn_sell_shape(c, A) : nullptr;
-  const bool overlap = multi && !c->neigh.empty() && !c->detached && S && S->int_begin >= 0 && !getenv("PYNAMA_NO_OVERLAP");
+  const bool overlap = multi && !c->neigh.empty() && !c->detached && (mf || (S && S->int_begin >= 0)) && !getenv("PYNAMA_NO_OVERLAP");
   if (getenv("PYNAMA_OVERLAP_REQUIRE")) PYN_CHECK(overlap, "halo/SpMV overlap not engaged (tests)");
 
   cgsr_setup_kernel<<<1, 1, 0, s>>>(c->d_scal, c->d_flag, check ? o.rtol : 0.0, check ? o.atol : 0.0, o.dtol);
@@ -706,10 +706,16 @@ static int solve_cg_sr(pyn_ctx* c, DMat& A, const double* b, double* x, const py
         PYN_HIP(hipEventRecord(c->ev_halo, c->comm_stream));
         if (prof) PYN_HIP(hipEventRecord(c->prof_ev[2 * prof_n], s));
         int g0 = 0, g1 = 0, g2 = 0;
-        PYN_TRY(pyn_sell_spmv_range(c, A, u, w, true, S->int_begin, S->int_end, 0, PYN_MAX_PARTIALS - 512, s, &g0));
-        PYN_HIP(hipStreamWaitEvent(s, c->ev_halo, 0));
-        PYN_TRY(pyn_sell_spmv_range(c, A, u, w, true, 0, S->int_begin, g0, 256, s, &g1));
-        PYN_TRY(pyn_sell_spmv_range(c, A, u, w, true, S->int_end, S->ns, g0 + g1, 256, s, &g2));
+        if (mf) {   // tiles that read no ghost plane, then (ghosts arrived) the bottom / top layers of tiles
+          PYN_TRY(pyn_lattice_matfree_part(c, o.matfree, u, w, true, 1, 0, PYN_MAX_PARTIALS - 512, s, &g0));
+          PYN_HIP(hipStreamWaitEvent(s, c->ev_halo, 0));
+          PYN_TRY(pyn_lattice_matfree_part(c, o.matfree, u, w, true, 2, g0, 512, s, &g1));
+        } else {
+          PYN_TRY(pyn_sell_spmv_range(c, A, u, w, true, S->int_begin, S->int_end, 0, PYN_MAX_PARTIALS - 512, s, &g0));
+          PYN_HIP(hipStreamWaitEvent(s, c->ev_halo, 0));
+          PYN_TRY(pyn_sell_spmv_range(c, A, u, w, true, 0, S->int_begin, g0, 256, s, &g1));
+          PYN_TRY(pyn_sell_spmv_range(c, A, u, w, true, S->int_end, S->ns, g0 + g1, 256, s, &g2));
+        }
         gsp = g0 + g1 + g2;
       } else {
         PYN_TRY(pyn_halo_exchange(c, u, A.bc));

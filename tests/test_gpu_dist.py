@@ -12,7 +12,10 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 @pytest.mark.parametrize("size,nelem,case", [(2, "9,8,11", "poisson-jitter"), (3, "16,15,17", "poisson"), (2, "7,6,9", "kle"),
-                                             (3, "8,7,10", "kle-jitter")])
+                                             (3, "8,7,10", "kle-jitter"),
+                                             # tall slabs: several layers of tiles per rank, so that the matrix-free products split
+                                             # into the tiles without ghost planes (overlapped with the halo exchange) and the rest
+                                             (2, "6,5,47", "poisson"), (3, "5,4,80", "poisson-jitter"), (2, "5,4,45", "kle")])
 def test_ranks_sharing_one_gpu(size, nelem, case):
     from pynama_amd import _lib
     cap = 4 << 20
@@ -20,6 +23,8 @@ def test_ranks_sharing_one_gpu(size, nelem, case):
         f.truncate(_lib.Context.shm_size(size, cap))
         f.flush()
         env = dict(os.environ, PYNAMA_SHM_CAP=str(cap))
+        if int(nelem.split(",")[2]) >= 40:       # tall slabs: the halo / product overlap must be engaged (assembled and matrix-free)
+            env["PYNAMA_OVERLAP_REQUIRE"] = "1"
         procs = [subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "dist_gpu_worker.py"), str(r), str(size), f.name, nelem, case],
                                   env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True) for r in range(size)]
         outs = []
