@@ -781,7 +781,7 @@ __global__ void __launch_bounds__(256) lattice_matfree_laplace_march_kernel(LatA
   }
   double dot = 0.0;
   for (int tb = blockIdx.x; tb < n_tiles; tb += gridDim.x) {
-    const int b = xcd_contiguous_tile(tb, n_tiles);
+    const int b = T.ablate == 6 ? tb : xcd_contiguous_tile(tb, n_tiles);
     const int bx = b % T.ntx, by = (b / T.ntx) % T.nty, bz = T.bz0 + (b / (T.ntx * T.nty)) * T.bzs;
     const int x0 = bx * 15, y0 = by * 15, z0 = bz * TZ;
     {   // node box: all loads of a thread issued before the first LDS write
