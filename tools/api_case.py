@@ -1,0 +1,27 @@
+#!/usr/bin/env python3
+"""The reference's own call sequence (UniformFlow: setUp, setUpSolver, solveKLE) on an n^3 box through the drop-in classes, timed.
+usage: api_case.py n [PETSc-style options, e.g. -pynama_mat_free]"""
+import os, sys, time, yaml
+sys.path.insert(0, os.getcwd())
+import pynama_amd
+pynama_amd.install_reference_layout()
+from cases.uniform import UniformFlow
+CASES = os.path.join(os.path.dirname(pynama_amd.__file__), "cases")
+with open(os.path.join(CASES, 'uniform.yaml')) as f:
+    y = yaml.load(f, Loader=yaml.Loader)
+from common.options import Options
+Options(["-ksp_type", "cg", "-pc_type", "jacobi", "-ksp_rtol", "1e-10", "-ksp_norm_type", "unpreconditioned"] + sys.argv[2:])
+n = int(sys.argv[1])
+t0 = time.time()
+fem = UniformFlow(y, case='uniform', lower=[0, 0, 0], upper=[1, 1, 1], nelem=[n, n, n], ngl=2)
+t1 = time.time()
+fem.setUp()
+t2 = time.time()
+fem.setUpSolver()
+t3 = time.time()
+ev, ew = fem.generateExactVecs()
+t4 = time.time()
+fem.solveKLE(time=0.0, vort=ew)
+fem.dom.ctx.sync()
+t5 = time.time()
+print(f"n={n}: construct {t1-t0:.2f}s setUp {t2-t1:.2f}s setUpSolver {t3-t2:.2f}s exact {t4-t3:.2f}s solveKLE {t5-t4:.2f}s its {fem.solver.getIterationNumber()} err {(ev - fem.vel).norm(norm_type=3):.2e}")
