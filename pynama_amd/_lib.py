@@ -68,7 +68,7 @@ SIGNATURES = {
     "pyn_bc_set": [_P, _I, _P],
     "pyn_csr_symbolic": [_P],
     "pyn_csr_info": [_P, C.POINTER(_L), C.POINTER(_L)],
-    "pyn_csr_get": [_P, _pi32, _pi32],
+    "pyn_csr_get": [_P, C.c_void_p, C.c_void_p],
     "pyn_patch_plan_set": [_P, _I, _P, _P],
     "pyn_patch_plan_set_kind": [_P, _I, _I, _P, _P],
     "pyn_mat_create": [_P, _I, _I, C.POINTER(_I)],
@@ -285,10 +285,11 @@ class Context:
         self.n_rows, self.nnzb = nr.value, nz.value
         return nr.value, nz.value
 
-    def csr_get(self):
+    def csr_get(self, cols=True):
+        """node graph on the host; cols=False copies the row offsets only (the column array is 27 x larger)"""
         rp = np.empty(self.n_rows + 1, np.int32)
-        ci = np.empty(self.nnzb, np.int32)
-        _check(self.lib.pyn_csr_get(self.h, rp, ci))
+        ci = np.empty(self.nnzb, np.int32) if cols else None
+        _check(self.lib.pyn_csr_get(self.h, rp.ctypes.data_as(C.c_void_p), ci.ctypes.data_as(C.c_void_p) if cols else None))
         return rp, ci
 
     def patch_plan_set(self, patch_ptr, patch_rows, kind=0):

@@ -614,6 +614,11 @@ class DMPlexDom(object):
     def getMatIndices(self):
         """Symbolic phase on the GPU (replaces the per-row Python loop of dmplex.py:305-333).
         Returns the reference's tuple; ind_d / ind_o are lazy DeviceGraph views."""
+        if self.comm.size == 1:        # every column is on-process: the row offsets are all that is needed
+            self.ctx.csr_symbolic()
+            rp, _ = self.ctx.csr_get(cols=False)
+            return (self.rStart, self.rEnd, np.diff(rp).astype(np.int32), np.zeros(self.nOwned, np.int32),
+                    DeviceGraph(self, True), DeviceGraph(self, False))
         rp, ci = self._hostGraph()
         cols = self._local2global(ci)
         inside = (cols >= self.rStart) & (cols < self.rEnd)
