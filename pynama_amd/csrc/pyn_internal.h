@@ -216,6 +216,8 @@ bool pyn_sell_supported(const DMat& A);
 int pyn_sell_spmv(pyn_ctx* c, const DMat& A, const double* x, double* y, bool dot, int* grid_out);
 void pyn_sell_drop_structure(pyn_ctx* c);
 const SellShape* pyn_sell_shape(pyn_ctx* c, const DMat& A);
+int pyn_sell_spmv_range2(pyn_ctx* c, const DMat& A, const double* x, double* y, bool dot, int64_t a0, int64_t a1, int64_t b0,
+                         int64_t b1, int poff, int max_grid, hipStream_t st, int* grid_out);
 int pyn_sell_spmv_range(pyn_ctx* c, const DMat& A, const double* x, double* y, bool dot, int64_t s0, int64_t s1, int poff,
                         int max_grid, hipStream_t st, int* grid_out);
 int pyn_lattice_detect(pyn_ctx* c, const int32_t* conn_host);  // pyn_assemble_tiled.hip

@@ -235,7 +235,7 @@ __global__ void cg_scalar_beta_kernel(double* scal, int* flag, int norm_type, in
 //   p = u + beta p ; s = w + beta s ; x += alpha p ; r -= alpha s
 // Same iterates as standard PCG in exact arithmetic; 3-4 launches and ONE all-reduce (3 doubles) per
 // iteration instead of 7 launches and two all-reduces: the variant used when nranks > 1.
-enum { S_GOLD = 10, S_AOLD = 11 };
+enum { S_GOLD = 10, S_AOLD = 11 };   // second slot pair of the fused scalar step: S_GOLD + 2, S_AOLD + 2
 
 __global__ void __launch_bounds__(256) cgsr_init_kernel(const double* __restrict__ b, const double* __restrict__ dinv,
                                                         double* __restrict__ x, double* __restrict__ r, double* __restrict__ u,
@@ -250,33 +250,6 @@ __global__ void __launch_bounds__(256) cgsr_init_kernel(const double* __restrict
     u[i] = ui;
     p[i] = 0.0;
     sv[i] = 0.0;
-    g += ri * ui;
-    nn += norm_type == PYN_NORM_PRECONDITIONED ? ui * ui : ri * ri;
-  }
-  block_partial(g, part + PYN_MAX_PARTIALS);
-  __syncthreads();
-  block_partial(nn, part + 2 * PYN_MAX_PARTIALS);
-}
-
-__global__ void __launch_bounds__(256) cgsr_update_kernel(const double* __restrict__ scal, const int* __restrict__ flag,
-                                                          const double* __restrict__ dinv, const double* __restrict__ w,
-                                                          double* __restrict__ u, double* __restrict__ p,
-                                                          double* __restrict__ sv, double* __restrict__ x,
-                                                          double* __restrict__ r, int64_t n, int norm_type,
-                                                          double* __restrict__ part) {
-  if (flag[F_DONE]) return;
-  const double alpha = scal[S_ALPHA], beta = scal[S_BETA];
-  double g = 0.0, nn = 0.0;
-  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
-    const double pi = u[i] + beta * p[i];
-    const double si = w[i] + beta * sv[i];
-    p[i] = pi;
-    sv[i] = si;
-    x[i] += alpha * pi;
-    const double ri = r[i] - alpha * si;
-    r[i] = ri;
-    const double ui = dinv ? dinv[i] * ri : ri;
-    u[i] = ui;
     g += ri * ui;
     nn += norm_type == PYN_NORM_PRECONDITIONED ? ui * ui : ri * ri;
   }
@@ -344,23 +317,103 @@ __device__ inline void cgsr_scalar_step(double* scal, int* flag, int norm_type, 
   scal[S_BETA] = beta;
 }
 
+// SCAL: the scalar step of iteration `it` >= 1 (convergence test on the all-reduced sums in S_TMP0.., alpha, beta) is
+// evaluated by every block from read-only inputs instead of by a one-thread launch in front of this kernel: across
+// ranks that launch sits on the critical path of every iteration.  gamma_old / alpha_old alternate between two slot
+// pairs (read parity it & 1, write the other) so that block 0 publishing the new pair never races with a block that
+// still reads the old one; block 0 alone writes the flags, the history and the reported scalars.  A block that starts
+// after block 0 raised F_DONE returns at the top, which is the decision it would have reached itself.
+template <bool SCAL>
+__global__ void __launch_bounds__(256) cgsr_update_kernel(double* __restrict__ scal, int* __restrict__ flag,
+                                                          const double* __restrict__ dinv, const double* __restrict__ w,
+                                                          double* __restrict__ u, double* __restrict__ p,
+                                                          double* __restrict__ sv, double* __restrict__ x,
+                                                          double* __restrict__ r, int64_t n, int norm_type,
+                                                          double* __restrict__ part, int it, int maxit, int check,
+                                                          double* __restrict__ hist, int hist_cap) {
+  if (flag[F_DONE]) return;
+  double alpha, beta;
+  if (SCAL) {
+    const double delta = scal[S_TMP0], gamma = scal[S_TMP0 + 1], nn = scal[S_TMP0 + 2];
+    const double rn = norm_type == PYN_NORM_NATURAL ? sqrt(fabs(gamma)) : sqrt(nn);
+    const int rd = (it & 1) ? 0 : 2, wr = 2 - rd;       // iteration 0 (cgsr_scalar_kernel) wrote S_GOLD / S_AOLD
+    const bool lead = blockIdx.x == 0 && threadIdx.x == 0;
+    int reason = 0;
+    if (!(rn == rn)) reason = PYN_DIVERGED_NANORINF;
+    else if (check && rn <= scal[S_TTOL]) reason = rn <= scal[S_ATOL] ? PYN_CONVERGED_ATOL : PYN_CONVERGED_RTOL;
+    else if (check && rn >= scal[S_DLIM]) reason = PYN_DIVERGED_DTOL;
+    else if (it >= maxit) reason = check ? PYN_DIVERGED_ITS : PYN_CONVERGED_ITS;
+    beta = gamma / scal[S_GOLD + rd];
+    alpha = gamma / (delta - beta * gamma / scal[S_AOLD + rd]);
+    if (!reason && (!(delta > 0.0) || !(alpha == alpha))) reason = PYN_DIVERGED_BREAKDOWN;
+    if (lead) {
+      flag[F_ITERS] = it;
+      if (hist && it < hist_cap) hist[it] = rn;
+      scal[S_RNORM] = rn;
+      if (reason) {
+        flag[F_REASON] = reason;
+        flag[F_DONE] = 1;
+      } else {
+        scal[S_GOLD + wr] = gamma;
+        scal[S_AOLD + wr] = alpha;
+        scal[S_ALPHA] = alpha;
+        scal[S_BETA] = beta;
+      }
+    }
+    if (reason) return;
+  } else {
+    alpha = scal[S_ALPHA];
+    beta = scal[S_BETA];
+  }
+  double g = 0.0, nn = 0.0;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    const double pi = u[i] + beta * p[i];
+    const double si = w[i] + beta * sv[i];
+    p[i] = pi;
+    sv[i] = si;
+    x[i] += alpha * pi;
+    const double ri = r[i] - alpha * si;
+    r[i] = ri;
+    const double ui = dinv ? dinv[i] * ri : ri;
+    u[i] = ui;
+    g += ri * ui;
+    nn += norm_type == PYN_NORM_PRECONDITIONED ? ui * ui : ri * ri;
+  }
+  block_partial(g, part + PYN_MAX_PARTIALS);
+  __syncthreads();
+  block_partial(nn, part + 2 * PYN_MAX_PARTIALS);
+}
+
 template <bool FUSE>
 __global__ void __launch_bounds__(256) cgsr_reduce_kernel(const double* __restrict__ part, int n0, int n1, double* scal,
                                                           int* flag, int norm_type, int maxit, int check, double* hist,
                                                           int hist_cap, int first) {
   if (flag[F_DONE]) return;
-  __shared__ double sm[4];
-  for (int sl = 0; sl < 3; ++sl) {
-    const int nb = sl == 0 ? n0 : n1;
-    double acc = 0.0;
-    for (int i = threadIdx.x; i < nb; i += 256) acc += part[sl * PYN_MAX_PARTIALS + i];
-    acc = wsum(acc);
-    if ((threadIdx.x & 63) == 0) sm[threadIdx.x >> 6] = acc;
-    __syncthreads();
-    if (threadIdx.x == 0) scal[S_TMP0 + sl] = sm[0] + sm[1] + sm[2] + sm[3];
-    __syncthreads();
+  __shared__ double sm[3][4];
+  // the three slices are loaded together (24 independent loads per lane, PYN_MAX_PARTIALS = 8 x 256) and share one
+  // barrier; per-lane accumulation order is the ascending one of a plain strided loop
+  double v[3][PYN_MAX_PARTIALS / 256];
+#pragma unroll
+  for (int j = 0; j < PYN_MAX_PARTIALS / 256; ++j) {
+    const int i = threadIdx.x + 256 * j;
+    v[0][j] = i < n0 ? part[i] : 0.0;
+    v[1][j] = i < n1 ? part[PYN_MAX_PARTIALS + i] : 0.0;
+    v[2][j] = i < n1 ? part[2 * PYN_MAX_PARTIALS + i] : 0.0;
   }
-  if (FUSE && threadIdx.x == 0) cgsr_scalar_step(scal, flag, norm_type, maxit, check, hist, hist_cap, first);
+#pragma unroll
+  for (int sl = 0; sl < 3; ++sl) {
+    double acc = 0.0;
+#pragma unroll
+    for (int j = 0; j < PYN_MAX_PARTIALS / 256; ++j) acc += v[sl][j];
+    acc = wsum(acc);
+    if ((threadIdx.x & 63) == 0) sm[sl][threadIdx.x >> 6] = acc;
+  }
+  __syncthreads();
+  if (threadIdx.x < 3) scal[S_TMP0 + threadIdx.x] = sm[threadIdx.x][0] + sm[threadIdx.x][1] + sm[threadIdx.x][2] + sm[threadIdx.x][3];
+  if (FUSE) {
+    __syncthreads();
+    if (threadIdx.x == 0) cgsr_scalar_step(scal, flag, norm_type, maxit, check, hist, hist_cap, first);
+  }
 }
 
 __global__ void cgsr_scalar_kernel(double* scal, int* flag, int norm_type, int maxit, int check, double* hist, int hist_cap,
@@ -676,6 +729,7 @@ static int solve_cg_sr(pyn_ctx* c, DMat& A, const double* b, double* x, const py
   const SellShape* S = sell ? pyn_sell_shape(c, A) : nullptr;
   const bool overlap = multi && !c->neigh.empty() && !c->detached && (mf || (S && S->int_begin >= 0)) && !getenv("PYNAMA_NO_OVERLAP");
   if (getenv("PYNAMA_OVERLAP_REQUIRE")) PYN_CHECK(overlap, "halo/SpMV overlap not engaged (tests)");
+  const bool no_fuse = getenv("PYNAMA_NO_SCALAR_FUSE") != nullptr;   // diagnostics: scalar step in its own launch
 
   cgsr_setup_kernel<<<1, 1, 0, s>>>(c->d_scal, c->d_flag, check ? o.rtol : 0.0, check ? o.atol : 0.0, o.dtol);
   cgsr_init_kernel<<<g, 256, 0, s>>>(b, dv, x, r, u, p, sv, n, o.norm_type, c->d_part);
@@ -713,8 +767,8 @@ static int solve_cg_sr(pyn_ctx* c, DMat& A, const double* b, double* x, const py
         } else {
           PYN_TRY(pyn_sell_spmv_range(c, A, u, w, true, S->int_begin, S->int_end, 0, PYN_MAX_PARTIALS - 512, s, &g0));
           PYN_HIP(hipStreamWaitEvent(s, c->ev_halo, 0));
-          PYN_TRY(pyn_sell_spmv_range(c, A, u, w, true, 0, S->int_begin, g0, 256, s, &g1));
-          PYN_TRY(pyn_sell_spmv_range(c, A, u, w, true, S->int_end, S->ns, g0 + g1, 256, s, &g2));
+          // bottom and top boundary slices in one launch
+          PYN_TRY(pyn_sell_spmv_range2(c, A, u, w, true, 0, S->int_begin, S->int_end, S->ns, g0, 512, s, &g1));
         }
         gsp = g0 + g1 + g2;
       } else {
@@ -729,10 +783,13 @@ static int solve_cg_sr(pyn_ctx* c, DMat& A, const double* b, double* x, const py
       }
       if (prof) PYN_HIP(hipEventRecord(c->prof_ev[2 * prof_n + 1], s));
       const int first = (issued + k) == 0;
+      bool scal_in_update = false;
       if (multi) {
         cgsr_reduce_kernel<false><<<1, 256, 0, s>>>(c->d_part, gsp, g, c->d_scal, c->d_flag, o.norm_type, maxit, check, hist, hist_cap, first);
         PYN_TRY(allreduce_tmp(c, 3));
-        cgsr_scalar_kernel<<<1, 1, 0, s>>>(c->d_scal, c->d_flag, o.norm_type, maxit, check, hist, hist_cap, first);
+        // iteration 0 fixes the tolerances from ||r_0|| in its own launch; later scalar steps ride in the update kernel
+        scal_in_update = !first && !no_fuse;
+        if (!scal_in_update) cgsr_scalar_kernel<<<1, 1, 0, s>>>(c->d_scal, c->d_flag, o.norm_type, maxit, check, hist, hist_cap, first);
       } else {
         cgsr_reduce_kernel<true><<<1, 256, 0, s>>>(c->d_part, gsp, g, c->d_scal, c->d_flag, o.norm_type, maxit, check, hist, hist_cap, first);
       }
@@ -740,7 +797,10 @@ static int solve_cg_sr(pyn_ctx* c, DMat& A, const double* b, double* x, const py
         PYN_HIP(hipEventRecord(c->prof_ev[2 * prof_max + prof_n], s));
         ++prof_n;
       }
-      cgsr_update_kernel<<<g, 256, 0, s>>>(c->d_scal, c->d_flag, dv, w, u, p, sv, x, r, n, o.norm_type, c->d_part);
+      if (scal_in_update)
+        cgsr_update_kernel<true><<<g, 256, 0, s>>>(c->d_scal, c->d_flag, dv, w, u, p, sv, x, r, n, o.norm_type, c->d_part, issued + k, maxit, check, hist, hist_cap);
+      else
+        cgsr_update_kernel<false><<<g, 256, 0, s>>>(c->d_scal, c->d_flag, dv, w, u, p, sv, x, r, n, o.norm_type, c->d_part, 0, 0, 0, nullptr, 0);
     }
     issued += todo;
     PYN_HIP(hipMemcpyAsync(c->h_flag, c->d_flag, 8 * sizeof(int), hipMemcpyDeviceToHost, s));

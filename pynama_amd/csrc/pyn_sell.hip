@@ -152,13 +152,14 @@ template <bool DOT>
 __global__ void __launch_bounds__(256) sell_spmv_kernel(const int64_t* __restrict__ sptr, const int* __restrict__ sw,
                                                         const int32_t* __restrict__ scol, const double* __restrict__ sval,
                                                         const double* __restrict__ x, double* __restrict__ y, int64_t n_rows,
-                                                        int64_t n_slices, const int* __restrict__ flag, double* __restrict__ part, int64_t s_begin, int part_off) {
+                                                        int64_t n_slices, const int* __restrict__ flag, double* __restrict__ part, int64_t s_begin, int part_off, int64_t hole_begin, int64_t hole_len) {
   if (flag && flag[0]) return;
   const int lane = threadIdx.x & 63;
   const int64_t w0 = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
   const int64_t nw = ((int64_t)gridDim.x * blockDim.x) >> 6;
   double dot = 0.0;
-  for (int64_t s = s_begin + w0; s < n_slices; s += nw) {
+  for (int64_t sq = s_begin + w0; sq < n_slices; sq += nw) {   // n_slices: logical end (hole removed)
+    const int64_t s = sq >= hole_begin ? sq + hole_len : sq;
     const int64_t base = sptr[s] + lane;
     const int wd = sw[s];
     const double* __restrict__ v = sval + base;
@@ -256,7 +257,7 @@ __global__ void __launch_bounds__(256) sellp_spmv_kernel(const int64_t* __restri
                                                          int npat, const double* __restrict__ sval,
                                                          const double* __restrict__ x, double* __restrict__ y, int64_t n_rows,
                                                          int64_t n_slices, const int* __restrict__ flag,
-                                                         double* __restrict__ part, int64_t s_begin, int part_off) {
+                                                         double* __restrict__ part, int64_t s_begin, int part_off, int64_t hole_begin, int64_t hole_len) {
   extern __shared__ int32_t ltab[];  // [npat][PAT_W]
   __shared__ double smd[4];
   if (flag && flag[0]) return;
@@ -268,7 +269,8 @@ __global__ void __launch_bounds__(256) sellp_spmv_kernel(const int64_t* __restri
   const int64_t w0 = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
   const int64_t nw = ((int64_t)gridDim.x * blockDim.x) >> 6;
   double dot = 0.0;
-  for (int64_t s = s_begin + w0; s < n_slices; s += nw) {
+  for (int64_t sq = s_begin + w0; sq < n_slices; sq += nw) {   // n_slices: logical end (hole removed)
+    const int64_t s = sq >= hole_begin ? sq + hole_len : sq;
     const int64_t row = s * SH + lane;
     const int wd = sw[s];
     const double* __restrict__ v = sval + sptr[s] + lane;
@@ -306,7 +308,7 @@ __global__ void __launch_bounds__(256) sellb_spmv_kernel(const int64_t* __restri
                                                          int npat, const int32_t* __restrict__ scol,
                                                          const double* __restrict__ sval, const double* __restrict__ x,
                                                          double* __restrict__ y, int64_t n_rows, int br, int64_t n_slices,
-                                                         const int* __restrict__ flag, double* __restrict__ part, int64_t s_begin, int part_off) {
+                                                         const int* __restrict__ flag, double* __restrict__ part, int64_t s_begin, int part_off, int64_t hole_begin, int64_t hole_len) {
   extern __shared__ int32_t ltab[];  // [npat][PAT_W]
   __shared__ double smd[4];
   if (flag && flag[0]) return;
@@ -318,7 +320,8 @@ __global__ void __launch_bounds__(256) sellb_spmv_kernel(const int64_t* __restri
   const int64_t w0 = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
   const int64_t nw = ((int64_t)gridDim.x * blockDim.x) >> 6;
   double dot = 0.0;
-  for (int64_t s = s_begin + w0; s < n_slices; s += nw) {
+  for (int64_t sq = s_begin + w0; sq < n_slices; sq += nw) {   // n_slices: logical end (hole removed)
+    const int64_t s = sq >= hole_begin ? sq + hole_len : sq;
     const int64_t row = s * SH + lane;
     const bool live = row < n_rows;
     const int64_t node = live ? row / br : 0;
@@ -518,22 +521,22 @@ bool pyn_sell_supported(const DMat& A) { return A.bc == 1 || A.bc == 2 || A.bc =
 
 template <int BC>
 static int launch_block(pyn_ctx* c, const SellShape& S, const DMat& A, const double* x, double* y, bool dot, int grid,
-                        int64_t s0, int64_t s1, int poff, hipStream_t st) {
+                        int64_t s0, int64_t s1, int poff, int64_t hb, int64_t hl, hipStream_t st) {
   const int64_t n = c->n_owned * A.br;
   const size_t lds = (size_t)(c->sell_npat + 1) * PAT_W * sizeof(int32_t);
   const bool pat = c->sell_npat > 0;
   if (pat && dot)
     sellb_spmv_kernel<BC, true, true><<<grid, 256, lds, st>>>(S.ptr, S.w, c->sell_pid, c->sell_tab, c->sell_npat, nullptr,
-                                                                     A.sell_val, x, y, n, A.br, s1, c->d_flag, c->d_part, s0, poff);
+                                                                     A.sell_val, x, y, n, A.br, s1, c->d_flag, c->d_part, s0, poff, hb, hl);
   else if (pat)
     sellb_spmv_kernel<BC, true, false><<<grid, 256, lds, st>>>(S.ptr, S.w, c->sell_pid, c->sell_tab, c->sell_npat, nullptr,
-                                                                      A.sell_val, x, y, n, A.br, s1, nullptr, nullptr, s0, poff);
+                                                                      A.sell_val, x, y, n, A.br, s1, nullptr, nullptr, s0, poff, hb, hl);
   else if (dot)
     sellb_spmv_kernel<BC, false, true><<<grid, 256, 0, st>>>(S.ptr, S.w, nullptr, nullptr, 0, S.col, A.sell_val, x, y, n,
-                                                                    A.br, s1, c->d_flag, c->d_part, s0, poff);
+                                                                    A.br, s1, c->d_flag, c->d_part, s0, poff, hb, hl);
   else
     sellb_spmv_kernel<BC, false, false><<<grid, 256, 0, st>>>(S.ptr, S.w, nullptr, nullptr, 0, S.col, A.sell_val, x, y, n,
-                                                                     A.br, s1, nullptr, nullptr, s0, poff);
+                                                                     A.br, s1, nullptr, nullptr, s0, poff, hb, hl);
   return PYN_OK;
 }
 
@@ -546,10 +549,19 @@ const SellShape* pyn_sell_shape(pyn_ctx* c, const DMat& A) {
 // y = A x over the slices [s0, s1) on stream `st`; the fused dot partials go to d_part[poff .. poff + grid)
 int pyn_sell_spmv_range(pyn_ctx* c, const DMat& A, const double* x, double* y, bool dot, int64_t s0, int64_t s1, int poff,
                         int max_grid, hipStream_t st, int* grid_out) {
+  return pyn_sell_spmv_range2(c, A, x, y, dot, s0, s1, s1, s1, poff, max_grid, st, grid_out);
+}
+
+// the same over [a0, a1) U [b0, b1), a1 <= b0, in ONE launch (a rank's bottom and top boundary slices): the kernels walk the
+// logical range with the hole [a1, b0) cut out
+int pyn_sell_spmv_range2(pyn_ctx* c, const DMat& A, const double* x, double* y, bool dot, int64_t a0, int64_t a1, int64_t b0,
+                         int64_t b1, int poff, int max_grid, hipStream_t st, int* grid_out) {
   const SellShape* S = pyn_sell_shape(c, A);
   PYN_CHECK(S && A.sell_valid, "pyn_sell_ensure first");
   PYN_CHECK(!dot || A.br == A.bc, "fused dot needs a square block shape");
-  PYN_CHECK(s0 >= 0 && s1 <= S->ns && s0 <= s1, "bad slice range");
+  PYN_CHECK(a0 >= 0 && a0 <= a1 && a1 <= b0 && b0 <= b1 && b1 <= S->ns, "bad slice ranges");
+  const int64_t hb = a1, hl = b0 - a1;        // hole in logical coordinates
+  const int64_t s0 = a0, s1 = b1 - hl;        // logical range
   if (s0 == s1) {
     if (grid_out) *grid_out = 0;
     return PYN_OK;
@@ -561,23 +573,23 @@ int pyn_sell_spmv_range(pyn_ctx* c, const DMat& A, const double* x, double* y, b
       const size_t lds = (size_t)(c->sell_npat + 1) * PAT_W * sizeof(int32_t);
       if (dot)
         sellp_spmv_kernel<true><<<grid, 256, lds, st>>>(S->ptr, S->w, c->sell_pid, c->sell_tab, c->sell_npat, A.sell_val, x, y,
-                                                        c->n_owned, s1, c->d_flag, c->d_part, s0, poff);
+                                                        c->n_owned, s1, c->d_flag, c->d_part, s0, poff, hb, hl);
       else
         sellp_spmv_kernel<false><<<grid, 256, lds, st>>>(S->ptr, S->w, c->sell_pid, c->sell_tab, c->sell_npat, A.sell_val, x, y,
-                                                         c->n_owned, s1, nullptr, nullptr, s0, poff);
+                                                         c->n_owned, s1, nullptr, nullptr, s0, poff, hb, hl);
     } else if (dot) {
-      sell_spmv_kernel<true><<<grid, 256, 0, st>>>(S->ptr, S->w, S->col, A.sell_val, x, y, c->n_owned, s1, c->d_flag, c->d_part, s0, poff);
+      sell_spmv_kernel<true><<<grid, 256, 0, st>>>(S->ptr, S->w, S->col, A.sell_val, x, y, c->n_owned, s1, c->d_flag, c->d_part, s0, poff, hb, hl);
     } else {
-      sell_spmv_kernel<false><<<grid, 256, 0, st>>>(S->ptr, S->w, S->col, A.sell_val, x, y, c->n_owned, s1, nullptr, nullptr, s0, poff);
+      sell_spmv_kernel<false><<<grid, 256, 0, st>>>(S->ptr, S->w, S->col, A.sell_val, x, y, c->n_owned, s1, nullptr, nullptr, s0, poff, hb, hl);
     }
   } else if (A.bc == 1) {
-    PYN_TRY(launch_block<1>(c, *S, A, x, y, dot, grid, s0, s1, poff, st));
+    PYN_TRY(launch_block<1>(c, *S, A, x, y, dot, grid, s0, s1, poff, hb, hl, st));
   } else if (A.bc == 2) {
-    PYN_TRY(launch_block<2>(c, *S, A, x, y, dot, grid, s0, s1, poff, st));
+    PYN_TRY(launch_block<2>(c, *S, A, x, y, dot, grid, s0, s1, poff, hb, hl, st));
   } else if (A.bc == 3) {
-    PYN_TRY(launch_block<3>(c, *S, A, x, y, dot, grid, s0, s1, poff, st));
+    PYN_TRY(launch_block<3>(c, *S, A, x, y, dot, grid, s0, s1, poff, hb, hl, st));
   } else {
-    PYN_TRY(launch_block<6>(c, *S, A, x, y, dot, grid, s0, s1, poff, st));
+    PYN_TRY(launch_block<6>(c, *S, A, x, y, dot, grid, s0, s1, poff, hb, hl, st));
   }
   PYN_HIP(hipGetLastError());
   if (grid_out) *grid_out = grid;

@@ -2,7 +2,8 @@
 """Turn rocprofv3 result databases (rocpd sqlite, the default output of this ROCm) into the small text files
 committed under profiles/.
   rocprof_summary.py stats  <results.db> <out.csv> [out.md]     --kernel-trace --stats run
-  rocprof_summary.py pmc    <fetch.db> <write.db> <out.json>    --pmc FETCH_SIZE / --pmc WRITE_SIZE runs"""
+  rocprof_summary.py pmc    <fetch.db> <write.db> <out.json>    --pmc FETCH_SIZE / --pmc WRITE_SIZE runs
+  rocprof_summary.py timeline <results.db> <out.txt> [n]        last n dispatches of a --kernel-trace run: start, duration, gap"""
 import json
 import re
 import sqlite3
@@ -48,8 +49,22 @@ def pmc(fetch_db, write_db, out_json):
                                  "128-B request; separate --pmc passes)", "kernels": res}, f, indent=1)
 
 
+def timeline(db, out_txt, n=60):
+    """Back-to-back picture of the last `n` kernel dispatches (us): where an iteration's time goes between launches."""
+    con = sqlite3.connect(db)
+    rows = con.execute("select name, start, end from kernels order by start desc limit ?", (int(n),)).fetchall()[::-1]
+    with open(out_txt, "w") as f:
+        f.write("start_us  dur_us  gap_before_us  kernel\n")
+        t0, prev_end = rows[0][1], rows[0][1]
+        for name, s, e in rows:
+            f.write("%9.1f %7.1f %7.1f  %s\n" % ((s - t0) / 1e3, (e - s) / 1e3, (s - prev_end) / 1e3, short(name, 70)))
+            prev_end = e
+
+
 if __name__ == "__main__":
-    if sys.argv[1] == "stats":
+    if sys.argv[1] == "timeline":
+        timeline(*sys.argv[2:5])
+    elif sys.argv[1] == "stats":
         stats(*sys.argv[2:5])
     else:
         pmc(*sys.argv[2:5])
