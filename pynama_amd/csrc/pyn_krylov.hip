@@ -144,6 +144,120 @@ __global__ void __launch_bounds__(256) cg_p_kernel(const double* __restrict__ sc
   }
 }
 
+// ---- one-rank CG without reduction / scalar launches ------------------------------------------------
+// Without a communicator nothing has to leave the device between a kernel that produces partial sums and the kernel
+// that consumes the scalar: every block of the consumer sums the <= PYN_MAX_PARTIALS partials itself (16 KB out of L2,
+// the same per-lane order / wave / block tree as sum_partials_kernel, so all blocks hold the same bits as the separate
+// launch would) and evaluates the scalar recurrence from read-only inputs.  r.z alternates between S_RZ and S_RZ_B by
+// iteration parity: block 0 publishes the new value into the slot nobody reads in this launch.  Four launches per
+// iteration (two sum_partials, alpha, beta) disappear; block 0 alone writes flags, history and reported scalars.
+enum { S_RZ_B = 14 };
+
+__device__ inline void all_block_sum2(const double* __restrict__ pa, int na, const double* __restrict__ pb, int nb,
+                                      double& sa, double& sb) {
+  __shared__ double sm2[2][4];
+  double va[PYN_MAX_PARTIALS / 256], vb[PYN_MAX_PARTIALS / 256];
+#pragma unroll
+  for (int j = 0; j < PYN_MAX_PARTIALS / 256; ++j) {
+    const int i = threadIdx.x + 256 * j;
+    va[j] = i < na ? pa[i] : 0.0;
+    vb[j] = (pb && i < nb) ? pb[i] : 0.0;
+  }
+  double a = 0.0, b = 0.0;
+#pragma unroll
+  for (int j = 0; j < PYN_MAX_PARTIALS / 256; ++j) {
+    a += va[j];
+    b += vb[j];
+  }
+  a = wsum(a);
+  b = wsum(b);
+  if ((threadIdx.x & 63) == 0) {
+    sm2[0][threadIdx.x >> 6] = a;
+    sm2[1][threadIdx.x >> 6] = b;
+  }
+  __syncthreads();
+  sa = sm2[0][0] + sm2[0][1] + sm2[0][2] + sm2[0][3];
+  sb = sm2[1][0] + sm2[1][1] + sm2[1][2] + sm2[1][3];
+}
+
+// alpha = r.z / p.Ap from the product's partials part[0][0..gsp) ; x += alpha p ; r -= alpha Ap ;
+// partials: [1] r.z  [2] norm^2   (slot 0 is still being read by the other blocks)
+__global__ void __launch_bounds__(256) cg_update_selfred_kernel(double* __restrict__ scal, int* __restrict__ flag,
+                                                                const double* __restrict__ dinv, const double* __restrict__ p,
+                                                                const double* __restrict__ Ap, double* __restrict__ x,
+                                                                double* __restrict__ r, int64_t n, int norm_type,
+                                                                double* __restrict__ part, int gsp, int it) {
+  if (flag[F_DONE]) return;
+  double pap, unused;
+  all_block_sum2(part, gsp, nullptr, 0, pap, unused);
+  const bool lead = blockIdx.x == 0 && threadIdx.x == 0;
+  if (!(pap > 0.0)) {  // indefinite matrix / breakdown (also catches NaN)
+    if (lead) {
+      scal[S_PAP] = pap;
+      scal[S_ALPHA] = 0.0;
+      flag[F_REASON] = pap == pap ? PYN_DIVERGED_BREAKDOWN : PYN_DIVERGED_NANORINF;
+      flag[F_DONE] = 1;
+    }
+    return;
+  }
+  const double alpha = scal[(it & 1) ? S_RZ : S_RZ_B] / pap;
+  if (lead) {
+    scal[S_PAP] = pap;
+    scal[S_ALPHA] = alpha;
+  }
+  double rz = 0.0, nn = 0.0;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    x[i] += alpha * p[i];
+    double ri = r[i] - alpha * Ap[i];
+    r[i] = ri;
+    double zi = dinv ? dinv[i] * ri : ri;
+    rz += ri * zi;
+    nn += norm_type == PYN_NORM_PRECONDITIONED ? zi * zi : ri * ri;
+  }
+  block_partial(rz, part + PYN_MAX_PARTIALS);
+  __syncthreads();
+  block_partial(nn, part + 2 * PYN_MAX_PARTIALS);
+}
+
+// convergence test + beta from part[1..2][0..g) ; p = dinv r + beta p
+__global__ void __launch_bounds__(256) cg_p_selfred_kernel(double* __restrict__ scal, int* __restrict__ flag,
+                                                           const double* __restrict__ dinv, const double* __restrict__ r,
+                                                           double* __restrict__ p, int64_t n, const double* __restrict__ part,
+                                                           int g, int it, int norm_type, int maxit, int check,
+                                                           double* __restrict__ hist, int hist_cap) {
+  if (flag[F_DONE]) return;
+  double rz_new, nn;
+  all_block_sum2(part + PYN_MAX_PARTIALS, g, part + 2 * PYN_MAX_PARTIALS, g, rz_new, nn);
+  const double rn = norm_type == PYN_NORM_NATURAL ? sqrt(fabs(rz_new)) : sqrt(nn);
+  const int rd = (it & 1) ? S_RZ : S_RZ_B, wr = (it & 1) ? S_RZ_B : S_RZ;
+  const double beta = rz_new / scal[rd];
+  int reason = 0;
+  if (check) {
+    if (!(rn == rn)) reason = PYN_DIVERGED_NANORINF;
+    else if (rn <= scal[S_TTOL]) reason = rn <= scal[S_ATOL] ? PYN_CONVERGED_ATOL : PYN_CONVERGED_RTOL;
+    else if (rn >= scal[S_DLIM]) reason = PYN_DIVERGED_DTOL;
+    else if (it >= maxit) reason = PYN_DIVERGED_ITS;
+  } else if (it >= maxit) {
+    reason = PYN_CONVERGED_ITS;
+  }
+  if (blockIdx.x == 0 && threadIdx.x == 0) {
+    flag[F_ITERS] = it;
+    scal[S_RNORM] = rn;
+    if (hist && it < hist_cap) hist[it] = rn;
+    scal[S_BETA] = beta;
+    scal[wr] = rz_new;
+    if (reason) {
+      flag[F_REASON] = reason;
+      flag[F_DONE] = 1;
+    }
+  }
+  if (reason) return;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    double zi = dinv ? dinv[i] * r[i] : r[i];
+    p[i] = zi + beta * p[i];
+  }
+}
+
 // one block: out[s] = sum(part[s][0..nblocks))
 __global__ void __launch_bounds__(256) sum_partials_kernel(const double* __restrict__ part, int nslots, int nblocks,
                                                            double* __restrict__ out, const int* __restrict__ flag) {
@@ -641,6 +755,7 @@ static int solve_cg(pyn_ctx* c, DMat& A, const double* b, double* x, const pyn_s
   }
   int issued = 0;
   const int chunk = 32;
+  const bool selfred = !pyn_has_comm(c) && !getenv("PYNAMA_NO_CG_FUSE");
   const int prof_max = o.profile ? 256 : 0;
   while ((int)c->prof_ev.size() < 2 * prof_max) {
     hipEvent_t e;
@@ -662,6 +777,12 @@ static int solve_cg(pyn_ctx* c, DMat& A, const double* b, double* x, const pyn_s
       else
         spmv_kernel<32, true><<<gs, 256, 0, s>>>(c->d_rowptr, c->d_colidx, A.val, p, Ap, rows, A.br, A.bc, c->d_flag, c->d_part);
       if (prof) PYN_HIP(hipEventRecord(c->prof_ev[2 * prof_n++ + 1], s));
+      if (selfred) {   // one rank: the consumers sum the partials and step the scalars themselves
+        const int it = issued + k + 1;
+        cg_update_selfred_kernel<<<g, 256, 0, s>>>(c->d_scal, c->d_flag, dv, p, Ap, x, r, n, o.norm_type, c->d_part, gsp, it);
+        cg_p_selfred_kernel<<<g, 256, 0, s>>>(c->d_scal, c->d_flag, dv, r, p, n, c->d_part, g, it, o.norm_type, maxit, check, hist, hist_cap);
+        continue;
+      }
       sum_partials_kernel<<<1, 256, 0, s>>>(c->d_part, 1, gsp, c->d_scal + S_TMP0, c->d_flag);
       PYN_TRY(allreduce_tmp(c, 1));
       cg_scalar_alpha_kernel<<<1, 1, 0, s>>>(c->d_scal, c->d_flag);
