@@ -200,8 +200,9 @@ def main():
         traffic = {}
         try:
             if world.size == 1 and n == 215:
-                for fn in ("r01d_pmc_traffic.json", "r01d_pmc_assembly.json"):    # the assembly entry comes from its own passes
-                    with open(os.path.join(ROOT, "profiles", fn)) as fh:
+                for fn in ("pmc_traffic.json", "pmc_assembly.json"):    # the assembly entry comes from its own passes
+                    tag = "r01e" if os.path.exists(os.path.join(ROOT, "profiles", "r01e_" + fn)) else "r01d"
+                    with open(os.path.join(ROOT, "profiles", f"{tag}_{fn}")) as fh:
                         traffic.update({k: v["hbm_bytes_per_launch"] for k, v in json.load(fh)["kernels"].items()})
         except (OSError, KeyError, ValueError):
             traffic = {}
