@@ -972,15 +972,25 @@ static int solve_cg_sr(pyn_ctx* c, DMat& A, const double* b, double* x, const py
 // ---- fused classical Gram-Schmidt for GMRES: all k+1 projections in ONE pass over the basis -----------------
 // h[j] = V_j . w for j < k1 (partials per block, chunks of 8 vectors so the accumulators stay in registers)
 constexpr int MD_GRID = 512;
-__global__ void __launch_bounds__(256) multi_dot_kernel(const double* __restrict__ V, int64_t ld, int k1,
-                                                        const double* __restrict__ w, int64_t n, double* __restrict__ part) {
+// PRE: w is produced here as dinv .* wraw (the preconditioned product) while its projections are taken -- the first
+// chunk writes it, later chunks (more than 8 basis vectors) re-read what the same lane wrote
+template <bool PRE>
+__global__ void __launch_bounds__(256) multi_dot_kernel(const double* __restrict__ V, int64_t ld, int k1, double* w, int64_t n,
+                                                        double* __restrict__ part, const double* __restrict__ dinv,
+                                                        const double* __restrict__ wraw) {
   __shared__ double sm[4];
   for (int c0 = 0; c0 < k1; c0 += 8) {
     double acc[8];
 #pragma unroll
     for (int j = 0; j < 8; ++j) acc[j] = 0.0;
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
-      const double wi = w[i];
+      double wi;
+      if (PRE && c0 == 0) {
+        wi = dinv ? dinv[i] * wraw[i] : wraw[i];
+        w[i] = wi;
+      } else {
+        wi = w[i];
+      }
 #pragma unroll
       for (int j = 0; j < 8; ++j)
         if (c0 + j < k1) acc[j] = fma(V[(int64_t)(c0 + j) * ld + i], wi, acc[j]);
@@ -1008,13 +1018,19 @@ __global__ void __launch_bounds__(256) multi_finish_kernel(const double* __restr
 }
 
 // w -= sum_j h[j] V_j  (h on the device: no host round trip between the projection and the update)
+// NORM: the partial sums of |w|^2 of the updated vector go to part[blockIdx.x] (grid <= MD_GRID): the norm of the new
+// basis vector needs no pass of its own
+template <bool NORM>
 __global__ void __launch_bounds__(256) multi_axpy_kernel(double* __restrict__ w, const double* __restrict__ V, int64_t ld, int k1,
-                                                         const double* __restrict__ h, int64_t n) {
+                                                         const double* __restrict__ h, int64_t n, double* __restrict__ part) {
+  double nrm = 0.0;
   for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
     double acc = w[i];
     for (int j = 0; j < k1; ++j) acc = fma(-h[j], V[(int64_t)j * ld + i], acc);
     w[i] = acc;
+    if (NORM) nrm = fma(acc, acc, nrm);
   }
+  if (NORM) block_partial(nrm, part);
 }
 
 // v *= 1/sqrt(hn[0]) (hn = v.v on the device); nothing if the norm vanished (happy breakdown)
@@ -1054,6 +1070,8 @@ static int solve_gmres(pyn_ctx* c, DMat& A, const double* b, double* x, const py
     return pyn_spmv_raw(c, A, xin, yout);
   };
   const int mdg = (int)std::max<int64_t>(1, std::min<int64_t>((n + 255) / 256, MD_GRID));
+  // grid of the update that also leaves the |vn|^2 partials: they may spill over all rows of mpart (consumed by then)
+  const int gn = (int)std::min<int64_t>(vgrid(n), (int64_t)(m + 1) * MD_GRID);
   const bool jac = o.pc == PYN_PC_JACOBI;
   if (jac) PYN_TRY(pyn_extract_diag_inv(c, A, dinv, true));
   const double* dv = jac ? dinv : nullptr;
@@ -1093,9 +1111,9 @@ static int solve_gmres(pyn_ctx* c, DMat& A, const double* b, double* x, const py
       double* vn = V + (int64_t)(k + 1) * nl;
       PYN_TRY(pyn_halo_exchange(c, vk, A.bc));
       PYN_TRY(product(vk, w));
-      wmul_kernel<<<g, 256, 0, s>>>(vn, dv, w, n);
       double hh = 0;
       if (mgs) {
+        wmul_kernel<<<g, 256, 0, s>>>(vn, dv, w, n);
         for (int j = 0; j <= k; ++j) {
           double h = 0;
           PYN_TRY(dev_dot(c, vn, V + (int64_t)j * nl, n, &h));
@@ -1108,13 +1126,19 @@ static int solve_gmres(pyn_ctx* c, DMat& A, const double* b, double* x, const py
       } else {
         const int k1 = k + 1;
         for (int pass = 0; pass < npass; ++pass) {      // projection + update (, then once more: refinement)
-          multi_dot_kernel<<<mdg, 256, 0, s>>>(V, nl, k1, vn, n, mpart);
+          // pass 0 also forms vn = dinv .* w; the last pass also leaves the partial sums of |vn|^2 in mpart[0][..]
+          if (pass == 0)
+            multi_dot_kernel<true><<<mdg, 256, 0, s>>>(V, nl, k1, vn, n, mpart, dv, w);
+          else
+            multi_dot_kernel<false><<<mdg, 256, 0, s>>>(V, nl, k1, vn, n, mpart, nullptr, nullptr);
           multi_finish_kernel<<<k1, 256, 0, s>>>(mpart, mdg, dh + pass * mh);
           PYN_TRY(pyn_allreduce_dev(c, dh + pass * mh, k1, 0, s));
-          multi_axpy_kernel<<<g, 256, 0, s>>>(vn, V, nl, k1, dh + pass * mh, n);
+          if (pass == npass - 1)
+            multi_axpy_kernel<true><<<gn, 256, 0, s>>>(vn, V, nl, k1, dh + pass * mh, n, mpart);
+          else
+            multi_axpy_kernel<false><<<g, 256, 0, s>>>(vn, V, nl, k1, dh + pass * mh, n, nullptr);
         }
-        multi_dot_kernel<<<mdg, 256, 0, s>>>(vn, nl, 1, vn, n, mpart);
-        multi_finish_kernel<<<1, 256, 0, s>>>(mpart, mdg, dh + 2 * mh);
+        multi_finish_kernel<<<1, 256, 0, s>>>(mpart, gn, dh + 2 * mh);
         PYN_TRY(pyn_allreduce_dev(c, dh + 2 * mh, 1, 0, s));
         scale_rsqrt_kernel<<<g, 256, 0, s>>>(vn, dh + 2 * mh, n);
         PYN_HIP(hipMemcpyAsync(hh_host.data(), dh, 3 * mh * sizeof(double), hipMemcpyDeviceToHost, s));
