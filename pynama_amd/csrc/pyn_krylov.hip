@@ -977,8 +977,9 @@ constexpr int MD_GRID = 512;
 template <bool PRE>
 __global__ void __launch_bounds__(256) multi_dot_kernel(const double* __restrict__ V, int64_t ld, int k1, double* w, int64_t n,
                                                         double* __restrict__ part, const double* __restrict__ dinv,
-                                                        const double* __restrict__ wraw) {
+                                                        const double* __restrict__ wraw, const int* __restrict__ flag) {
   __shared__ double sm[4];
+  if (flag && flag[F_DONE]) return;
   for (int c0 = 0; c0 < k1; c0 += 8) {
     double acc[8];
 #pragma unroll
@@ -1007,8 +1008,10 @@ __global__ void __launch_bounds__(256) multi_dot_kernel(const double* __restrict
   }
 }
 
-__global__ void __launch_bounds__(256) multi_finish_kernel(const double* __restrict__ part, int nblocks, double* __restrict__ out) {
+__global__ void __launch_bounds__(256) multi_finish_kernel(const double* __restrict__ part, int nblocks, double* __restrict__ out,
+                                                           const int* __restrict__ flag) {
   __shared__ double sm[4];
+  if (flag && flag[F_DONE]) return;
   double acc = 0.0;
   for (int i = threadIdx.x; i < nblocks; i += 256) acc += part[(int64_t)blockIdx.x * MD_GRID + i];
   acc = wsum(acc);
@@ -1022,7 +1025,9 @@ __global__ void __launch_bounds__(256) multi_finish_kernel(const double* __restr
 // basis vector needs no pass of its own
 template <bool NORM>
 __global__ void __launch_bounds__(256) multi_axpy_kernel(double* __restrict__ w, const double* __restrict__ V, int64_t ld, int k1,
-                                                         const double* __restrict__ h, int64_t n, double* __restrict__ part) {
+                                                         const double* __restrict__ h, int64_t n, double* __restrict__ part,
+                                                         const int* __restrict__ flag) {
+  if (flag && flag[F_DONE]) return;
   double nrm = 0.0;
   for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
     double acc = w[i];
@@ -1034,23 +1039,69 @@ __global__ void __launch_bounds__(256) multi_axpy_kernel(double* __restrict__ w,
 }
 
 // v *= 1/sqrt(hn[0]) (hn = v.v on the device); nothing if the norm vanished (happy breakdown)
-__global__ void __launch_bounds__(256) scale_rsqrt_kernel(double* __restrict__ v, const double* __restrict__ hn, int64_t n) {
+__global__ void __launch_bounds__(256) scale_rsqrt_kernel(double* __restrict__ v, const double* __restrict__ hn, int64_t n,
+                                                          const int* __restrict__ flag) {
+  if (flag && flag[F_DONE]) return;
   const double q = hn[0];
   if (!(q > 0.0)) return;
   const double r = 1.0 / sqrt(q);
   for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) v[i] *= r;
 }
 
-// Left-preconditioned restarted GMRES(m), Givens rotations on the host.  Orthogonalisation: classical
-// Gram-Schmidt with one refinement pass (two fused projection + update sweeps, ONE host synchronisation per
-// iteration; as stable as modified Gram-Schmidt) -- PETSc's KSPGMRES default is the classical variant too.
+// ---- Givens rotations of one restart cycle on the device (classical Gram-Schmidt variants) -------------------------
+// The host used to read the new Hessenberg column after every inner iteration (one synchronisation per iteration,
+// ~45 us of idle device at 0.85 M rows).  One thread now applies the previous rotations, forms the new one, updates the
+// residual estimate and raises F_DONE (convergence estimate reached / happy breakdown); the projection, update and
+// scaling kernels of the remaining iterations of the cycle return at once.  The host reads H, g and the number of
+// columns ONCE per cycle.  flag[F_KUSED] = columns built in this cycle.
+enum { F_KUSED = 3 };
+
+__global__ void gmres_cycle_init_kernel(double* __restrict__ gg, double beta, int m, int* __restrict__ flag) {
+  for (int i = threadIdx.x; i <= m; i += blockDim.x) gg[i] = i == 0 ? beta : 0.0;
+  if (threadIdx.x == 0) {
+    flag[F_DONE] = 0;
+    flag[F_KUSED] = 0;
+  }
+}
+
+// dh: h1[mh] (first projection), h2[mh] (refinement), |v|^2 at 2 mh.  Hd row-major [(m+1)][m] like the host copy.
+__global__ void gmres_givens_kernel(const double* __restrict__ dh, int mh, int npass, int k, int m, double* __restrict__ Hd,
+                                    double* __restrict__ cs, double* __restrict__ sn, double* __restrict__ gg, double ttol,
+                                    int* __restrict__ flag) {
+  if (flag[F_DONE]) return;
+  const double hh = sqrt(fmax(0.0, dh[2 * mh]));
+  double below = hh;                                   // H[k+1][k]
+  double prev = dh[0] + (npass == 2 ? dh[mh] : 0.0);   // running H[j][k]
+  for (int j = 0; j < k; ++j) {
+    const double next = dh[j + 1] + (npass == 2 ? dh[mh + j + 1] : 0.0);
+    const double a = cs[j] * prev + sn[j] * next;
+    const double bnew = -sn[j] * prev + cs[j] * next;
+    Hd[(size_t)j * m + k] = a;
+    prev = bnew;
+  }
+  const double den = hypot(prev, below);
+  const double ck = prev / den, sk = below / den;
+  cs[k] = ck;
+  sn[k] = sk;
+  Hd[(size_t)k * m + k] = den;
+  Hd[(size_t)(k + 1) * m + k] = 0.0;
+  const double gk = gg[k];
+  gg[k + 1] = -sk * gk;
+  gg[k] = ck * gk;
+  flag[F_KUSED] = k + 1;
+  if (fabs(gg[k + 1]) <= ttol || hh == 0.0) flag[F_DONE] = 1;
+}
+
+// Left-preconditioned restarted GMRES(m).  Orthogonalisation: classical Gram-Schmidt with one refinement pass (two
+// fused projection + update sweeps, Givens rotations on the device, ONE host synchronisation per restart cycle;
+// as stable as modified Gram-Schmidt) -- PETSc's KSPGMRES default is the classical variant too.
 // PYNAMA_GMRES_MGS=1 selects the step-by-step modified Gram-Schmidt (k+2 synchronisations per iteration).
 static int solve_gmres(pyn_ctx* c, DMat& A, const double* b, double* x, const pyn_solve_opts& o, pyn_solve_info* info) {
   const int64_t n = c->n_owned * A.br;
   const int64_t nl = n_local(c) * A.br;
   const int m = std::max(1, o.restart);
   const int mh = m + 2;                                  // h1[m+1], then (offset mh) h2[m+1], then (2 mh) the norm
-  size_t need = (size_t)((int64_t)(m + 1) * nl + 2 * nl + n + (int64_t)(m + 1) * MD_GRID + 3 * mh) * sizeof(double);
+  size_t need = (size_t)((int64_t)(m + 1) * nl + 2 * nl + n + (int64_t)(m + 1) * MD_GRID + 3 * mh + (int64_t)(m + 1) * m + 3 * m + 1) * sizeof(double);
   PYN_TRY(pyn_ensure_work(c, need));
   double* V = c->d_work;            // (m+1) x nl
   double* w = V + (int64_t)(m + 1) * nl;  // nl (needs ghost space as SpMV input? no: output) -> n used
@@ -1058,7 +1109,10 @@ static int solve_gmres(pyn_ctx* c, DMat& A, const double* b, double* x, const py
   double* dinv = t + nl;
   double* mpart = dinv + n;         // (m+1) x MD_GRID partial sums of the fused projections
   double* dh = mpart + (int64_t)(m + 1) * MD_GRID;       // device copy of the projection coefficients
-  std::vector<double> hh_host((size_t)3 * mh);
+  double* Hd = dh + 3 * mh;                              // (m+1) x m Hessenberg matrix after the rotations, then cs, sn, g
+  double* csd = Hd + (int64_t)(m + 1) * m;
+  double* snd = csd + m;
+  double* ggd = snd + m;
   const bool mgs = o.gmres_orthog == 2 || getenv("PYNAMA_GMRES_MGS") != nullptr;
   const int npass = o.gmres_orthog == 1 ? 1 : 2;
   // the product: matrix-free operator, the SELL-64 image, or block CSR
@@ -1106,46 +1160,59 @@ static int solve_gmres(pyn_ctx* c, DMat& A, const double* b, double* x, const py
     std::fill(gg.begin(), gg.end(), 0.0);
     gg[0] = beta;
     int kused = 0;
-    for (int k = 0; k < m; ++k) {
+    if (!mgs) {
+      // one restart cycle without host round trips: rotations and the convergence estimate live on the device
+      const int todo = std::min(m, maxit - its);
+      const int* fl = c->d_flag;
+      gmres_cycle_init_kernel<<<1, 64, 0, s>>>(ggd, beta, m, c->d_flag);
+      for (int k = 0; k < todo; ++k) {
+        double* vk = V + (int64_t)k * nl;
+        double* vn = V + (int64_t)(k + 1) * nl;
+        PYN_TRY(pyn_halo_exchange(c, vk, A.bc));
+        PYN_TRY(product(vk, w));
+        const int k1 = k + 1;
+        for (int pass = 0; pass < npass; ++pass) {      // projection + update (, then once more: refinement)
+          // pass 0 also forms vn = dinv .* w; the last pass also leaves the partial sums of |vn|^2 in mpart[0][..]
+          if (pass == 0)
+            multi_dot_kernel<true><<<mdg, 256, 0, s>>>(V, nl, k1, vn, n, mpart, dv, w, fl);
+          else
+            multi_dot_kernel<false><<<mdg, 256, 0, s>>>(V, nl, k1, vn, n, mpart, nullptr, nullptr, fl);
+          multi_finish_kernel<<<k1, 256, 0, s>>>(mpart, mdg, dh + pass * mh, fl);
+          PYN_TRY(pyn_allreduce_dev(c, dh + pass * mh, k1, 0, s));
+          if (pass == npass - 1)
+            multi_axpy_kernel<true><<<gn, 256, 0, s>>>(vn, V, nl, k1, dh + pass * mh, n, mpart, fl);
+          else
+            multi_axpy_kernel<false><<<g, 256, 0, s>>>(vn, V, nl, k1, dh + pass * mh, n, nullptr, fl);
+        }
+        multi_finish_kernel<<<1, 256, 0, s>>>(mpart, gn, dh + 2 * mh, fl);
+        PYN_TRY(pyn_allreduce_dev(c, dh + 2 * mh, 1, 0, s));
+        scale_rsqrt_kernel<<<g, 256, 0, s>>>(vn, dh + 2 * mh, n, fl);
+        gmres_givens_kernel<<<1, 1, 0, s>>>(dh, mh, npass, k, m, Hd, csd, snd, ggd, ttol, c->d_flag);
+      }
+      PYN_HIP(hipMemcpyAsync(H.data(), Hd, (size_t)(m + 1) * m * sizeof(double), hipMemcpyDeviceToHost, s));
+      PYN_HIP(hipMemcpyAsync(gg.data(), ggd, (size_t)(m + 1) * sizeof(double), hipMemcpyDeviceToHost, s));
+      PYN_HIP(hipMemcpyAsync(c->h_flag, c->d_flag, 8 * sizeof(int), hipMemcpyDeviceToHost, s));
+      PYN_HIP(hipStreamSynchronize(s));
+      kused = c->h_flag[F_KUSED];
+      its += kused;
+      rn = std::fabs(gg[kused]);
+    }
+    for (int k = 0; mgs && k < m; ++k) {   // modified Gram-Schmidt: step by step, rotations on the host
       double* vk = V + (int64_t)k * nl;
       double* vn = V + (int64_t)(k + 1) * nl;
       PYN_TRY(pyn_halo_exchange(c, vk, A.bc));
       PYN_TRY(product(vk, w));
       double hh = 0;
-      if (mgs) {
-        wmul_kernel<<<g, 256, 0, s>>>(vn, dv, w, n);
-        for (int j = 0; j <= k; ++j) {
-          double h = 0;
-          PYN_TRY(dev_dot(c, vn, V + (int64_t)j * nl, n, &h));
-          H[(size_t)j * m + k] = h;
-          waxpby_kernel<<<g, 256, 0, s>>>(vn, 1.0, vn, -h, V + (int64_t)j * nl, n);
-        }
-        PYN_TRY(dev_dot(c, vn, vn, n, &hh));
-        hh = sqrt(hh);
-        if (hh > 0) waxpby_kernel<<<g, 256, 0, s>>>(vn, 1.0 / hh, vn, 0.0, vn, n);
-      } else {
-        const int k1 = k + 1;
-        for (int pass = 0; pass < npass; ++pass) {      // projection + update (, then once more: refinement)
-          // pass 0 also forms vn = dinv .* w; the last pass also leaves the partial sums of |vn|^2 in mpart[0][..]
-          if (pass == 0)
-            multi_dot_kernel<true><<<mdg, 256, 0, s>>>(V, nl, k1, vn, n, mpart, dv, w);
-          else
-            multi_dot_kernel<false><<<mdg, 256, 0, s>>>(V, nl, k1, vn, n, mpart, nullptr, nullptr);
-          multi_finish_kernel<<<k1, 256, 0, s>>>(mpart, mdg, dh + pass * mh);
-          PYN_TRY(pyn_allreduce_dev(c, dh + pass * mh, k1, 0, s));
-          if (pass == npass - 1)
-            multi_axpy_kernel<true><<<gn, 256, 0, s>>>(vn, V, nl, k1, dh + pass * mh, n, mpart);
-          else
-            multi_axpy_kernel<false><<<g, 256, 0, s>>>(vn, V, nl, k1, dh + pass * mh, n, nullptr);
-        }
-        multi_finish_kernel<<<1, 256, 0, s>>>(mpart, gn, dh + 2 * mh);
-        PYN_TRY(pyn_allreduce_dev(c, dh + 2 * mh, 1, 0, s));
-        scale_rsqrt_kernel<<<g, 256, 0, s>>>(vn, dh + 2 * mh, n);
-        PYN_HIP(hipMemcpyAsync(hh_host.data(), dh, 3 * mh * sizeof(double), hipMemcpyDeviceToHost, s));
-        PYN_HIP(hipStreamSynchronize(s));
-        for (int j = 0; j <= k; ++j) H[(size_t)j * m + k] = hh_host[j] + (npass == 2 ? hh_host[mh + j] : 0.0);
-        hh = sqrt(std::max(0.0, hh_host[2 * mh]));
+      wmul_kernel<<<g, 256, 0, s>>>(vn, dv, w, n);
+      for (int j = 0; j <= k; ++j) {
+        double h = 0;
+        PYN_TRY(dev_dot(c, vn, V + (int64_t)j * nl, n, &h));
+        H[(size_t)j * m + k] = h;
+        waxpby_kernel<<<g, 256, 0, s>>>(vn, 1.0, vn, -h, V + (int64_t)j * nl, n);
       }
+      PYN_TRY(dev_dot(c, vn, vn, n, &hh));
+      hh = sqrt(hh);
+      if (hh > 0) waxpby_kernel<<<g, 256, 0, s>>>(vn, 1.0 / hh, vn, 0.0, vn, n);
       H[(size_t)(k + 1) * m + k] = hh;
       for (int j = 0; j < k; ++j) {
         double a = cs[j] * H[(size_t)j * m + k] + sn[j] * H[(size_t)(j + 1) * m + k];
