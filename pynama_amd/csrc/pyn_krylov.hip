@@ -973,17 +973,24 @@ static int solve_cg_sr(pyn_ctx* c, DMat& A, const double* b, double* x, const py
 // h[j] = V_j . w for j < k1 (partials per block, chunks of 8 vectors so the accumulators stay in registers)
 constexpr int MD_GRID = 512;
 // PRE: w is produced here as dinv .* wraw (the preconditioned product) while its projections are taken -- the first
-// chunk writes it, later chunks (more than 8 basis vectors) re-read what the same lane wrote
-template <bool PRE>
+// chunk writes it, later chunks (more than NV basis vectors) re-read what the same lane wrote.
+// NV accumulators per lane: the whole basis (<= 32 vectors) in ONE sweep over w with NV independent loads in flight
+// per row; vectors beyond k1 are clamped to the last one (cached re-reads, results dropped) so that the row loop has
+// no branches; one barrier per chunk in the epilogue.  Per-vector summation order is that of a plain strided loop.
+template <bool PRE, int NV>
 __global__ void __launch_bounds__(256) multi_dot_kernel(const double* __restrict__ V, int64_t ld, int k1, double* w, int64_t n,
                                                         double* __restrict__ part, const double* __restrict__ dinv,
                                                         const double* __restrict__ wraw, const int* __restrict__ flag) {
-  __shared__ double sm[4];
+  __shared__ double sm[NV][4];
   if (flag && flag[F_DONE]) return;
-  for (int c0 = 0; c0 < k1; c0 += 8) {
-    double acc[8];
+  for (int c0 = 0; c0 < k1; c0 += NV) {
+    double acc[NV];
+    const double* vp[NV];
 #pragma unroll
-    for (int j = 0; j < 8; ++j) acc[j] = 0.0;
+    for (int j = 0; j < NV; ++j) {
+      acc[j] = 0.0;
+      vp[j] = V + (int64_t)min(c0 + j, k1 - 1) * ld;
+    }
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
       double wi;
       if (PRE && c0 == 0) {
@@ -993,18 +1000,34 @@ __global__ void __launch_bounds__(256) multi_dot_kernel(const double* __restrict
         wi = w[i];
       }
 #pragma unroll
-      for (int j = 0; j < 8; ++j)
-        if (c0 + j < k1) acc[j] = fma(V[(int64_t)(c0 + j) * ld + i], wi, acc[j]);
+      for (int j = 0; j < NV; ++j) acc[j] = fma(vp[j][i], wi, acc[j]);
     }
+    if (c0) __syncthreads();
 #pragma unroll
-    for (int j = 0; j < 8; ++j) {
-      if (c0 + j >= k1) break;
+    for (int j = 0; j < NV; ++j) {
       const double v = wsum(acc[j]);
-      __syncthreads();
-      if ((threadIdx.x & 63) == 0) sm[threadIdx.x >> 6] = v;
-      __syncthreads();
-      if (threadIdx.x == 0) part[(int64_t)(c0 + j) * MD_GRID + blockIdx.x] = sm[0] + sm[1] + sm[2] + sm[3];
+      if ((threadIdx.x & 63) == 0) sm[j][threadIdx.x >> 6] = v;
     }
+    __syncthreads();
+    if (threadIdx.x < NV && c0 + threadIdx.x < k1)
+      part[(int64_t)(c0 + threadIdx.x) * MD_GRID + blockIdx.x] = sm[threadIdx.x][0] + sm[threadIdx.x][1] + sm[threadIdx.x][2] + sm[threadIdx.x][3];
+  }
+}
+
+template <bool PRE>
+static void launch_multi_dot(int grid, hipStream_t s, const double* V, int64_t ld, int k1, double* w, int64_t n, double* part,
+                             const double* dinv, const double* wraw, const int* flag) {
+  switch ((std::min(k1, 32) + 3) / 4) {   // accumulators in steps of four: at most three clamped (redundant) vectors
+#define PYN_MD(NV) multi_dot_kernel<PRE, NV><<<grid, 256, 0, s>>>(V, ld, k1, w, n, part, dinv, wraw, flag); break
+    case 1: PYN_MD(4);
+    case 2: PYN_MD(8);
+    case 3: PYN_MD(12);
+    case 4: PYN_MD(16);
+    case 5: PYN_MD(20);
+    case 6: PYN_MD(24);
+    case 7: PYN_MD(28);
+    default: PYN_MD(32);
+#undef PYN_MD
   }
 }
 
@@ -1174,9 +1197,9 @@ static int solve_gmres(pyn_ctx* c, DMat& A, const double* b, double* x, const py
         for (int pass = 0; pass < npass; ++pass) {      // projection + update (, then once more: refinement)
           // pass 0 also forms vn = dinv .* w; the last pass also leaves the partial sums of |vn|^2 in mpart[0][..]
           if (pass == 0)
-            multi_dot_kernel<true><<<mdg, 256, 0, s>>>(V, nl, k1, vn, n, mpart, dv, w, fl);
+            launch_multi_dot<true>(mdg, s, V, nl, k1, vn, n, mpart, dv, w, fl);
           else
-            multi_dot_kernel<false><<<mdg, 256, 0, s>>>(V, nl, k1, vn, n, mpart, nullptr, nullptr, fl);
+            launch_multi_dot<false>(mdg, s, V, nl, k1, vn, n, mpart, nullptr, nullptr, fl);
           multi_finish_kernel<<<k1, 256, 0, s>>>(mpart, mdg, dh + pass * mh, fl);
           PYN_TRY(pyn_allreduce_dev(c, dh + pass * mh, k1, 0, s));
           if (pass == npass - 1)
