@@ -1088,11 +1088,10 @@ __global__ void gmres_cycle_init_kernel(double* __restrict__ gg, double beta, in
 }
 
 // dh: h1[mh] (first projection), h2[mh] (refinement), |v|^2 at 2 mh.  Hd row-major [(m+1)][m] like the host copy.
-__global__ void gmres_givens_kernel(const double* __restrict__ dh, int mh, int npass, int k, int m, double* __restrict__ Hd,
-                                    double* __restrict__ cs, double* __restrict__ sn, double* __restrict__ gg, double ttol,
-                                    int* __restrict__ flag) {
-  if (flag[F_DONE]) return;
-  const double hh = sqrt(fmax(0.0, dh[2 * mh]));
+__device__ inline void gmres_givens_step(const double* __restrict__ dh, double vv, int mh, int npass, int k, int m,
+                                         double* __restrict__ Hd, double* __restrict__ cs, double* __restrict__ sn,
+                                         double* __restrict__ gg, double ttol, int* __restrict__ flag) {
+  const double hh = sqrt(fmax(0.0, vv));
   double below = hh;                                   // H[k+1][k]
   double prev = dh[0] + (npass == 2 ? dh[mh] : 0.0);   // running H[j][k]
   for (int j = 0; j < k; ++j) {
@@ -1113,6 +1112,31 @@ __global__ void gmres_givens_kernel(const double* __restrict__ dh, int mh, int n
   gg[k] = ck * gk;
   flag[F_KUSED] = k + 1;
   if (fabs(gg[k + 1]) <= ttol || hh == 0.0) flag[F_DONE] = 1;
+}
+
+// dh: h1[mh] (first projection), h2[mh] (refinement), |v|^2 at 2 mh.  Hd row-major [(m+1)][m] like the host copy.
+__global__ void gmres_givens_kernel(const double* __restrict__ dh, int mh, int npass, int k, int m, double* __restrict__ Hd,
+                                    double* __restrict__ cs, double* __restrict__ sn, double* __restrict__ gg, double ttol,
+                                    int* __restrict__ flag) {
+  if (flag[F_DONE]) return;
+  gmres_givens_step(dh, dh[2 * mh], mh, npass, k, m, Hd, cs, sn, gg, ttol, flag);
+}
+
+// one rank: |v|^2 summed per block from the update sweep's partials (the tree of multi_finish_kernel), block 0 steps the
+// rotations, everybody scales -- the norm reduction and the rotation launch disappear.  A block that starts after block 0
+// raised F_DONE skips the scaling of a vector the back-substitution never reads.
+__global__ void __launch_bounds__(256) gmres_scale_givens_kernel(double* __restrict__ v, const double* __restrict__ part, int nparts,
+                                                                 int64_t n, const double* __restrict__ dh, int mh, int npass,
+                                                                 int k, int m, double* __restrict__ Hd, double* __restrict__ cs,
+                                                                 double* __restrict__ sn, double* __restrict__ gg, double ttol,
+                                                                 int* __restrict__ flag) {
+  if (flag[F_DONE]) return;
+  double q, unused;
+  all_block_sum2(part, nparts, nullptr, 0, q, unused);
+  if (blockIdx.x == 0 && threadIdx.x == 0) gmres_givens_step(dh, q, mh, npass, k, m, Hd, cs, sn, gg, ttol, flag);
+  if (!(q > 0.0)) return;
+  const double r = 1.0 / sqrt(q);
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) v[i] *= r;
 }
 
 // Left-preconditioned restarted GMRES(m).  Orthogonalisation: classical Gram-Schmidt with one refinement pass (two
@@ -1207,10 +1231,14 @@ static int solve_gmres(pyn_ctx* c, DMat& A, const double* b, double* x, const py
           else
             multi_axpy_kernel<false><<<g, 256, 0, s>>>(vn, V, nl, k1, dh + pass * mh, n, nullptr, fl);
         }
-        multi_finish_kernel<<<1, 256, 0, s>>>(mpart, gn, dh + 2 * mh, fl);
-        PYN_TRY(pyn_allreduce_dev(c, dh + 2 * mh, 1, 0, s));
-        scale_rsqrt_kernel<<<g, 256, 0, s>>>(vn, dh + 2 * mh, n, fl);
-        gmres_givens_kernel<<<1, 1, 0, s>>>(dh, mh, npass, k, m, Hd, csd, snd, ggd, ttol, c->d_flag);
+        if (!pyn_has_comm(c)) {
+          gmres_scale_givens_kernel<<<g, 256, 0, s>>>(vn, mpart, gn, n, dh, mh, npass, k, m, Hd, csd, snd, ggd, ttol, c->d_flag);
+        } else {
+          multi_finish_kernel<<<1, 256, 0, s>>>(mpart, gn, dh + 2 * mh, fl);
+          PYN_TRY(pyn_allreduce_dev(c, dh + 2 * mh, 1, 0, s));
+          scale_rsqrt_kernel<<<g, 256, 0, s>>>(vn, dh + 2 * mh, n, fl);
+          gmres_givens_kernel<<<1, 1, 0, s>>>(dh, mh, npass, k, m, Hd, csd, snd, ggd, ttol, c->d_flag);
+        }
       }
       PYN_HIP(hipMemcpyAsync(H.data(), Hd, (size_t)(m + 1) * m * sizeof(double), hipMemcpyDeviceToHost, s));
       PYN_HIP(hipMemcpyAsync(gg.data(), ggd, (size_t)(m + 1) * sizeof(double), hipMemcpyDeviceToHost, s));
