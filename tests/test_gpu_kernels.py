@@ -347,6 +347,30 @@ def test_cg_zero_rhs_and_maxit(lib, variant):
     ctx.close()
 
 
+@pytest.mark.parametrize("orthog", [0, 1])
+@pytest.mark.parametrize("restart", [1, 3, 5, 12, 40])
+def test_gmres_restart_lengths_and_limits(lib, restart, orthog):
+    """restart cycles run without host round trips (rotations on the device): short cycles, cycles longer than the 32
+    accumulators of the projection sweep (second chunk re-reads the vector the first one produced), limits that end in
+    the middle of a cycle -- iteration counts and iterates of the oracle"""
+    mesh, ctx, A, vb, vx, b = _poisson(lib, [7, 6, 5])
+    S = mat_to_scipy(ctx, A, 1, 1)
+    kw = dict(method=lib.KSP_GMRES, pc=lib.PC_JACOBI, restart=restart, gmres_orthog=orthog)
+    x_o, it_o, _ = fo.gmres(S, b, rtol=1e-10, restart=restart, maxit=3000)
+    info = ctx.solve(A, vb, vx, rtol=1e-10, maxit=3000, **kw)
+    assert info.reason == 2 and abs(info.iters - it_o) <= max(1, it_o // 100)
+    assert rel_err(ctx.vec_get(vx, 1), x_o) < 1e-7
+    lim = restart + max(1, restart // 2)                    # ends in the middle of the second cycle
+    x_l, it_l, _ = fo.gmres(S, b, rtol=1e-30, restart=restart, maxit=lim)
+    info = ctx.solve(A, vb, vx, rtol=1e-30, maxit=lim, **kw)
+    assert info.iters == lim and info.reason == -3
+    assert rel_err(ctx.vec_get(vx, 1), x_l) < 1e-9
+    info = ctx.solve(A, vb, vx, fixed_iters=lim, **kw)
+    assert info.iters == lim and info.reason == 4
+    assert rel_err(ctx.vec_get(vx, 1), x_l) < 1e-9
+    ctx.close()
+
+
 @pytest.mark.parametrize("orthog", [0, 1, 2])
 def test_gmres_matches_oracle(lib, orthog):
     """0: classical Gram-Schmidt + refinement (fused, default), 1: classical without refinement (PETSc's default),
