@@ -223,8 +223,8 @@ def main():
             "ms_per_step": wall / args.steps * 1e3,
             "breakdown_ms": {"assembly": asm_mean, "cg": cg_mean, "cg_iters": args.cg_iters,
                              "spmv_kernel": spmv_mean, "symbolic_once": symbolic_ms,
-                             # N > 1 (single-reduction CG): end of the product -> scalars ready = partial sums + the one
-                             # all-reduce + scalar step, per iteration (0 on one GPU: standard PCG is not bracketed)
+                             # N > 1 (single-reduction CG): end of the product -> all-reduced sums ready = partial sums + the one
+                             # all-reduce, per iteration (the scalar step rides in the update kernel; 0 on one GPU)
                              "cg_reduction_per_iter": red_mean,
                              # overlapped halo exchange (pack + grouped send/recv on the communication stream), per iteration
                              "cg_halo_per_iter": halo_mean},
