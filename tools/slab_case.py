@@ -24,7 +24,8 @@ for t in Spectral(2, 3).deviceTables():
 bm = dom.boundaryMaskLocal()
 ctx.bc_set(1, bm)
 n_rows, nnz = ctx.csr_symbolic()
-ctx.patch_plan_set(*dom.patchPlan((7, 7, 7)))
+if os.environ.get("PYNAMA_SLAB_PLAN"):      # the patch-plan kernels instead of the plan-free lattice ones the bench runs
+    ctx.patch_plan_set(*dom.patchPlan((7, 7, 7)))
 A = ctx.mat_create(1, 1)
 for _ in range(3):
     ctx.assemble_scalar(_lib.FORM_LAPLACE, A)
