@@ -3,6 +3,7 @@
 committed under profiles/.
   rocprof_summary.py stats  <results.db> <out.csv> [out.md]     --kernel-trace --stats run
   rocprof_summary.py pmc    <fetch.db> <write.db> <out.json>    --pmc FETCH_SIZE / --pmc WRITE_SIZE runs
+  rocprof_summary.py counters <results.db> <out.json> [kernel-substring]   any --pmc run: per-kernel mean of every counter
   rocprof_summary.py timeline <results.db> <out.txt> [n]        last n dispatches of a --kernel-trace run: start, duration, gap"""
 import json
 import re
@@ -61,8 +62,23 @@ def timeline(db, out_txt, n=60):
             prev_end = e
 
 
+def counters(db, out_json, needle=""):
+    con = sqlite3.connect(db)
+    res = {}
+    q = "select kernel_name, counter_name, count(*), avg(value) from counters_collection group by kernel_name, counter_name"
+    for name, cn, n, mean in con.execute(q):
+        if needle and needle not in name:
+            continue
+        key = re.split(r"[<(]", re.sub(r"^void\s+", "", name).replace("(anonymous namespace)::", ""))[0].strip()
+        res.setdefault(key, {"launches": n})[cn] = mean
+    with open(out_json, "w") as f:
+        json.dump(res, f, indent=1)
+
+
 if __name__ == "__main__":
-    if sys.argv[1] == "timeline":
+    if sys.argv[1] == "counters":
+        counters(*sys.argv[2:5])
+    elif sys.argv[1] == "timeline":
         timeline(*sys.argv[2:5])
     elif sys.argv[1] == "stats":
         stats(*sys.argv[2:5])
