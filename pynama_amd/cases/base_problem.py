@@ -5,8 +5,9 @@ Mirrors ``src/cases/base_problem.py``: ``BaseProblem`` (config parsing :18-44,97
 (``setUpEmptyMats`` :463-477, ``buildKLEMats`` :499-552, ``solveKLE`` :479-481, ``getKLEError``
 :483-497).  The per-cell Python loop of ``buildKLEMats`` is ONE fused device pass here.
 
-Out of scope for this path: the PETSc TS time integrator, the HDF5/XDMF
-viewer, the operator chain of ``evalRHS`` (row f1) and ``NoSlipFreeSlip`` (row f2).
+Also here, from SURVEY.md section 8(f): the operator chain of ``evalRHS`` (f1: ``buildOperators`` / ``computeVtensV``,
+:132-140, 212-252) and ``NoSlipFreeSlip`` (f2, :315-454); ``saveStep`` writes the HDF5 / XDMF pair of f4.
+Not built (out of scope): the PETSc TS time integrator that would call ``evalRHS``.
 """
 import logging
 

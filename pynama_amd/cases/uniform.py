@@ -1,36 +1,32 @@
-"""Uniform-flow case (mirrors src/cases/uniform.py:12-62): BC value [1,0(,0)] on the external
-boundary, zero vorticity, exact solution v == const."""
+"""Uniform-flow case: the velocity e_x imposed on the whole external boundary, zero vorticity, so the KLE solve must
+return v = e_x everywhere.  API of the reference's case (src/cases/uniform.py: `UniformFlow` with `setUp`,
+`computeInitialCondition`, `applyBoundaryConditions`, `generateExactVecs`); the matrices are built ONCE, by
+`BaseProblem.setUp` (the reference assembles them twice in a row, uniform.py:14-30)."""
+import numpy as np
+
 from pynama_amd.cases.base_problem import FreeSlip
 
 
 class UniformFlow(FreeSlip):
     def setUp(self):
-        self.setUpGeneral()
-        if self.dim == 2:
-            self.cteValue = [1, 0]
-        elif self.dim == 3:
-            self.cteValue = [1, 0, 0]
-        else:
+        if self.dim not in (2, 3):
             raise Exception("Wrong dim")
-        # (the reference builds everything twice, uniform.py:14-30; once is enough)
-        self.setUpBoundaryConditions()
-        self.setUpEmptyMats()
-        self.buildKLEMats()
-        self.buildOperators()
+        self.cteValue = np.eye(self.dim)[0].tolist()     # e_x: [1, 0] / [1, 0, 0]
+        super().setUp()
+
+    def _uniform(self, vec, nodes):
+        vec.set(0.0)
+        return self.dom.applyValuesToVec(nodes, self.cteValue, vec)
 
     def computeInitialCondition(self, startTime):
         self.vort.set(0.0)
 
     def applyBoundaryConditions(self, time):
-        self.vel.set(0.0)
-        self.vel = self.dom.applyValuesToVec(self.bcNodes, self.cteValue, self.vel)
+        self.vel = self._uniform(self.vel, self.bcNodes)
 
     def generateExactVecs(self, time=None):
-        exactVel = self.mat.K.createVecRight()
-        exactVort = self.mat.Rw.createVecRight()
-        exactVel.setName(f"{self.caseName}-exact-vel")
-        exactVort.setName(f"{self.caseName}-exact-vort")
-        allNodes = self.dom.getAllNodes()
-        exactVel = self.dom.applyValuesToVec(allNodes, self.cteValue, exactVel)
-        exactVort.set(0.0)
-        return exactVel, exactVort
+        vel, vort = self.mat.K.createVecRight(), self.mat.Rw.createVecRight()
+        for vec, what in ((vel, "vel"), (vort, "vort")):
+            vec.setName(f"{self.caseName}-exact-{what}")
+        vort.set(0.0)
+        return self._uniform(vel, self.dom.getAllNodes()), vort

@@ -488,6 +488,7 @@ extern "C" int pyn_elem_tables_set(pyn_ctx* c, int which, int ngp, const double*
       }
     c->aff_standard = pyn_q1_affine_tables_standard(aff);
     c->aff_rw_standard = pyn_q1_mixed_tables_standard(w, H, Hrs);
+    c->q1_gauss_standard = pyn_q1_gauss_tables_standard(w, H, Hrs, HrsCoo);
     PYN_TRY(dev_upload(&c->d_aff, aff, (size_t)(6 * 36 + 32 + 9), c->stream));
   }
   PYN_HIP(hipStreamSynchronize(c->stream));

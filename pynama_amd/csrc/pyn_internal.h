@@ -153,6 +153,7 @@ struct pyn_ctx {
   int mesh_affine = -1;          // every element a parallelepiped? (-1: not checked yet; reset by pyn_mesh_set)
   bool aff_rw_standard = false;  // ... and so is int N_a d N_b (affine Rw path)
   bool aff_standard = false;  // the uploaded tables are those of the trilinear hexahedron in closed form
+  bool q1_gauss_standard = false;  // ... pointwise: 2x2x2 Gauss rule, unit weights (lean general-geometry kernels)
   double* d_aff = nullptr;  // Q1-hex affine tables: [6][36] reference matrices + [4][8] non-affine monomial signs + [3][3] S
 
   // boundary condition
@@ -235,3 +236,5 @@ int pyn_lattice_matfree_part(pyn_ctx* c, int op, const double* x, double* y, boo
                              int* grid_out);   // tiles without (zsel 1) / with (zsel 2) ghost planes: halo overlap
 int pyn_assemble_kle_lattice(pyn_ctx* c, double alpha_d, double alpha_w, double* K, double* Krhs, double* Rw, bool* handled);
 bool pyn_q1_mixed_tables_standard(const double* w, const double* H, const double* Hrs);
+bool pyn_q1_gauss_tables_standard(const double* w, const double* H, const double* Hrs, const double* HrsCoo);   // pyn_assemble_march.hip
+int pyn_assemble_lattice_march(pyn_ctx* c, void* lat_args, int tile);   // general geometry, z-marching (pyn_assemble_march.hip)

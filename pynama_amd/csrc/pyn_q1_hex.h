@@ -253,4 +253,133 @@ __device__ __forceinline__ double jacobian_inverse(const double* __restrict__ hc
   return det;
 }
 
+// ---- lean closed-form element Laplacian (general geometry, standard 2x2x2 Gauss tables: pyn_q1_gauss_tables_standard) ----
+constexpr double Q1_GP = 0.57735026918962576451;   // 1/sqrt(3): the 2-point Gauss abscissa (utilities.py:43-61, N = 2)
+constexpr int Q1_NODE[2][2][2] = {{{0, 4}, {1, 7}}, {{3, 5}, {2, 6}}};   // [i][j][k] -> local node
+
+// index of pair (a < b) in the packed strict upper triangle of 8 x 8
+__host__ __device__ constexpr int q1_off(int a, int b) { return a * 7 - (a * (a - 1)) / 2 + (b - a - 1); }
+
+// unnormalised Haar coefficients of the corner coordinates: C[bz][by][bx][c] = sum_a sx^bx sy^by sz^bz X_a[c]
+// (8 x the coefficient of xi^bx eta^by zeta^bz in the trilinear map).  P[k][j][i][c] = corner (i, j, k).
+__device__ __forceinline__ void q1_haar_coeffs(const double (&P)[2][2][2][3], double (&C)[2][2][2][3]) {
+#pragma unroll
+  for (int c = 0; c < 3; ++c) {
+    double a[2][2][2], b[2][2][2];
+#pragma unroll
+    for (int k = 0; k < 2; ++k)
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        a[k][j][0] = P[k][j][1][c] + P[k][j][0][c];
+        a[k][j][1] = P[k][j][1][c] - P[k][j][0][c];
+      }
+#pragma unroll
+    for (int k = 0; k < 2; ++k)
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        b[k][0][i] = a[k][1][i] + a[k][0][i];
+        b[k][1][i] = a[k][1][i] - a[k][0][i];
+      }
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        C[0][j][i][c] = b[1][j][i] + b[0][j][i];
+        C[1][j][i][c] = b[1][j][i] - b[0][j][i];
+      }
+  }
+}
+
+// reciprocal by v_rcp_f64 + two Newton steps (the determinant of a valid element is far from the ends of the range)
+__device__ __forceinline__ double q1_rcp(double d) {
+  double r = __builtin_amdgcn_rcp(d);
+  double e = fma(-d, r, 1.0);
+  r = fma(r, e, r);
+  e = fma(-d, r, 1.0);
+  return fma(r, e, r);
+}
+
+// Geometry at the Gauss point (SX, SY, SZ)/sqrt(3), everything unnormalised (J' = 8 J):  rows r_d = d x / d xi_d from
+// the Haar coefficients, A_d = r_{d+1} x r_{d+2} (the columns of adj J'), det' = r_0 . A_0 = 512 detJ.  Physical
+// gradients:  G[x][a] = (sum_d A_d[x] h_d[a]) / det'  with  h_d[a] = s_d(a) prod_{e != d} (1 + s_e(a) xi_e)  = 8 Hrs.
+template <int SX, int SY, int SZ>
+__device__ __forceinline__ double q1_point_adj(const double (&C)[2][2][2][3], double (&A)[3][3]) {
+  constexpr double xi = SX * Q1_GP, eta = SY * Q1_GP, zeta = SZ * Q1_GP;
+  double r0[3], r1[3], r2[3];
+#pragma unroll
+  for (int c = 0; c < 3; ++c) {
+    const double m = fma(xi, C[1][1][1][c], C[1][1][0][c]);   // shared by the eta- and zeta-rows
+    r0[c] = fma(zeta, fma(eta, C[1][1][1][c], C[1][0][1][c]), fma(eta, C[0][1][1][c], C[0][0][1][c]));
+    r1[c] = fma(zeta, m, fma(xi, C[0][1][1][c], C[0][1][0][c]));
+    r2[c] = fma(eta, m, fma(xi, C[1][0][1][c], C[1][0][0][c]));
+  }
+  A[0][0] = r1[1] * r2[2] - r1[2] * r2[1];
+  A[0][1] = r1[2] * r2[0] - r1[0] * r2[2];
+  A[0][2] = r1[0] * r2[1] - r1[1] * r2[0];
+  A[1][0] = r2[1] * r0[2] - r2[2] * r0[1];
+  A[1][1] = r2[2] * r0[0] - r2[0] * r0[2];
+  A[1][2] = r2[0] * r0[1] - r2[1] * r0[0];
+  A[2][0] = r0[1] * r1[2] - r0[2] * r1[1];
+  A[2][1] = r0[2] * r1[0] - r0[0] * r1[2];
+  A[2][2] = r0[0] * r1[1] - r0[1] * r1[0];
+  return r0[0] * A[0][0] + r0[1] * A[0][1] + r0[2] * A[0][2];
+}
+
+// h_d[a] at the Gauss point (SX, SY, SZ)/sqrt(3): compile-time constants
+template <int SX, int SY, int SZ>
+__host__ __device__ constexpr double q1_h(int d, int i, int j, int k) {
+  const double px = 1.0 + (2 * i - 1) * SX * Q1_GP, py = 1.0 + (2 * j - 1) * SY * Q1_GP, pz = 1.0 + (2 * k - 1) * SZ * Q1_GP;
+  return d == 0 ? (2 * i - 1) * py * pz : (d == 1 ? (2 * j - 1) * px * pz : (2 * k - 1) * px * py);
+}
+
+// one Gauss point of the scalar Laplacian:  L_ab += (w / 512) / det' * sum_x g_x[a] g_x[b],  g_x = sum_d A_d[x] h_d
+// (off-diagonal pairs only); ws = w_g / 512
+template <int SX, int SY, int SZ>
+__device__ __forceinline__ void q1_laplace_point(const double (&C)[2][2][2][3], const double ws, double (&L)[28]) {
+  double A[3][3];
+  const double det = q1_point_adj<SX, SY, SZ>(C, A);
+  const double s = ws * q1_rcp(det);
+#pragma unroll
+  for (int x = 0; x < 3; ++x) {
+    double g[8];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int k = 0; k < 2; ++k)
+          g[Q1_NODE[i][j][k]] = fma(A[2][x], q1_h<SX, SY, SZ>(2, i, j, k),
+                                    fma(A[1][x], q1_h<SX, SY, SZ>(1, i, j, k), A[0][x] * q1_h<SX, SY, SZ>(0, i, j, k)));
+#pragma unroll
+    for (int a = 0; a < 7; ++a) {
+      const double t = s * g[a];
+#pragma unroll
+      for (int b = a + 1; b < 8; ++b) L[q1_off(a, b)] = fma(t, g[b], L[q1_off(a, b)]);
+    }
+  }
+}
+
+// the 28 off-diagonal entries of the element Laplacian (spectral.py:117-131 restricted to one component)
+__device__ __forceinline__ void q1_laplace_lean(const double (&P)[2][2][2][3], const double ws, double (&L)[28]) {
+  double C[2][2][2][3];
+  q1_haar_coeffs(P, C);
+#pragma unroll
+  for (int i = 0; i < 28; ++i) L[i] = 0.0;
+  q1_laplace_point<-1, -1, -1>(C, ws, L);
+  q1_laplace_point<+1, -1, -1>(C, ws, L);
+  q1_laplace_point<-1, +1, -1>(C, ws, L);
+  q1_laplace_point<+1, +1, -1>(C, ws, L);
+  q1_laplace_point<-1, -1, +1>(C, ws, L);
+  q1_laplace_point<+1, -1, +1>(C, ws, L);
+  q1_laplace_point<-1, +1, +1>(C, ws, L);
+  q1_laplace_point<+1, +1, +1>(C, ws, L);
+}
+
+template <int G>   // Gauss point G of the 2x2x2 rule: bit d of G = side of axis d
+__device__ __forceinline__ void q1_laplace_point_idx(const double (&C)[2][2][2][3], const double ws, double (&L)[28]) {
+  q1_laplace_point<(G & 1) * 2 - 1, ((G >> 1) & 1) * 2 - 1, ((G >> 2) & 1) * 2 - 1>(C, ws, L);
+}
+
+__device__ __forceinline__ double q1_sym(const double (&L)[28], int a, int b) { return a < b ? L[q1_off(a, b)] : L[q1_off(b, a)]; }
+
 }  // namespace

@@ -234,6 +234,13 @@ class Operators(Mat):
             m.assemble()
         self.mats = [self.Curl, self.DivSrT, self.SrT]
 
+    def lumpedWeights(self, bs):
+        """The lumped nodal weights repeated per DOF (the reference keeps their reciprocal in `weigCurl` etc.,
+        mat_generator.py:172-186, and inverts it again to weight its error norms, custom_func.py:145)."""
+        v = Vec(self.ctx, bs)
+        v.setArray(np.repeat(self.weights, bs))
+        return v
+
     def setValues(self, localOperators, nodes):
         raise NotImplementedError("per-cell Operators.setValues is replaced by Operators.assembleOperators(elem)")
 

@@ -399,9 +399,11 @@ def test_uniform_flow_kle(lib, nelem, ngl, tol):
     vvel, vrhs, vx = ctx.vec_create(dim), ctx.vec_create(dim), ctx.vec_create(dim)
     ctx.vec_set(vvel, vel.ravel())
     ctx.spmv(Krhs, vvel, vrhs)                      # vort = 0 -> rhs = Krhs * vel
-    info = ctx.solve(K, vrhs, vx, rtol=1e-15, atol=1e-14, norm_type=lib.NORM_UNPRECONDITIONED, maxit=20000)
+    # the settings of the API-level twin (KspSolver's preonly/lu substitute, tests/test_gpu_api.py:46-49): the reference's
+    # own bars -- 1e-12 (2-D, test_solver.py:20-27) and 2e-13 (3-D, :52-62) -- hold at the C ABI as well
+    info = ctx.solve(K, vrhs, vx, rtol=1e-14, atol=1e-300, dtol=1e8, norm_type=lib.NORM_UNPRECONDITIONED, maxit=200000)
     err = np.linalg.norm(ctx.vec_get(vx, dim) - np.tile(cte, mesh.n_node))
-    assert err < max(tol, 50 * 1e-14), (err, info.iters, info.reason)
+    assert err < tol, (err, info.iters, info.reason)
     ctx.close()
 
 
