@@ -11,15 +11,25 @@ One *step* = one pass of the hot path over that mesh:
         elimination; symbolic phase excluded)           -> element-DOFs/s
     (2) `--cg-iters` Jacobi-PCG iterations on the assembled matrix    -> CG iterations/s
 Inputs (connectivity, coordinates, CSR pattern, vectors) are resident in HBM before timing.
-After the timed steps the same CG runs once more with the matrix-free operator (`matrix_free` in the line).
 N > 1: the SAME mesh is row-partitioned in z-slabs over the ranks ("scaling": "strong"), halo
-planes and dot products go over RCCL inside libpynama_hip.so.
+planes and dot products go over RCCL inside libpynama_hip.so; a start-up self-test of the
+communicator runs first under a bounded wait (pynama_amd/common/comm.py).
+
+Next to the headline the same run reports, outside the timed region (N = 1 only):
+  * `roofline_assembly_general`: the assembly of the SAME mesh with jittered nodes -- the
+    quadrature path (the reference integrates every cell, spectral.py:117-156), not the
+    parallelepiped closed form the uniform box admits;
+  * `configs`: the other single-GPU configurations of BASELINE.json (C1 2-D plumbing case, C2
+    128^3 Poisson, C3 128^3 KLE with 3 DOFs per node, C5 5 M tetrahedra with GMRES(30)+Jacobi),
+    each with its residual check;
+  * `matrix_free`: the same CG with the operator recomputed from the mesh.
 
 The product path is torch-free: ranks/LOCAL_RANK come from the launcher's environment, the RCCL
 id is exchanged through a node-local file (pynama_amd/common/comm.py).
 Only the `cpu_baseline` leg touches oracle/ (the C restatement, as the thing timed on the CPU).
 """
 import argparse
+import glob
 import json
 import os
 import sys
@@ -33,12 +43,55 @@ sys.path.insert(0, ROOT)
 HBM_PEAK_GBS = 8000.0       # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s (spec)
 
 
-def algorithmic_bytes(n_elem, n_node, nnz, nn=8, dim=3):
-    """compulsory traffic, FP64 values, int32 indices."""
-    asm = 4 * nn * n_elem + 8 * dim * n_node + 4 * (n_node + 1) + 4 * nnz + 8 * nnz
-    spmv = 12 * nnz + 4 * (n_node + 1) + 16 * n_node
-    cg_iter = 12 * nnz + 148 * n_node
+def algorithmic_bytes(n_elem, n_node, nnz, nn=8, dim=3, ndof=1):
+    """compulsory traffic, FP64 values, int32 indices (block CSR for ndof > 1:
+    one node-level column index per ndof x ndof block)."""
+    nv = nnz * ndof * ndof
+    asm = 4 * nn * n_elem + 8 * dim * n_node + 4 * (n_node + 1) + 4 * nnz + 8 * nv
+    spmv = 8 * nv + 4 * nnz + 4 * (n_node + 1) + 16 * n_node * ndof
+    cg_iter = 8 * nv + 4 * nnz + 148 * n_node * ndof
     return asm, spmv, cg_iter
+
+
+def sell_entries(rowptr, ndof=1):
+    """stored entries of the SELL-64 image (slice width = longest scalar row of the slice)"""
+    ln = np.repeat(np.diff(rowptr).astype(np.int64) * ndof, ndof)
+    pad = (-len(ln)) % 64
+    if pad:
+        ln = np.concatenate([ln, np.zeros(pad, np.int64)])
+    return int(ln.reshape(-1, 64).max(axis=1).sum() * 64)
+
+
+def roofline(kernel, bytes_alg, ms, **extra):
+    gbs = bytes_alg / (ms * 1e-3) / 1e9 if ms > 0 else 0.0
+    out = {"kernel": kernel, "bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS,
+           "algorithmic_bytes_per_launch": bytes_alg, "ms_per_launch": ms}
+    out.update(extra)
+    return out
+
+
+class Traffic:
+    """HBM bytes per launch from the PMC counters: collected in separate rocprofv3 --pmc passes (never together with the timed
+    run), committed under profiles/ together with the hash of the kernel sources they were taken on.  Quoted only when that
+    hash is the one embedded in the library that just ran."""
+
+    def __init__(self, lib_hash):
+        self.lib_hash, self.k, self.why = lib_hash, {}, "no PMC summary under profiles/ was taken on these kernel sources"
+        for fn in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_*.json"))):
+            try:
+                with open(fn) as fh:
+                    d = json.load(fh)
+            except (OSError, ValueError):
+                continue
+            if d.get("source_hash") != lib_hash:
+                continue
+            for name, v in d.get("kernels", {}).items():
+                if "hbm_bytes_per_launch" in v:
+                    self.k[name] = {"bytes": v["hbm_bytes_per_launch"], "file": os.path.basename(fn)}
+
+    def get(self, kernel):
+        v = self.k.get(kernel)
+        return (v["bytes"], v["file"]) if v else (None, self.why)
 
 
 def cpu_baseline(dom, rp, ci, bmask, b, budget_s=8.0):
@@ -73,7 +126,193 @@ def cpu_baseline(dom, rp, ci, bmask, b, budget_s=8.0):
     return {"value": reps * m.n_elem * 8 / t_asm, "unit": "element-DOFs/s", "cores": cores, "kind": "port",
             "cg_iters_per_s": iters / t_cg,
             "sample": f"C/OpenMP oracle on {cores} threads: {reps} assembly passes over all {m.n_elem} elements "
-                      f"({t_asm:.1f} s) + {iters} Jacobi-PCG iterations on the full {m.n_node}-row matrix ({t_cg:.1f} s)"}
+                      f"({t_asm:.1f} s) + {iters} Jacobi-PCG iterations on the full {m.n_node}-row matrix ({t_cg:.1f} s); "
+                      "PETSc is not installable on the box, so the reference's own KSP path cannot be timed"}
+
+
+def smooth_load(X, h3, mask):
+    f = (1.0 + X[:, 0] + 2.0 * X[:, 1] ** 2 + np.exp(np.prod(X, axis=1)) * np.cos(3.0 * X[:, -1])) * h3
+    f[mask != 0] = 0.0
+    return f
+
+
+def median_assembly(ctx, fn, reps):
+    t = []
+    for _ in range(reps):
+        fn()
+        t.append(ctx.timers()["assemble_ms"])
+    return float(np.median(t)), float(np.min(t))
+
+
+# ---- the other single-GPU configurations of BASELINE.json (outside the timed region) ------------------------------------------
+def general_geometry_leg(_lib, DMPlexDom, Spectral, n, traffic, reps=5):
+    """assembly of the bench mesh with jittered nodes (0.2 h): the quadrature path"""
+    dom = DMPlexDom(boxMesh={"nelem": [n, n, n], "lower": [0, 0, 0], "upper": [1, 1, 1]}, jitter=0.2)
+    dom.setFemIndexing(2)
+    ctx = dom.ctx
+    for t in Spectral(2, 3).deviceTables():
+        ctx.tables_set(*t)
+    ctx.bc_set(1, dom.boundaryMaskLocal())
+    n_rows, nnz = ctx.csr_symbolic()
+    A = ctx.mat_create(1, 1)
+    ctx.assemble_scalar(_lib.FORM_LAPLACE, A, -1)
+    med, best = median_assembly(ctx, lambda: ctx.assemble_scalar(_lib.FORM_LAPLACE, A, -1), reps)
+    B_asm, _, _ = algorithmic_bytes(n ** 3, (n + 1) ** 3, nnz)
+    kern = "assemble_q1_hex_march_kernel"
+    tb, src = traffic.get(kern)
+    out = roofline(kern + " (z-marching quadrature path: lean closed form of the 2x2x2 rule per element, LDS rows, x-line stores)",
+                   B_asm, med, min_ms=best, element_dofs_per_s=n ** 3 * 8 / (med * 1e-3), traffic=tb, traffic_source=src,
+                   mesh=f"{n}^3 Q1 hex, nodes jittered by 0.2 h (general geometry, every element integrated with 8 Gauss points)",
+                   bound_note="FP64 VALU: about 1,770 FP64 instructions per element against 387 B of compulsory traffic")
+    ctx.close()
+    return out
+
+
+def config_poisson(_lib, DMPlexDom, Spectral, nelem, cg_iters, name):
+    dim = len(nelem)
+    dom = DMPlexDom(boxMesh={"nelem": nelem, "lower": [0] * dim, "upper": [1] * dim})
+    dom.setFemIndexing(2)
+    ctx = dom.ctx
+    for t in Spectral(2, dim).deviceTables():
+        ctx.tables_set(*t)
+    bm = dom.boundaryMaskLocal()
+    ctx.bc_set(1, bm)
+    n_rows, nnz = ctx.csr_symbolic()
+    A = ctx.mat_create(1, 1)
+    ctx.assemble_scalar(_lib.FORM_LAPLACE, A, -1)
+    med, best = median_assembly(ctx, lambda: ctx.assemble_scalar(_lib.FORM_LAPLACE, A, -1), 5)
+    ne, nn_e = int(np.prod(nelem)), 2 ** dim
+    B_asm, B_spmv, B_cg = algorithmic_bytes(ne, n_rows, nnz, nn=nn_e, dim=dim)
+    vb, vx = ctx.vec_create(1), ctx.vec_create(1)
+    ctx.vec_set(vb, smooth_load(dom.xyz[:dom.nOwned], 1.0 / ne, bm[:dom.nOwned]))
+    for _ in range(2):
+        info = ctx.solve(A, vb, vx, fixed_iters=cg_iters, norm_type=_lib.NORM_UNPRECONDITIONED, profile=1)
+    chk = ctx.solve(A, vb, vx, rtol=1e-10, maxit=20000, norm_type=_lib.NORM_UNPRECONDITIONED)
+    out = {"config": name, "n_elem": ne, "n_dof": n_rows, "nnz": nnz,
+           "assembly_ms": med, "element_dofs_per_s": ne * nn_e / (med * 1e-3),
+           "assembly_frac_of_hbm_peak": B_asm / (med * 1e-3) / 1e9 / HBM_PEAK_GBS,
+           "cg_iters_per_s": cg_iters / (info.solve_ms * 1e-3), "spmv_ms": info.spmv_ms,
+           "spmv_frac_of_hbm_peak": B_spmv / (info.spmv_ms * 1e-3) / 1e9 / HBM_PEAK_GBS if info.spmv_ms > 0 else None,
+           "cg_iteration_frac_of_hbm_peak": B_cg / (info.solve_ms / cg_iters * 1e-3) / 1e9 / HBM_PEAK_GBS,
+           "algorithmic_bytes": {"assembly": B_asm, "spmv": B_spmv, "cg_iteration": B_cg},
+           "check": {"cg_iters_to_rtol_1e-10": int(chk.iters), "reason": int(chk.reason), "true_residual": float(chk.true_resid)}}
+    ctx.close()
+    return out
+
+
+def config_kle(_lib, DMPlexDom, Spectral, n, cg_iters):
+    """C3: 3 DOFs per node on the 128^3 mesh -- the reference's KLE system stands in for 'linear elasticity' (SURVEY.md 0.3:
+    the reference has no elasticity form; K is its vector-valued stiffness with 3x3 blocks)"""
+    dom = DMPlexDom(boxMesh={"nelem": [n, n, n], "lower": [0, 0, 0], "upper": [1, 1, 1]})
+    dom.setFemIndexing(2)
+    ctx = dom.ctx
+    for t in Spectral(2, 3).deviceTables():
+        ctx.tables_set(*t)
+    bm = dom.boundaryMaskLocal()
+    ctx.bc_set(3, np.repeat(bm[:, None], 3, axis=1))
+    n_rows, nnz = ctx.csr_symbolic()
+    K, Krhs, Rw = ctx.mat_create(3, 3), ctx.mat_create(3, 3), ctx.mat_create(3, 3)
+    ctx.assemble_kle(1e3, 1e2, K, Krhs, Rw, -1)
+    med, best = median_assembly(ctx, lambda: ctx.assemble_kle(1e3, 1e2, K, Krhs, Rw, -1), 3)
+    B_asm1, B_spmv, B_cg = algorithmic_bytes(n ** 3, n_rows, nnz, ndof=3)
+    B_asm = 3 * B_asm1                      # three block matrices leave the assembly: K, Krhs, Rw (4.46 GB each, SURVEY.md 8d)
+    vel = np.zeros((dom.nOwned, 3))
+    vel[bm[:dom.nOwned] != 0] = [1.0, 0.0, 0.0]
+    vv, vr, vx = ctx.vec_create(3), ctx.vec_create(3), ctx.vec_create(3)
+    ctx.vec_set(vv, vel.ravel())
+    ctx.spmv(Krhs, vv, vr)                  # zero vorticity: rhs = Krhs v_bc (base_problem.py:479-481)
+    for _ in range(2):
+        info = ctx.solve(K, vr, vx, fixed_iters=cg_iters, profile=1)
+    chk = ctx.solve(K, vr, vx, rtol=1e-10, maxit=20000, norm_type=_lib.NORM_UNPRECONDITIONED)
+    err = float(np.abs(ctx.vec_get(vx, 3).reshape(-1, 3) - [1.0, 0.0, 0.0]).max())
+    out = {"config": f"C3: 3D KLE (3 DOF/node, alpha_d 1e3, alpha_w 1e2) on {n}^3 Q1 hex, uniform-flow boundary data", "n_elem": n ** 3,
+           "n_dof": 3 * n_rows, "nnz_blocks": nnz, "assembly_ms_K_Krhs_Rw": med,
+           "element_dofs_per_s": n ** 3 * 24 / (med * 1e-3),
+           "assembly_frac_of_hbm_peak": B_asm / (med * 1e-3) / 1e9 / HBM_PEAK_GBS,
+           "kernel": "assemble_q1_hex_kle_lattice_kernel (closed-form blocks on parallelepipeds, four waves per tile)",
+           "cg_iters_per_s": cg_iters / (info.solve_ms * 1e-3), "block_spmv_ms": info.spmv_ms,
+           "spmv_frac_of_hbm_peak": B_spmv / (info.spmv_ms * 1e-3) / 1e9 / HBM_PEAK_GBS if info.spmv_ms > 0 else None,
+           "cg_iteration_frac_of_hbm_peak": B_cg / (info.solve_ms / cg_iters * 1e-3) / 1e9 / HBM_PEAK_GBS,
+           "format": "block SELL-64, one node-level column pattern id per row (block-CSR byte model of SURVEY.md 8d: 5.29 GB / iteration)",
+           "algorithmic_bytes": {"assembly_3_matrices": B_asm, "spmv": B_spmv, "cg_iteration": B_cg},
+           "check": {"cg_iters_to_rtol_1e-10": int(chk.iters), "reason": int(chk.reason), "true_residual": float(chk.true_resid),
+                     "max_error_vs_exact_uniform_flow": err}}
+    ctx.close()
+    return out
+
+
+def kuhn_box(n, seed=2024):
+    """n^3 unit-box hexes -> 6 n^3 positively oriented tetrahedra, nodes randomly renumbered"""
+    from itertools import permutations
+    lat = n + 1
+    strides = np.array([1, lat, lat * lat])
+    i, j, k = np.meshgrid(np.arange(n), np.arange(n), np.arange(n), indexing="ij")
+    base = (i * strides[0] + j * strides[1] + k * strides[2]).ravel()
+    conn = []
+    for perm in permutations(range(3)):
+        offs = [0]
+        for d in perm:
+            offs.append(offs[-1] + strides[d])
+        if sum(1 for a in range(3) for b in range(a + 1, 3) if perm[a] > perm[b]) % 2:
+            offs[-1], offs[-2] = offs[-2], offs[-1]
+        conn.append(base[:, None] + np.array(offs)[None, :])
+    conn = np.stack(conn, axis=1).reshape(-1, 4)
+    ax = np.linspace(0.0, 1.0, lat)
+    z, y, x = np.meshgrid(ax, ax, ax, indexing="ij")
+    xyz = np.stack([x.ravel(), y.ravel(), z.ravel()], axis=1)
+    p = np.random.default_rng(seed).permutation(lat ** 3)
+    return xyz[np.argsort(p)], p[conn].astype(np.int32)
+
+
+def config_tets(_lib, DMPlexDom, n, gmres_iters):
+    """C5: unstructured tetrahedra in random node numbering, imported-mesh path (Morton renumbering, patch-plan P1 kernel),
+    GMRES(30)+Jacobi.  The mesh enters through the in-memory form of the Gmsh reader's result; the file round trip itself is
+    tests/test_gpu_fullsize.py::test_c5_unstructured_tets_gmsh_gmres (12 s of text parsing, not a device measurement)."""
+    from pynama_amd.elements.simplex import Simplex
+    xyz, conn = kuhn_box(n)
+    dom = DMPlexDom(mesh={"dim": 3, "xyz": xyz, "conn": conn, "facets": [], "cell": "simplex"})
+    dom.setFemIndexing(2)
+    ctx = dom.ctx
+    for t in Simplex(3).deviceTables():
+        ctx.tables_set(*t)
+    bm = dom.boundaryMaskLocal()
+    ctx.bc_set(1, bm)
+    n_rows, nnz = ctx.csr_symbolic()
+    A = ctx.mat_create(1, 1)
+    ctx.assemble_scalar(_lib.FORM_LAPLACE, A)
+    med, best = median_assembly(ctx, lambda: ctx.assemble_scalar(_lib.FORM_LAPLACE, A), 5)
+    ne = conn.shape[0]
+    B_asm, B_spmv, _ = algorithmic_bytes(ne, n_rows, nnz, nn=4)
+    vb, vx, vy = ctx.vec_create(1), ctx.vec_create(1), ctx.vec_create(1)
+    ctx.vec_set(vb, smooth_load(dom.xyz[:dom.nOwned], 1.0 / n ** 3, bm[:dom.nOwned]))
+    sp = []
+    for _ in range(5):
+        ctx.spmv(A, vb, vy)
+        sp.append(ctx.timers()["spmv_ms"])
+    spmv_ms = float(np.median(sp))
+    for _ in range(2):
+        info = ctx.solve(A, vb, vx, method=_lib.KSP_GMRES, pc=_lib.PC_JACOBI, fixed_iters=gmres_iters, restart=30, gmres_orthog=1)
+    # GMRES(m): inner step j costs 12 nnz + 20 N + 40 N (j + 1) bytes (SURVEY.md 8d); mean over a cycle of m = 30 steps
+    m = 30
+    B_gmres = 12 * nnz + 20 * n_rows + 40 * n_rows * (m + 1) / 2.0
+    chk = ctx.solve(A, vb, vx, method=_lib.KSP_GMRES, pc=_lib.PC_JACOBI, rtol=1e-10, restart=30, maxit=100000,
+                    norm_type=_lib.NORM_UNPRECONDITIONED, gmres_orthog=1)
+    basis_mb = 8.0 * n_rows * (m + 1) / 1e6
+    out = {"config": f"C5: {ne} linear tetrahedra ({n}^3 hexes cut in 6), {n_rows} nodes in random numbering -> Morton order, GMRES(30)+Jacobi",
+           "n_elem": ne, "n_dof": n_rows, "nnz": nnz, "assembly_ms": med, "element_dofs_per_s": ne * 4 / (med * 1e-3),
+           "assembly_frac_of_hbm_peak": B_asm / (med * 1e-3) / 1e9 / HBM_PEAK_GBS,
+           "kernel": "assemble_p1_tet_tiled_kernel (patches of 343 consecutive rows, LDS adds, rows written once)",
+           "spmv_ms": spmv_ms, "spmv_algorithmic_GBs": B_spmv / (spmv_ms * 1e-3) / 1e9,
+           "gmres_iters_per_s": gmres_iters / (info.solve_ms * 1e-3),
+           "gmres_iteration_algorithmic_GBs": B_gmres / (info.solve_ms / gmres_iters * 1e-3) / 1e9,
+           "gmres_iteration_frac_of_hbm_peak": B_gmres / (info.solve_ms / gmres_iters * 1e-3) / 1e9 / HBM_PEAK_GBS,
+           "residency_note": f"matrix ({12 * nnz / 1e6:.0f} MB) and Krylov basis ({basis_mb:.0f} MB) fit the 256 MiB Infinity Cache: "
+                             "these rates are cache rates, the HBM roofline is not the bound here (launch latency of the five "
+                             "kernels per inner step is)",
+           "algorithmic_bytes": {"assembly": B_asm, "spmv": B_spmv, "gmres_iteration_mean": B_gmres},
+           "check": {"gmres_iters_to_rtol_1e-10": int(chk.iters), "reason": int(chk.reason), "true_residual": float(chk.true_resid)}}
+    ctx.close()
+    return out
 
 
 def main():
@@ -85,10 +324,12 @@ def main():
     ap.add_argument("--cg-iters", type=int, default=100, help="fixed CG iterations per step")
     ap.add_argument("--variant", type=int, default=1, help="assembly kernel: 0 generic atomics, 1 auto (plan-free lattice kernel on box meshes), "
                     "2 patch-plan kernel on 7x7x7 tiles")
-    ap.add_argument("--jitter", type=float, default=0.0, help="diagnostics: perturb interior nodes by jitter*h (general geometry)")
+    ap.add_argument("--jitter", type=float, default=0.0, help="perturb interior nodes of the HEADLINE mesh by jitter*h (diagnostics; the "
+                    "general-geometry leg always runs on its own jittered mesh)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-check", action="store_true")
     ap.add_argument("--no-matfree", action="store_true", help="skip the matrix-free CG leg (reported alongside, not the headline)")
+    ap.add_argument("--no-extra", action="store_true", help="skip the general-geometry leg and the other BASELINE configurations")
     args = ap.parse_args()
 
     from pynama_amd import _lib
@@ -104,6 +345,9 @@ def main():
     dom = DMPlexDom(boxMesh={"nelem": [n, n, n], "lower": [0, 0, 0], "upper": [1, 1, 1]}, jitter=args.jitter)
     dom.setFemIndexing(2)
     ctx = dom.ctx                                     # creates the context, RCCL comm, uploads the mesh
+    selftest = None
+    if world.size > 1:                                # fail loudly BEFORE the timed region: rank echo, neighbours, halo planes
+        selftest = world.selftest(ctx, dom)
     for t in Spectral(2, 3).deviceTables():
         ctx.tables_set(*t)
     bmask = dom.boundaryMaskLocal()
@@ -115,11 +359,9 @@ def main():
     A = ctx.mat_create(1, 1)
     vb, vx = ctx.vec_create(1), ctx.vec_create(1)
     h = 1.0 / n
-    X = dom.xyz[:dom.nOwned]
     # lumped load of a smooth non-separable source (NOT a discrete eigenvector: with
     # f = sin sin sin on a uniform grid CG would converge in one iteration)
-    f = (1.0 + X[:, 0] + 2.0 * X[:, 1] ** 2 + np.exp(X[:, 0] * X[:, 1] * X[:, 2]) * np.cos(3.0 * X[:, 2])) * h ** 3
-    f[bmask[:dom.nOwned] != 0] = 0.0
+    f = smooth_load(dom.xyz[:dom.nOwned], h ** 3, bmask[:dom.nOwned])
     ctx.vec_set(vb, f)
 
     n_elem_global = n ** 3
@@ -136,8 +378,13 @@ def main():
                          norm_type=_lib.NORM_UNPRECONDITIONED, profile=1 if profile else 0)
         return t_asm, info.solve_ms, info.spmv_ms, info.reduce_ms, info.halo_ms
 
-    for _ in range(args.warmup):
-        step(False)
+    for k in range(args.warmup):
+        if world.size > 1 and k == 0:    # the first distributed step: overlapped halo exchange + one all-reduce per iteration
+            with world.bounded("first assembly + CG step across ranks (overlapped halo exchange, all-reduce per iteration)", 300):
+                step(False)
+                ctx.sync()
+        else:
+            step(False)
     ctx.barrier()
     ctx.sync()
     t0 = time.perf_counter()
@@ -165,6 +412,12 @@ def main():
         check = {"cg_iters_to_rtol_1e-10": int(info.iters), "reason": int(info.reason),
                  "true_residual": float(info.true_resid), "solve_ms": float(info.solve_ms)}
 
+    # ---- N > 1: the single-reduction (Chronopoulos-Gear) iteration runs across ranks; its one-rank time separates the cost of
+    # the algorithm from the cost of the wire in the scaling curve.  N = 1: the same form through a one-rank RCCL communicator
+    # is `tools/slab_case.py 1` (a second context; not repeated here)
+    cg_variant = "standard PCG, 3 launches per iteration (one rank)" if world.size == 1 else \
+                 "single-reduction PCG (Chronopoulos-Gear): one 24-byte all-reduce + one halo exchange per iteration"
+
     # ---- the same iteration with the matrix-free operator (outside the timed region; reported alongside, the
     # headline stays on the assembled matrix): no matrix values streamed, identical iterates
     mfree = None
@@ -188,41 +441,70 @@ def main():
         except _lib.PynamaHipError as e:
             mfree = {"error": str(e)}
 
+    one = world.rank == 0 and world.size == 1
     cpu = None
-    if world.rank == 0 and world.size == 1 and not args.no_cpu_baseline:
-        rp, ci = ctx.csr_get()
-        cpu = cpu_baseline(dom, rp, ci, bmask, f)
+    rp = None
+    if one:
+        rp, ci = ctx.csr_get(cols=not args.no_cpu_baseline)
+        if not args.no_cpu_baseline:
+            cpu = cpu_baseline(dom, rp, ci, bmask, f)
+            del ci
+    topo = ctx.mesh_topology()[0]
+    world_size, rank = world.size, world.rank
+    nranks_rccl = selftest["nranks_seen_by_rccl"] if selftest else 1
 
-    if world.rank == 0:
-        # HBM traffic per launch from the PMC counters: collected in separate rocprofv3 --pmc passes
-        # (never together with the timed run) and committed under profiles/; only valid for the
-        # default single-GPU workload they were measured on
-        traffic = {}
-        try:
-            if world.size == 1 and n == 215:
-                for fn in ("pmc_traffic.json", "pmc_assembly.json"):    # the assembly entry comes from its own passes
-                    tag = "r01e" if os.path.exists(os.path.join(ROOT, "profiles", "r01e_" + fn)) else "r01d"
-                    with open(os.path.join(ROOT, "profiles", f"{tag}_{fn}")) as fh:
-                        traffic.update({k: v["hbm_bytes_per_launch"] for k, v in json.load(fh)["kernels"].items()})
-        except (OSError, KeyError, ValueError):
-            traffic = {}
-        asm_kernel = ("assemble_q1_hex_lattice_kernel" if args.variant == 1 and ctx.mesh_topology()[0] == "lattice"
+    # the headline context is released before the other configurations allocate theirs
+    extra, general = None, None
+    traffic = Traffic(_lib.source_hash())
+    if one and not args.no_extra:
+        ctx.close()
+        general = general_geometry_leg(_lib, DMPlexDom, Spectral, n, traffic)
+        extra = {}
+        for key, fn in (("C1", lambda: config_poisson(_lib, DMPlexDom, Spectral, [32, 32], 100,
+                                                       "C1: 2D Poisson on 32x32 Q1 quads (the reference's CPU-runnable case; plumbing: launch-bound at 1,089 DOFs)")),
+                        ("C2", lambda: config_poisson(_lib, DMPlexDom, Spectral, [128, 128, 128], 100,
+                                                       "C2: 3D Poisson on 128^3 Q1 hex, FP64 assembly + Jacobi-PCG")),
+                        ("C3", lambda: config_kle(_lib, DMPlexDom, Spectral, 128, 50)),
+                        ("C5", lambda: config_tets(_lib, DMPlexDom, 94, 300))):
+            try:
+                extra[key] = fn()
+            except Exception as e:                      # a failing side configuration must not take the headline line with it
+                extra[key] = {"error": f"{type(e).__name__}: {e}"}
+        extra["C4"] = {"config": "C4: 256^3 over 8 GPUs", "note": "multi-GPU only: measured by `bench.py --gpus 8` at its own size class "
+                                                                     "(the N-GPU runs of this bench partition the 215^3 headline mesh)"}
+
+    if rank == 0:
+        asm_kernel = ("assemble_q1_hex_lattice_kernel" if args.variant == 1 and topo == "lattice" and args.jitter == 0.0
+                      else "assemble_q1_hex_march_kernel" if args.variant == 1 and topo == "lattice"
                       else "assemble_q1_hex_tiled_kernel" if args.variant != 0 else "assemble_generic_kernel")
         B_asm, B_spmv, B_cg = algorithmic_bytes(n_elem_global, n_node_global, nnz_global)
         # per-rank share of the algorithmic bytes (strong scaling: each GPU streams 1/N of them)
-        share = 1.0 / world.size
-        asm_gbs = B_asm * share / (asm_mean * 1e-3) / 1e9
-        spmv_gbs = B_spmv * share / (spmv_mean * 1e-3) / 1e9 if spmv_mean > 0 else 0.0
+        share = 1.0 / world_size
         cg_gbs = B_cg * share / (cg_mean / args.cg_iters * 1e-3) / 1e9
+        # the format the SpMV actually reads: SELL-64 values (padding included) + one 4-byte column-pattern id per row
+        # (dictionary mode) + x and y; quoted NEXT to the CSR-model `achieved` the metric definition prescribes
+        fmt = None
+        if rp is not None:
+            fmt_bytes = 8.0 * sell_entries(rp) + 4.0 * n_rows + 16.0 * n_rows
+            fmt = {"bytes_per_launch": fmt_bytes, "GBs": fmt_bytes / (spmv_mean * 1e-3) / 1e9,
+                   "frac": fmt_bytes / (spmv_mean * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                   "model": "8 B x SELL-64 stored entries (slice padding included) + 4 B pattern id per row + 16 B per row (x, y); "
+                            "no per-entry column index is streamed"}
+        tr_spmv, src_spmv = traffic.get("sellp_spmv_kernel")
+        tr_asm, src_asm = traffic.get(asm_kernel)
+        other = wall / args.steps * 1e3 - asm_mean - cg_mean
         out = {
             "metric": "assembled element-DOFs/sec + CG iterations/sec, 10M-DOF Poisson, 1/2/4/8 MI355X",
             "value": elem_dofs_per_step / (asm_mean * 1e-3),
             "unit": "element-DOFs/s (assembly phase); cg_iters_per_s alongside",
             "cg_iters_per_s": args.cg_iters / (cg_mean * 1e-3),
-            "n_gpus": world.size, "steps": args.steps, "warmup": args.warmup,
+            "n_gpus": world_size, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": wall / args.steps * 1e3,
             "breakdown_ms": {"assembly": asm_mean, "cg": cg_mean, "cg_iters": args.cg_iters,
                              "spmv_kernel": spmv_mean, "symbolic_once": symbolic_ms,
+                             # what a step spends outside the two metered phases: the SELL-64 image of the fresh values
+                             # (sell_fill_kernel; 1 / diagonal leaves the assembly with the rows) + launch gaps
+                             "cg_setup_and_gaps": other,
                              # N > 1 (single-reduction CG): end of the product -> all-reduced sums ready = partial sums + the one
                              # all-reduce, per iteration (the scalar step rides in the update kernel; 0 on one GPU)
                              "cg_reduction_per_iter": red_mean,
@@ -232,24 +514,28 @@ def main():
             "dtype": "f64", "data": "synthetic",
             "config": {"workload": f"3D Poisson, {n}^3 Q1 hex elements, {n_node_global} DOFs, nnz {nnz_global}, "
                                    f"FP64 assembly + Jacobi-PCG ({args.cg_iters} its/step)",
-                       "partition": f"z-slabs x{world.size}", "assembly_variant": args.variant},
-            "roofline": {"kernel": "sellp_spmv_kernel (SELL-64 + column-pattern dictionary SpMV inside CG)", "bound": "hbm", "achieved": spmv_gbs,
-                         "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": spmv_gbs / HBM_PEAK_GBS, "traffic": traffic.get("sellp_spmv_kernel"),
-                         "algorithmic_bytes_per_launch": B_spmv * share},
-            "roofline_assembly": {"kernel": asm_kernel + " (zero + integration + scatter, one launch)", "bound": "hbm",
-                                  "achieved": asm_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                                  "frac": asm_gbs / HBM_PEAK_GBS,
-                                  "traffic": traffic.get(asm_kernel) if args.jitter == 0.0 else None,
-                                  "algorithmic_bytes_per_launch": B_asm * share},
+                       "partition": f"z-slabs x{world_size}", "assembly_variant": args.variant, "cg_variant": cg_variant,
+                       "nranks_seen_by_rccl": nranks_rccl, "kernel_source_hash": _lib.source_hash()},
+            "roofline": roofline("sellp_spmv_kernel (SELL-64 + column-pattern dictionary SpMV inside CG)", B_spmv * share, spmv_mean,
+                                 traffic=tr_spmv, traffic_source=src_spmv, format_actually_read=fmt,
+                                 note="`achieved` = SURVEY.md 8(d)'s CSR byte model (12 nnz + 4 (N+1) + 16 N) / measured launch time, as the "
+                                      "metric prescribes; `format_actually_read` prices the bytes this kernel really streams"),
+            "roofline_assembly": roofline(asm_kernel + " (zero + integration + scatter, one launch"
+                                          + (": parallelepiped closed form, exact on the uniform box)" if asm_kernel.endswith("lattice_kernel") else ")"),
+                                          B_asm * share, asm_mean, traffic=tr_asm, traffic_source=src_asm),
+            "roofline_assembly_general": general,
             "roofline_cg_iteration": {"bound": "hbm", "achieved": cg_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                       "frac": cg_gbs / HBM_PEAK_GBS, "algorithmic_bytes_per_iteration": B_cg * share},
             "check": check,
-            "matrix_free": dict(mfree, traffic=traffic.get("lattice_matfree_laplace_march_kernel")) if mfree and "error" not in mfree else mfree,
+            "selftest": selftest,
+            "matrix_free": mfree,
+            "configs": extra,
             "cpu_baseline": cpu,
         }
         print(json.dumps(out))
     world.cleanup()
-    ctx.close()
+    if not (one and not args.no_extra):
+        ctx.close()
 
 
 if __name__ == "__main__":

@@ -57,6 +57,7 @@ enum { PYN_CONVERGED_RTOL = 2, PYN_CONVERGED_ATOL = 3, PYN_CONVERGED_ITS = 4,
 
 const char* pyn_last_error(void);
 int pyn_version(void);
+const char* pyn_source_hash(void);   /* first 16 hex digits of the sha256 of the kernel sources this library was built from */
 int pyn_device_count(int* count);
 
 /* ---- context -------------------------------------------------------------------------- */
@@ -83,6 +84,13 @@ int pyn_comm_init(pyn_ctx* ctx, int rank, int nranks, const void* unique_id, int
 int pyn_comm_init_shm(pyn_ctx* ctx, int rank, int nranks, const char* path, int64_t cap_bytes);
 int pyn_comm_barrier(pyn_ctx* ctx);               /* device + host barrier over all ranks */
 int pyn_comm_allreduce_f64(pyn_ctx* ctx, double* inout, int n, int op /*0 sum, 1 max*/);
+/* Start-up self-test of the communicator: RCCL's own rank count, all-reduce of 1 and of the rank, one halo exchange of a
+ * rank-stamped vector on the main stream and one on the communication stream (the overlapped form of the CG), each checked
+ * on the receiver.  info[5]: ranks seen by RCCL, sum(1), sum(rank), ghosts checked (main / communication stream).  The
+ * reference's analogue is implicit: PETSc checks its communicator at KSPSetUp / MatAssemblyEnd (src/solver/ksp_solver.py:19,
+ * src/matrices/mat_generator.py:14-17).  Call after pyn_halo_set. */
+int pyn_comm_selftest(pyn_ctx* ctx, double* info, int ninfo);
+
 /* Row partition + halo plan of this rank.  Local node numbering: owned nodes
  * [0, n_owned) in global order, then ghosts grouped by owning neighbour (recv order).
  *   send_idx[send_ptr[k] .. send_ptr[k+1]) : owned local node ids sent to neigh[k]
@@ -140,6 +148,7 @@ int pyn_patch_plan_set_kind(pyn_ctx* ctx, int kind, int n_patch, const int32_t* 
  * Handles are small non-negative ints.  A vector with block size b has (n_owned+n_ghost)*b
  * entries; only the owned part is meaningful to the caller. */
 int pyn_mat_create(pyn_ctx* ctx, int br, int bc, int* mat_id);      /* mat_generator.py:95-99 */
+int pyn_mat_destroy(pyn_ctx* ctx, int mat_id);                      /* Mat.destroy(): values, solver image and Jacobi data are released, the handle dies */
 int pyn_mat_zero(pyn_ctx* ctx, int mat_id);
 int pyn_mat_get_values(pyn_ctx* ctx, int mat_id, double* val);      /* layout above */
 int pyn_mat_get_diagonal(pyn_ctx* ctx, int mat_id, int vec_id);

@@ -61,6 +61,7 @@ SIGNATURES = {
     "pyn_comm_init_shm": [_P, _I, _I, C.c_char_p, _L],
     "pyn_comm_barrier": [_P],
     "pyn_comm_allreduce_f64": [_P, _pf64, _I, _I],
+    "pyn_comm_selftest": [_P, _pf64, _I],
     "pyn_halo_set": [_P, _L, _L, _I, _pi32, _pi64, _pi32, _pi64],
     "pyn_mesh_set": [_P, _I, _I, _L, _L, _pi32, _pf64],
     "pyn_mesh_topology": [_P, C.POINTER(_I), C.POINTER(_I), C.POINTER(_I), C.POINTER(_I)],
@@ -72,6 +73,7 @@ SIGNATURES = {
     "pyn_patch_plan_set": [_P, _I, _P, _P],
     "pyn_patch_plan_set_kind": [_P, _I, _I, _P, _P],
     "pyn_mat_create": [_P, _I, _I, C.POINTER(_I)],
+    "pyn_mat_destroy": [_P, _I],
     "pyn_mat_zero": [_P, _I],
     "pyn_mat_get_values": [_P, _I, _pf64],
     "pyn_mat_get_diagonal": [_P, _I, _I],
@@ -128,8 +130,9 @@ def load_library():
         fn = getattr(lib, name)          # AttributeError if the symbol is missing
         fn.argtypes = args
         fn.restype = C.c_int
-    lib.pyn_last_error.argtypes = []
-    lib.pyn_last_error.restype = C.c_char_p
+    for name in ("pyn_last_error", "pyn_source_hash"):
+        getattr(lib, name).argtypes = []
+        getattr(lib, name).restype = C.c_char_p
     _lib = lib
     return lib
 
@@ -137,6 +140,11 @@ def load_library():
 def _check(rc):
     if rc != 0:
         raise PynamaHipError(f"[{rc}] {_lib.pyn_last_error().decode(errors='replace')}")
+
+
+def source_hash() -> str:
+    """identity of the kernel sources the loaded library was built from (profiles/*.json record it)"""
+    return load_library().pyn_source_hash().decode()
 
 
 def device_count() -> int:
@@ -235,6 +243,13 @@ class Context:
         _check(self.lib.pyn_comm_allreduce_f64(self.h, a, a.size, 1 if op == "max" else 0))
         return a
 
+    def comm_selftest(self):
+        """rank count seen by RCCL, all-reduce of 1 / of the rank, rank-stamped halo exchange on both streams (raises on a mismatch)"""
+        info = np.zeros(8)
+        _check(self.lib.pyn_comm_selftest(self.h, info, info.size))
+        return {"nranks_seen_by_rccl": int(info[0]), "allreduce_sum_ones": info[1], "allreduce_sum_ranks": info[2],
+                "halo_ghosts_checked_main_stream": int(info[3]), "halo_ghosts_checked_comm_stream": int(info[4])}
+
     def halo_set(self, n_owned, n_ghost, neigh, send_ptr, send_idx, recv_ptr):
         neigh = _i32(neigh)
         _check(self.lib.pyn_halo_set(self.h, n_owned, n_ghost, len(neigh), neigh if len(neigh) else np.zeros(1, np.int32),
@@ -280,6 +295,7 @@ class Context:
     # -- graph
     def csr_symbolic(self):
         _check(self.lib.pyn_csr_symbolic(self.h))
+        self.graph_gen = getattr(self, "graph_gen", 0) + 1     # every matrix handle of the previous graph is dead now
         nr, nz = _L(0), _L(0)
         _check(self.lib.pyn_csr_info(self.h, C.byref(nr), C.byref(nz)))
         self.n_rows, self.nnzb = nr.value, nz.value
@@ -317,6 +333,10 @@ class Context:
 
     def mat_row_scale(self, mid, vid):
         _check(self.lib.pyn_mat_row_scale(self.h, mid, vid))
+
+    def mat_destroy(self, mid):
+        if self.h:
+            _check(self.lib.pyn_mat_destroy(self.h, mid))
 
     def mat_diagonal(self, mid, vid):
         _check(self.lib.pyn_mat_get_diagonal(self.h, mid, vid))

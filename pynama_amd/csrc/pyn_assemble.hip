@@ -1029,7 +1029,7 @@ static int mat_ptr(pyn_ctx* c, int id, int br, int bc, const char* name, double*
   PYN_TRY(pyn_check_mat(c, id, name));
   DMat& m = c->mats[id];
   PYN_CHECK(m.br == br && m.bc == bc, "%s must have block shape %dx%d (has %dx%d)", name, br, bc, m.br, m.bc);
-  m.sell_valid = false;  // values are about to change
+  m.touch();  // values are about to change
   *out = m.val;
   return PYN_OK;
 }
@@ -1143,7 +1143,18 @@ extern "C" int pyn_assemble_scalar(pyn_ctx* c, int form, int Aid, int Arhs, int 
   double *pA, *pAr;
   PYN_TRY(mat_ptr(c, Aid, 1, 1, "A", &pA));
   PYN_TRY(mat_ptr(c, Arhs, 1, 1, "Arhs", &pAr));
-  return run_assembly(c, form, 0.0, 0.0, pA, pAr, nullptr, nullptr, variant);
+  // the Jacobi data of A: kernels that see whole rows (lattice store phases) write 1 / diagonal on the way out
+  c->asm_dinv = nullptr;
+  c->asm_dinv_written = false;
+  if (Aid >= 0 && form == PYN_FORM_LAPLACE && !getenv("PYNAMA_NO_ASM_DINV")) {
+    DMat& m = c->mats[Aid];
+    if (!m.dinv) PYN_HIP(hipMalloc((void**)&m.dinv, (size_t)c->n_owned * sizeof(double)));
+    c->asm_dinv = m.dinv;
+  }
+  const int rc = run_assembly(c, form, 0.0, 0.0, pA, pAr, nullptr, nullptr, variant);
+  if (rc == PYN_OK && c->asm_dinv && c->asm_dinv_written) c->mats[Aid].dinv_valid = true;
+  c->asm_dinv = nullptr;
+  return rc;
 }
 
 extern "C" int pyn_elem_local(pyn_ctx* c, int form, double alpha_d, double alpha_w, const double* corners, double* out0,
@@ -1222,7 +1233,7 @@ extern "C" int pyn_assemble_operator(pyn_ctx* c, int rule, int nterms, const int
   A.op_terms = dt;
   A.op_coef = dc;
   A.K = M.val;
-  M.sell_valid = false;
+  M.touch();
   PYN_HIP(hipEventRecord(c->ev0, c->stream));
   PYN_HIP(hipMemsetAsync(M.val, 0, (size_t)c->nnzb * M.br * M.bc * sizeof(double), c->stream));
   PYN_TRY(launch_generic<false>(c, A, c->n_elem));

@@ -164,9 +164,9 @@ __global__ void __launch_bounds__(TILE_THREADS, AFF ? 3 : 2) assemble_q1_hex_lat
   }
   const int anybc = __syncthreads_or(lat_meta_commit<TX, TY, TZ, TILE_THREADS>(T, z0, tid, meta, rlo, zrd, nbc));
   if (lat_tile_plain<TX, TY, TZ>(T, x0, y0, z0, zrd, anybc) && T.ablate != 4)
-    lat_store_plain<TX, TY, TZ>(T, acc, rlo, tid, TILE_THREADS);
+    lat_store_plain<TX, TY, TZ>(T, acc, rlo, tid, TILE_THREADS, x0, y0, z0);
   else
-    lat_store<TX, TY, TZ>(T, x0, y0, acc, rlo, zrd, nbc, tid, TILE_THREADS);
+    lat_store<TX, TY, TZ>(T, x0, y0, acc, rlo, zrd, nbc, tid, TILE_THREADS, z0);
 }
 
 // y_e = L_e x_e for a parallelepiped WITHOUT forming L_e: in the Haar basis of each axis ((v0, v1) -> (s, d) = (v0 + v1,
@@ -1162,6 +1162,7 @@ static int lat_fill_args(pyn_ctx* c, LatArgs& T, double* A, double* Arhs, int* m
   T.q.aff = getenv("PYNAMA_NO_AFFINE") ? nullptr : c->d_aff;
   T.A = A;
   T.Arhs = Arhs;
+  T.dinv = nullptr;
   const char* ab = getenv("PYNAMA_LATTICE_ABLATE");  // diagnostics: 1 = no element phase, 4 = no plain-tile store path
   T.ablate = ab ? atoi(ab) : 0;
   T.lean = c->q1_gauss_standard && !getenv("PYNAMA_NO_LEAN") ? 1 : 0;
@@ -1247,6 +1248,8 @@ int pyn_assemble_lattice(pyn_ctx* c, double* A, double* Arhs, bool* handled) {
   LatArgs T;
   int mesh_aff = 0;
   PYN_TRY(lat_fill_args(c, T, A, Arhs, &mesh_aff));
+  T.dinv = c->asm_dinv;            // the store phases see whole rows: 1 / diagonal leaves with them (no diag_kernel pass)
+  c->asm_dinv_written = T.dinv != nullptr;
   const bool affine = mesh_aff == 1 && T.q.aff != nullptr && c->aff_standard;
   // measured at 10M DOFs: parallelepipeds are store-bound -> small tiles, 5 workgroups per CU;
   // the quadrature path is FP64-bound -> 7x7x7 tiles (least redundant integration that fits the LDS twice)

@@ -269,9 +269,9 @@ __global__ void __launch_bounds__((TX + 1) * (TY + 1), WPS) assemble_q1_hex_marc
     if (own_b && !(T.ablate & 8)) {
       double* buf = lds + (l & 1) * MT::ACC;
       if (lat_tile_plain<TX, TY, 1>(T, x0, y0, l, zrd, anybc) && T.ablate != 4)
-        lat_store_plain<TX, TY, 1, true>(T, buf, rlo, tid, NT);
+        lat_store_plain<TX, TY, 1, true>(T, buf, rlo, tid, NT, x0, y0, l);
       else
-        lat_store<TX, TY, 1, true>(T, x0, y0, buf, rlo, zrd, nbc, tid, NT);
+        lat_store<TX, TY, 1, true>(T, x0, y0, buf, rlo, zrd, nbc, tid, NT, l);
     }
     MARCH_STAMP(6);
     if (T.dbg && tid == 0 && l - zc0 + 1 < 32) T.dbg[((size_t)blockIdx.x * 32 + (l - zc0 + 1)) * 8 + 7] = __builtin_amdgcn_s_memrealtime();

@@ -42,7 +42,11 @@ void pyn_set_error(const char* fmt, ...) {
 }
 
 extern "C" const char* pyn_last_error(void) { return g_err; }
-extern "C" int pyn_version(void) { return 100; }
+extern "C" int pyn_version(void) { return 101; }
+#ifndef PYN_SRC_HASH
+#define PYN_SRC_HASH "unknown"
+#endif
+extern "C" const char* pyn_source_hash(void) { return PYN_SRC_HASH; }
 
 extern "C" int pyn_device_count(int* count) {
   PYN_CHECK(count, "count is NULL");
@@ -124,6 +128,7 @@ extern "C" int pyn_ctx_destroy(pyn_ctx* c) {
   for (auto& m : c->mats) {
     (void)hipFree(m.val);
     (void)hipFree(m.sell_val);
+    (void)hipFree(m.dinv);
   }
   pyn_sell_drop_structure(c);
   for (auto& v : c->vecs) (void)hipFree(v.d);
@@ -285,6 +290,60 @@ extern "C" int pyn_comm_barrier(pyn_ctx* c) {
   PYN_HIP(hipStreamSynchronize(c->stream));
   double one = 1.0;
   return pyn_comm_allreduce_f64(c, &one, 1, 0);
+}
+
+__global__ void selftest_fill_kernel(double* x, int64_t n_owned, int64_t n_all, double stamp) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n_all; i += (int64_t)gridDim.x * blockDim.x)
+    x[i] = i < n_owned ? stamp : -1.0;
+}
+
+// Start-up self-test of the communicator (bench.py --gpus N runs it before anything is timed, under a host watchdog that
+// names the phase and exits if a collective never returns): (1) what RCCL thinks the world is, (2) all-reduce of 1 and of
+// the rank, (3) one halo exchange of a rank-stamped vector on the main stream, checked on the receiver, (4) the same on the
+// communication stream with the event ordering the overlapped CG uses.  info: [0] ranks seen by RCCL, [1] sum of ones,
+// [2] sum of ranks, [3] ghosts checked (main stream), [4] ghosts checked (communication stream).
+extern "C" int pyn_comm_selftest(pyn_ctx* c, double* info, int ninfo) {
+  PYN_CHECK(c && info && ninfo >= 5, "bad arguments");
+  for (int i = 0; i < ninfo; ++i) info[i] = 0.0;
+  PYN_CHECK(pyn_has_comm(c), "self-test needs a communicator");
+  PYN_HIP(hipSetDevice(c->device));
+  int seen = c->nranks;
+  if (c->comm) PYN_NCCL(ncclCommCount(c->comm, &seen));
+  info[0] = seen;
+  PYN_CHECK(seen == c->nranks, "RCCL communicator has %d ranks, the launcher declared %d", seen, c->nranks);
+  double v[2] = {1.0, (double)c->rank};
+  PYN_TRY(pyn_comm_allreduce_f64(c, v, 2, 0));
+  info[1] = v[0];
+  info[2] = v[1];
+  const double want = 0.5 * c->nranks * (c->nranks - 1);
+  PYN_CHECK(v[0] == (double)c->nranks && v[1] == want, "all-reduce self-test: sum(1) = %g (want %d), sum(rank) = %g (want %g)", v[0],
+            c->nranks, v[1], want);
+  if (c->neigh.empty() || !c->halo_set) return PYN_OK;
+  const int64_t na = c->n_owned + c->n_ghost;
+  DevTmp x;
+  PYN_HIP(x.alloc((size_t)na * sizeof(double)));
+  std::vector<double> ghosts((size_t)c->n_ghost);
+  for (int pass = 0; pass < 2; ++pass) {
+    const double base = pass == 0 ? 1.0 : 101.0;   // stamp = base + rank
+    selftest_fill_kernel<<<1024, 256, 0, c->stream>>>(x.as<double>(), c->n_owned, na, base + c->rank);
+    if (pass == 0) {
+      PYN_TRY(pyn_halo_exchange(c, x.as<double>(), 1));
+    } else {   // as in solve_cg_sr: vector ready -> exchange on the communication stream -> main stream waits for the ghosts
+      PYN_HIP(hipEventRecord(c->ev_vec, c->stream));
+      PYN_HIP(hipStreamWaitEvent(c->comm_stream, c->ev_vec, 0));
+      PYN_TRY(pyn_halo_exchange_on(c, x.as<double>(), 1, c->comm_stream));
+      PYN_HIP(hipEventRecord(c->ev_halo, c->comm_stream));
+      PYN_HIP(hipStreamWaitEvent(c->stream, c->ev_halo, 0));
+    }
+    PYN_HIP(hipMemcpyAsync(ghosts.data(), x.as<double>() + c->n_owned, (size_t)c->n_ghost * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    PYN_HIP(hipStreamSynchronize(c->stream));
+    for (size_t k = 0; k < c->neigh.size(); ++k)
+      for (int64_t j = c->recv_ptr[k]; j < c->recv_ptr[k + 1]; ++j)
+        PYN_CHECK(ghosts[(size_t)j] == base + c->neigh[k], "halo self-test (%s stream): ghost %lld from rank %d holds %g, want %g",
+                  pass ? "communication" : "main", (long long)j, c->neigh[k], ghosts[(size_t)j], base + c->neigh[k]);
+    info[3 + pass] = (double)c->n_ghost;
+  }
+  return PYN_OK;
 }
 
 extern "C" int pyn_halo_set(pyn_ctx* c, int64_t n_owned, int64_t n_ghost, int n_neigh, const int32_t* neigh,
@@ -541,11 +600,22 @@ extern "C" int pyn_mat_create(pyn_ctx* c, int br, int bc, int* mat_id) {
   return PYN_OK;
 }
 
+extern "C" int pyn_mat_destroy(pyn_ctx* c, int id) {
+  PYN_TRY(pyn_check_mat(c, id, "pyn_mat_destroy"));
+  DMat& m = c->mats[id];
+  PYN_HIP(hipStreamSynchronize(c->stream));   // no kernel in flight may still read the arrays
+  (void)hipFree(m.val);
+  (void)hipFree(m.sell_val);
+  (void)hipFree(m.dinv);
+  m = DMat();   // live = false: the handle is dead, its slot is not reused (handles stay stable)
+  return PYN_OK;
+}
+
 extern "C" int pyn_mat_zero(pyn_ctx* c, int id) {
   PYN_TRY(pyn_check_mat(c, id, "pyn_mat_zero"));
   DMat& m = c->mats[id];
   PYN_HIP(hipMemsetAsync(m.val, 0, (size_t)c->nnzb * m.br * m.bc * sizeof(double), c->stream));
-  m.sell_valid = false;
+  m.touch();
   return PYN_OK;
 }
 

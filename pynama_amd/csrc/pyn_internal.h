@@ -80,7 +80,10 @@ struct DMat {
   double* val = nullptr;  // [nnzb*br*bc], layout in pynama_hip.h
   double* sell_val = nullptr;  // SELL-64 image of `val` (scalar matrices, solver side)
   bool sell_valid = false;
+  double* dinv = nullptr;      // 1 / diagonal per scalar row (Jacobi), written by the lattice assemblies in their store
+  bool dinv_valid = false;     // phase, else extracted once per matrix version (pyn_dinv_ensure)
   bool live = false;
+  void touch() { sell_valid = dinv_valid = false; }   // the values are about to change
 };
 
 struct PatchPlan {
@@ -196,6 +199,9 @@ struct pyn_ctx {
   double* d_work = nullptr;
   size_t work_bytes = 0;
   std::vector<hipEvent_t> prof_ev;  // event pool for per-kernel timing
+  // 1/diagonal target of the scalar assembly in flight (the K matrix's DMat::dinv) and whether a kernel filled it
+  double* asm_dinv = nullptr;
+  bool asm_dinv_written = false;
   // element-local scratch for pyn_elem_local
   double* d_eloc = nullptr;
   size_t eloc_bytes = 0;
@@ -212,6 +218,7 @@ int pyn_check_vec(pyn_ctx* c, int id, const char* what);
 int pyn_reduce_host(pyn_ctx* c, int nslots, int nblocks, int op, double* out);  // partials -> host, allreduced
 int pyn_spmv_raw(pyn_ctx* c, const DMat& A, const double* x, double* y);        // no halo exchange
 int pyn_extract_diag_inv(pyn_ctx* c, const DMat& A, double* dinv, bool invert);
+int pyn_dinv_ensure(pyn_ctx* c, DMat& A);   // A.dinv valid for the current values (one diag_kernel per matrix version at most)
 int pyn_sell_ensure(pyn_ctx* c, DMat& A);
 bool pyn_sell_supported(const DMat& A);
 int pyn_sell_spmv(pyn_ctx* c, const DMat& A, const double* x, double* y, bool dot, int* grid_out);

@@ -588,6 +588,16 @@ int pyn_extract_diag_inv(pyn_ctx* c, const DMat& A, double* d, bool invert) {
   return PYN_OK;
 }
 
+int pyn_dinv_ensure(pyn_ctx* c, DMat& A) {
+  PYN_CHECK(A.br == A.bc, "diagonal of a non-square block matrix");
+  if (!A.dinv) PYN_HIP(hipMalloc((void**)&A.dinv, (size_t)c->n_owned * A.br * sizeof(double)));
+  if (!A.dinv_valid) {
+    PYN_TRY(pyn_extract_diag_inv(c, A, A.dinv, true));
+    A.dinv_valid = true;
+  }
+  return PYN_OK;
+}
+
 extern "C" int pyn_mat_get_diagonal(pyn_ctx* c, int mat_id, int vec_id) {
   PYN_TRY(pyn_check_mat(c, mat_id, "get_diagonal"));
   PYN_TRY(pyn_check_vec(c, vec_id, "get_diagonal"));
@@ -605,7 +615,7 @@ extern "C" int pyn_mat_axpy(pyn_ctx* c, int ym, double a, int xm) {
   DMat &Y = c->mats[ym], &X = c->mats[xm];
   PYN_CHECK(Y.br == X.br && Y.bc == X.bc, "block shape mismatch");
   int64_t n = c->nnzb * Y.br * Y.bc;
-  Y.sell_valid = false;
+  Y.touch();
   mat_axpy_kernel<<<vgrid(n), 256, 0, c->stream>>>(Y.val, a, X.val, n);
   return PYN_OK;
 }
@@ -632,7 +642,7 @@ extern "C" int pyn_mat_row_scale(pyn_ctx* c, int mat_id, int vec_id) {
   DMat& A = c->mats[mat_id];
   PYN_CHECK(c->vecs[vec_id].bs == A.br, "block size mismatch");
   int64_t rows = c->n_owned * A.br;
-  A.sell_valid = false;
+  A.touch();
   int grid = (int)std::max<int64_t>(1, std::min<int64_t>((rows * 64 + 255) / 256, 8192));
   row_scale_kernel<<<grid, 256, 0, c->stream>>>(c->d_rowptr, A.val, c->vecs[vec_id].d, c->n_owned, A.br, A.bc);
   return PYN_OK;
@@ -733,8 +743,9 @@ static int solve_cg(pyn_ctx* c, DMat& A, const double* b, double* x, const pyn_s
   double* dinv = Ap + n;
   double* hist = dinv + n;
   const bool jac = o.pc == PYN_PC_JACOBI;
-  if (jac) PYN_TRY(pyn_extract_diag_inv(c, A, dinv, true));
-  const double* dv = jac ? dinv : nullptr;
+  if (jac) PYN_TRY(pyn_dinv_ensure(c, A));   // cached per matrix version (written by the lattice assemblies themselves)
+  const double* dv = jac ? A.dinv : nullptr;
+  (void)dinv;
   const int g = vgrid(n);
   const int64_t rows = n;
   const int gs = (int)std::max<int64_t>(1, std::min<int64_t>((rows * 32 + 255) / 256, PYN_MAX_PARTIALS));
@@ -838,8 +849,9 @@ static int solve_cg_sr(pyn_ctx* c, DMat& A, const double* b, double* x, const py
   double* dinv = sv + n;
   double* hist = dinv + n;
   const bool jac = o.pc == PYN_PC_JACOBI;
-  if (jac) PYN_TRY(pyn_extract_diag_inv(c, A, dinv, true));
-  const double* dv = jac ? dinv : nullptr;
+  if (jac) PYN_TRY(pyn_dinv_ensure(c, A));   // cached per matrix version (written by the lattice assemblies themselves)
+  const double* dv = jac ? A.dinv : nullptr;
+  (void)dinv;
   const int g = vgrid(n);
   const int64_t rows = n;
   const int gs = (int)std::max<int64_t>(1, std::min<int64_t>((rows * 32 + 255) / 256, PYN_MAX_PARTIALS));
@@ -1174,8 +1186,9 @@ static int solve_gmres(pyn_ctx* c, DMat& A, const double* b, double* x, const py
   // grid of the update that also leaves the |vn|^2 partials: they may spill over all rows of mpart (consumed by then)
   const int gn = (int)std::min<int64_t>(vgrid(n), (int64_t)(m + 1) * MD_GRID);
   const bool jac = o.pc == PYN_PC_JACOBI;
-  if (jac) PYN_TRY(pyn_extract_diag_inv(c, A, dinv, true));
-  const double* dv = jac ? dinv : nullptr;
+  if (jac) PYN_TRY(pyn_dinv_ensure(c, A));   // cached per matrix version (written by the lattice assemblies themselves)
+  const double* dv = jac ? A.dinv : nullptr;
+  (void)dinv;
   hipStream_t s = c->stream;
   const int g = vgrid(n);
   PYN_HIP(hipMemsetAsync(x, 0, n * sizeof(double), s));

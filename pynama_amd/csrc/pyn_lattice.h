@@ -35,6 +35,7 @@ struct LatArgs {
   TileArgs q;              // quadrature tables (w, hrs, hcoo, aff) -- only those fields are used
   double* A;
   double* Arhs;
+  double* dinv = nullptr;              // 1 / diagonal per owned row, written with the rows (may be null)
   unsigned long long* dbg = nullptr;   // diagnostics (PYNAMA_MARCH_STAMPS): per-phase s_memtime stamps of the marching kernels
 };
 
@@ -212,7 +213,7 @@ __device__ __forceinline__ void lat_integrate(const LatArgs& T, int x0, int y0, 
 // ZERO: clear each accumulator after reading it (the z-marching kernels reuse the buffer for the next plane).
 template <int TX, int TY, int TZ, bool ZERO = false>
 __device__ __forceinline__ void lat_store(const LatArgs& T, int x0, int y0, double* acc, const int* rlo, const int* zrd,
-                                          const unsigned char* nbc, int t, int nt) {
+                                          const unsigned char* nbc, int t, int nt, int z0 = 0) {
   using LT = LatTile<TX, TY, TZ>;
   const int nx = T.nx, ny = T.ny;
   double* __restrict__ outA = T.A;
@@ -261,6 +262,11 @@ __device__ __forceinline__ void lat_store(const LatArgs& T, int x0, int y0, doub
       if (lo[u] >= 0) {
         outA[lo[u]] = va;
         if (outR) outR[lo[u]] = vr;
+        if (T.dinv && diag[u]) {   // Jacobi data on the way out (owned rows carry the ids (zo ny + y) nx + x)
+          const int s = min(s0 + u * NH, LT::NR - 1);
+          const int rx = s % TX, ry = (s / TX) % TY, rz = s / (TX * TY);
+          T.dinv[((int64_t)(z0 + rz) * ny + (y0 + ry)) * nx + x0 + rx] = 1.0 / va;
+        }
         if (ZERO) acc[ai[u]] = 0.0;   // every accumulated slot is some row's CSR entry: this clears the whole buffer
       }
     }
@@ -272,7 +278,8 @@ __device__ __forceinline__ void lat_store(const LatArgs& T, int x0, int y0, doub
 // one contiguous run of TX*27 doubles both in LDS and in the CSR value array.  Straight coalesced copy.
 constexpr int ZCODE_STD = 3 | (0 << 2) | (1 << 4) | (2 << 6);
 template <int TX, int TY, int TZ, bool ZERO = false>
-__device__ __forceinline__ void lat_store_plain(const LatArgs& T, double* acc, const int* rlo, int t, int nt) {
+__device__ __forceinline__ void lat_store_plain(const LatArgs& T, double* acc, const int* rlo, int t, int nt, int x0 = 0, int y0 = 0,
+                                                int z0 = 0) {
   constexpr int LINE = TX * 27, NL = TY * TZ, PER = (LINE + 63) / 64;
   double* __restrict__ outA = T.A;
   double* __restrict__ outR = T.Arhs;
@@ -292,6 +299,8 @@ __device__ __forceinline__ void lat_store_plain(const LatArgs& T, double* acc, c
       if (i < LINE) {
         outA[base + i] = v[j];
         if (outR) outR[base + i] = 0.0;
+        if (T.dinv && i % 27 == 13)   // the diagonal entry of row i / 27 of this x-line
+          T.dinv[((int64_t)(z0 + l / TY) * T.ny + (y0 + l % TY)) * T.nx + x0 + i / 27] = 1.0 / v[j];
       }
     }
   }

@@ -38,6 +38,7 @@ static int pyn_symbolic_reset_dependents(pyn_ctx* c) {
   for (auto& m : c->mats) {
     (void)hipFree(m.val);
     (void)hipFree(m.sell_val);
+    (void)hipFree(m.dinv);
   }
   c->mats.clear();
   pyn_sell_drop_structure(c);

@@ -119,10 +119,11 @@ class DMPlexDom(object):
             self.nelem = [int(n) for n in faces]
             self.lower = [float(v) for v in lower[:len(self.nelem)]]
             self.upper = [float(v) for v in upper[:len(self.nelem)]]
-        elif 'fileName' in kwargs:
-            # Gmsh quad/hex mesh (dmplex.py:22-23): explicit connectivity, file node numbering
+        elif 'fileName' in kwargs or 'mesh' in kwargs:
+            # Gmsh quad/hex mesh (dmplex.py:22-23): explicit connectivity, file node numbering.  `mesh=` takes what
+            # read_msh returns ({"dim", "xyz", "conn", "facets", "cell"}): an imported mesh that is already in memory
             from pynama_amd.domain.gmsh import read_msh
-            self._msh = read_msh(kwargs['fileName'])
+            self._msh = kwargs['mesh'] if 'mesh' in kwargs else read_msh(kwargs['fileName'])
             dimf = self._msh["dim"]
             self.nelem = [0] * dimf
             self.lower = [float(v) for v in self._msh["xyz"].min(axis=0)]
@@ -162,11 +163,16 @@ class DMPlexDom(object):
                 # TEST transport: ranks share one GPU, collectives go through the shared-memory file (tests/test_gpu_dist.py)
                 ctx.comm_init_shm(self.comm.rank, self.comm.size, os.environ["PYNAMA_SHM_TRANSPORT"],
                                   int(os.environ.get("PYNAMA_SHM_CAP", str(8 << 20))))
-                ctx.halo_set(*self._halo_plan())
+                plan = self._halo_plan()
+                self._neigh_ranks = list(plan[2])
+                ctx.halo_set(*plan)
             elif self.comm.size > 1:
-                uid = self.comm.unique_id(_lib.Context.unique_id)
-                ctx.comm_init(self.comm.rank, self.comm.size, uid)
-                ctx.halo_set(*self._halo_plan())
+                uid = self.comm.unique_id(_lib.Context.unique_id)          # a fresh id per communicator
+                with self.comm.bounded(f"ncclCommInitRank ({self.comm.size} ranks)"):
+                    ctx.comm_init(self.comm.rank, self.comm.size, uid)
+                plan = self._halo_plan()
+                self._neigh_ranks = list(plan[2])
+                ctx.halo_set(*plan)
             elif os.environ.get("PYNAMA_FORCE_COMM") == "1":
                 # one rank, but with a real RCCL communicator: the collective code paths of a multi-GPU
                 # run (single-reduction CG, all-reduced scalars) can be timed and tested on one GPU

@@ -22,8 +22,22 @@ class DeviceMat:
     def __init__(self, ctx, br, bc, name=None):
         self.ctx, self.br, self.bc = ctx, br, bc
         self.id = ctx.mat_create(br, bc)
+        self._gen = getattr(ctx, "graph_gen", 0)
         self._name = name
         self._assembled = False
+
+    def destroy(self):
+        """PETSc.Mat.destroy(): release the device arrays (values, solver-side image, Jacobi data)."""
+        # (a new pyn_csr_symbolic drops every matrix of the old graph and hands the ids out again)
+        if self.id is not None and getattr(self.ctx, "h", None) and getattr(self.ctx, "graph_gen", 0) == self._gen:
+            self.ctx.mat_destroy(self.id)
+        self.id = None
+
+    def __del__(self):
+        try:
+            self.destroy()
+        except Exception:       # interpreter shutdown / context already closed
+            pass
 
     def setName(self, name):
         self._name = name

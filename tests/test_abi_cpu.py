@@ -24,9 +24,10 @@ def test_library_exports_every_declared_symbol():
     assert len(syms) >= 40
     for s in syms:
         assert hasattr(lib, s), f"{s} declared in include/pynama_hip.h but not exported"
-    # and the ctypes table binds exactly those (pyn_last_error is bound separately)
-    assert set(_lib.SIGNATURES) | {"pyn_last_error"} == set(syms)
-    assert lib.pyn_version() >= 100
+    # and the ctypes table binds exactly those (the two string-valued entries are bound separately)
+    assert set(_lib.SIGNATURES) | {"pyn_last_error", "pyn_source_hash"} == set(syms)
+    assert lib.pyn_version() >= 101
+    assert len(_lib.source_hash()) == 16 and _lib.source_hash() != "unknown"
 
 
 def test_no_cpu_fallback():

@@ -1,6 +1,8 @@
 """GPU parity tests (run on a real MI355X with `-m gpu`): every result of the HIP path, called
 through the C ABI (pynama_amd._lib.Context == include/pynama_hip.h), is compared with the CPU
 oracle (oracle/fem_oracle.py) and with the reference's golden vectors (tests/golden)."""
+import os
+
 import numpy as np
 import pytest
 
@@ -1236,3 +1238,43 @@ def test_matfree_fuzz_against_assembled(lib):
             ctx.close()
         finally:
             del os.environ["PYNAMA_MATFREE_TILE"]
+
+
+# ---- Jacobi data written by the assembly itself (DMat::dinv): same iterates as the extracted diagonal ----------------------
+@pytest.mark.parametrize("jitter,tile", [(0.0, None), (0.2, None), (0.2, "1"), (0.0, "2")])
+def test_assembly_emits_jacobi_diagonal(lib, jitter, tile):
+    """the lattice store phases (tile kernels, z-marching kernel, interior and boundary / Dirichlet rows) write 1 / diagonal with
+    the rows; CG with that data equals CG with the diagonal extracted from the CSR values (PYNAMA_NO_ASM_DINV), iterate by
+    iterate, and re-assembling a matrix refreshes it"""
+    mesh = fo.box_mesh([17, 12, 19], [0, 0, 0], [1.0, 0.8, 1.1], 2, jitter=jitter)
+    rng = np.random.default_rng(3)
+    some = np.unique(np.concatenate([mesh.boundary, rng.choice(mesh.n_node, size=40, replace=False)]))
+    b = rng.standard_normal(mesh.n_node)
+    b[some] = 0.0
+    xs = []
+    for no_dinv in (False, True):
+        if no_dinv:
+            os.environ["PYNAMA_NO_ASM_DINV"] = "1"
+        if tile:
+            os.environ["PYNAMA_LATTICE_TILE"] = tile
+        try:
+            ctx = make_ctx(lib, mesh, 2, bc_ndof=1, bc_nodes=some)
+            A = ctx.mat_create(1, 1)
+            ctx.assemble_scalar(lib.FORM_LAPLACE, A, -1)
+            vb, vx = ctx.vec_create(1), ctx.vec_create(1)
+            ctx.vec_set(vb, b)
+            ctx.solve(A, vb, vx, fixed_iters=25, norm_type=lib.NORM_UNPRECONDITIONED)
+            x1 = ctx.vec_get(vx, 1).copy()
+            ctx.assemble_scalar(lib.FORM_LAPLACE, A, -1)      # second version of the same matrix
+            ctx.solve(A, vb, vx, fixed_iters=25, norm_type=lib.NORM_UNPRECONDITIONED)
+            x2 = ctx.vec_get(vx, 1)      # (LDS atomics: the summation order of an entry, hence its last bit, varies between launches)
+            assert np.abs(x1 - x2).max() <= 1e-12 * np.abs(x1).max()
+            d = ctx.vec_create(1)
+            ctx.mat_diagonal(A, d)
+            assert np.abs(ctx.vec_get(d, 1)[some] - 1.0).max() == 0.0          # identity rows
+            xs.append(x1)
+            ctx.close()
+        finally:
+            os.environ.pop("PYNAMA_NO_ASM_DINV", None)
+            os.environ.pop("PYNAMA_LATTICE_TILE", None)
+    assert np.abs(xs[0] - xs[1]).max() <= 1e-13 * np.abs(xs[1]).max()

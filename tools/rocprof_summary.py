@@ -47,7 +47,19 @@ def pmc(fetch_db, write_db, out_json):
             v["hbm_bytes_per_launch"] = (2.0 * v["FETCH_SIZE_KB"] + v["WRITE_SIZE_KB"]) * 1024.0
     with open(out_json, "w") as f:
         json.dump({"correction": "(2*FETCH_SIZE + WRITE_SIZE)*1024 bytes per launch (gfx950 FETCH_SIZE counts 64 B per "
-                                 "128-B request; separate --pmc passes)", "kernels": res}, f, indent=1)
+                                 "128-B request; separate --pmc passes)",
+                   "source_hash": _source_hash(),      # the kernel sources these counters belong to (bench.py checks it)
+                   "kernels": res}, f, indent=1)
+
+
+def _source_hash():
+    import os
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    try:
+        from pynama_amd import _lib
+        return _lib.source_hash()
+    except Exception:      # summarising on a machine without the library: bench.py will not quote these counters
+        return "unknown"
 
 
 def timeline(db, out_txt, n=60):
