@@ -888,8 +888,122 @@ __device__ __forceinline__ void kle_lat_rows(const KleLatArgs& T, const double (
   }
 }
 
-template <int TX, int TY, int TZ, bool RW>
-__global__ void __launch_bounds__(256, 3) assemble_q1_hex_kle_lattice_kernel(KleLatArgs T) {
+// General geometry (any trilinear hexahedron): the same block formulas with the element quantities from the lean closed form of
+// the 2x2x2 rule (pyn_q1_hex.h) instead of the parallelepiped integrals --
+//   L_ab    = sum_g (w_g / 512) / det'_g  g_g[a] . g_g[b],                g = adj(J') h  (unnormalised gradients, G = g / det')
+//   T_m[ab] = sum_g w_g detJ_g H_a(g) G_mb(g) = (1 / 4096) sum_g N'_a(g) g_g,m[b]      (the determinant cancels)
+//   Gr      = adj(J'_0) s / det'_0,  c_r = w_r det'_0 / 512                            (reduced rule: the centroid)
+// for the two node rows {A0, A0+1} this wave adds.  Every wave recomputes the geometry of its element (54 + 72 of its ~190
+// FP64 instructions per Gauss point): the node rows are what is split four ways, as in the closed-form kernel.
+template <bool RW, int A0>
+__device__ __forceinline__ void kle_gen_point(const double (&C)[2][2][2][3], const Q1PointTab& tb, double (&Lab)[2][8], double (&Tv)[3][2][8]) {
+  double A[3][3];
+  const double det = q1_point_adj_rt(C, tb, A);
+  const double s = RW ? 0.0 : (1.0 / 512.0) * q1_rcp(det);
+#pragma unroll
+  for (int x = 0; x < 3; ++x) {
+    double g[8];
+#pragma unroll
+    for (int a = 0; a < 8; ++a) g[a] = fma(A[2][x], tb.h[2][a], fma(A[1][x], tb.h[1][a], A[0][x] * tb.h[0][a]));
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      const int a = A0 + h;
+      if (!RW) {
+        const double t = s * g[a];
+#pragma unroll
+        for (int b = 0; b < 8; ++b) Lab[h][b] = fma(t, g[b], Lab[h][b]);
+      } else {
+        const double na = tb.n[a];   // N'_a / 4096 at this point
+#pragma unroll
+        for (int b = 0; b < 8; ++b) Tv[x][h][b] = fma(na, g[b], Tv[x][h][b]);
+      }
+    }
+  }
+}
+
+template <int TX, int TY, int TZ, bool RW, int A0>
+__device__ __forceinline__ void kle_lat_rows_general(const KleLatArgs& T, const double (&P)[2][2][2][3], int lx, int ly, int lz, int z0,
+                                                     double* acc) {
+  constexpr int CX[8] = {0, 0, 1, 1, 0, 1, 1, 0};
+  constexpr int CY[8] = {0, 1, 1, 0, 0, 0, 1, 1};
+  constexpr int CZ[8] = {0, 0, 0, 0, 1, 1, 1, 1};
+  double C[2][2][2][3];
+  q1_haar_coeffs(P, C);
+  // reduced rule: the centroid (xi = 0): J'_0 rows are the first-order Haar coefficients
+  double Gr[3][8], cr;
+  {
+    double r0[3], r1[3], r2[3], A[3][3];
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+      r0[c] = C[0][0][1][c];
+      r1[c] = C[0][1][0][c];
+      r2[c] = C[1][0][0][c];
+    }
+    A[0][0] = r1[1] * r2[2] - r1[2] * r2[1];
+    A[0][1] = r1[2] * r2[0] - r1[0] * r2[2];
+    A[0][2] = r1[0] * r2[1] - r1[1] * r2[0];
+    A[1][0] = r2[1] * r0[2] - r2[2] * r0[1];
+    A[1][1] = r2[2] * r0[0] - r2[0] * r0[2];
+    A[1][2] = r2[0] * r0[1] - r2[1] * r0[0];
+    A[2][0] = r0[1] * r1[2] - r0[2] * r1[1];
+    A[2][1] = r0[2] * r1[0] - r0[0] * r1[2];
+    A[2][2] = r0[0] * r1[1] - r0[1] * r1[0];
+    const double det0 = r0[0] * A[0][0] + r0[1] * A[0][1] + r0[2] * A[0][2];
+    const double ri = q1_rcp(det0);
+    cr = T.wr[0] * det0 * (1.0 / 512.0);
+#pragma unroll
+    for (int x = 0; x < 3; ++x)
+#pragma unroll
+      for (int a = 0; a < 8; ++a)
+        Gr[x][a] = ((2 * CX[a] - 1) * A[0][x] + (2 * CY[a] - 1) * A[1][x] + (2 * CZ[a] - 1) * A[2][x]) * ri;
+  }
+  const double caw = cr * T.alpha_w, cad = cr * T.alpha_d;
+  double Lab[2][8], Tv[3][2][8];
+#pragma unroll
+  for (int h = 0; h < 2; ++h)
+#pragma unroll
+    for (int b = 0; b < 8; ++b) {
+      Lab[h][b] = 0.0;
+      Tv[0][h][b] = Tv[1][h][b] = Tv[2][h][b] = 0.0;
+    }
+#pragma nounroll
+  for (int G = 0; G < 8; ++G) kle_gen_point<RW, A0>(C, Q1_POINTS[G], Lab, Tv);
+#pragma unroll
+  for (int h = 0; h < 2; ++h) {
+    const int a = A0 + h;
+    const int rx = lx - 1 + CX[a], ry = ly - 1 + CY[a], rz = lz - 1 + CZ[a];
+    if (rx < 0 || rx >= TX || ry < 0 || ry >= TY || rz < 0 || rz >= TZ || z0 + rz >= T.L.n_own) continue;
+    double* rowp = acc + ((rz * TY + ry) * TX + rx) * 243;
+#pragma unroll
+    for (int b = 0; b < 8; ++b) {
+      const int kk = (CZ[b] - CZ[a] + 1) * 9 + (CY[b] - CY[a] + 1) * 3 + (CX[b] - CX[a] + 1);
+      if (!RW) {
+        const double s_ab = Gr[0][a] * Gr[0][b] + Gr[1][a] * Gr[1][b] + Gr[2][a] * Gr[2][b];
+        const double diag = Lab[h][b] + caw * s_ab;
+#pragma unroll
+        for (int pp = 0; pp < 3; ++pp)
+#pragma unroll
+          for (int q = 0; q < 3; ++q) {
+            double v = cad * Gr[pp][a] * Gr[q][b] - caw * Gr[q][a] * Gr[pp][b];
+            if (pp == q) v += diag;
+            atomicAdd(&rowp[(pp * 27 + kk) * 3 + q], v);
+          }
+      } else {
+        const double hb = T.Hr[b];
+#pragma unroll
+        for (int m = 0; m < 3; ++m) {
+          const double wv = Tv[m][h][b] - caw * Gr[m][a] * hb;
+          const int P1 = (m + 1) % 3, P2 = (m + 2) % 3;
+          atomicAdd(&rowp[(P2 * 27 + kk) * 3 + P1], wv);
+          atomicAdd(&rowp[(P1 * 27 + kk) * 3 + P2], -wv);
+        }
+      }
+    }
+  }
+}
+
+template <int TX, int TY, int TZ, bool RW, bool GEN>
+__global__ void __launch_bounds__(256, GEN ? 2 : 3) assemble_q1_hex_kle_lattice_kernel(KleLatArgs T) {
   using LT = LatTile<TX, TY, TZ>;
   constexpr int ROW = 243, ACC = LT::NR * ROW;
   extern __shared__ __align__(16) double lds[];
@@ -916,6 +1030,25 @@ __global__ void __launch_bounds__(256, 3) assemble_q1_hex_kle_lattice_kernel(Kle
     const int n00 = gy * nx + gx;
     const double* q0 = L.xyz + (int64_t)(lat_plane(L, gl) + n00) * 3;
     const double* qz = L.xyz + (int64_t)(lat_plane(L, gl + 1) + n00) * 3;
+    if (GEN) {   // general geometry: all eight corners, quadrature in closed form
+      double P[2][2][2][3];
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+          for (int cc = 0; cc < 3; ++cc) {
+            P[0][j][i][cc] = q0[(j * nx + i) * 3 + cc];
+            P[1][j][i][cc] = qz[(j * nx + i) * 3 + cc];
+          }
+      switch (part) {
+        case 0: kle_lat_rows_general<TX, TY, TZ, RW, 0>(T, P, lx, ly, lz, z0, acc); break;
+        case 1: kle_lat_rows_general<TX, TY, TZ, RW, 2>(T, P, lx, ly, lz, z0, acc); break;
+        case 2: kle_lat_rows_general<TX, TY, TZ, RW, 4>(T, P, lx, ly, lz, z0, acc); break;
+        default: kle_lat_rows_general<TX, TY, TZ, RW, 6>(T, P, lx, ly, lz, z0, acc); break;
+      }
+      continue;
+    }
     double E[3][3];
 #pragma unroll
     for (int x = 0; x < 3; ++x) {
@@ -1187,7 +1320,7 @@ static int lat_fill_args(pyn_ctx* c, LatArgs& T, double* A, double* Arhs, int* m
   return PYN_OK;
 }
 
-template <int TX, int TY, int TZ>
+template <int TX, int TY, int TZ, bool GEN>
 static int launch_kle_lattice(pyn_ctx* c, KleLatArgs& T, double* K, double* Krhs, double* Rw) {
   using LT = LatTile<TX, TY, TZ>;
   T.L.ntx = (T.L.nx + TX - 1) / TX;
@@ -1196,21 +1329,21 @@ static int launch_kle_lattice(pyn_ctx* c, KleLatArgs& T, double* K, double* Krhs
   const size_t lds = (size_t)LT::NR * 243 * sizeof(double) + LT::META_INTS * sizeof(int);
   static bool attr_done = false;
   if (!attr_done) {
-    PYN_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(assemble_q1_hex_kle_lattice_kernel<TX, TY, TZ, false>),
+    PYN_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(assemble_q1_hex_kle_lattice_kernel<TX, TY, TZ, false, GEN>),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    PYN_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(assemble_q1_hex_kle_lattice_kernel<TX, TY, TZ, true>),
+    PYN_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(assemble_q1_hex_kle_lattice_kernel<TX, TY, TZ, true, GEN>),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     attr_done = true;
   }
   if (K) {
     T.L.A = K;
     T.L.Arhs = Krhs;
-    assemble_q1_hex_kle_lattice_kernel<TX, TY, TZ, false><<<n_tiles, 256, lds, c->stream>>>(T);
+    assemble_q1_hex_kle_lattice_kernel<TX, TY, TZ, false, GEN><<<n_tiles, 256, lds, c->stream>>>(T);
   }
   if (Rw) {
     T.L.A = Rw;
     T.L.Arhs = nullptr;
-    assemble_q1_hex_kle_lattice_kernel<TX, TY, TZ, true><<<n_tiles, 256, lds, c->stream>>>(T);
+    assemble_q1_hex_kle_lattice_kernel<TX, TY, TZ, true, GEN><<<n_tiles, 256, lds, c->stream>>>(T);
   }
   PYN_HIP(hipGetLastError());
   return PYN_OK;
@@ -1218,13 +1351,15 @@ static int launch_kle_lattice(pyn_ctx* c, KleLatArgs& T, double* K, double* Krhs
 
 // KLE on lattices of parallelepipeds (the reference's box meshes): plan-free kernels
 int pyn_assemble_kle_lattice(pyn_ctx* c, double alpha_d, double alpha_w, double* K, double* Krhs, double* Rw, bool* handled) {
-  if (!c->lat.valid || c->quad[0].ngp != 8 || c->quad[1].ngp != 1 || !c->aff_standard || !c->aff_rw_standard ||
-      getenv("PYNAMA_NO_AFFINE") || getenv("PYNAMA_NO_KLE_LATTICE"))
-    return PYN_OK;
+  if (!c->lat.valid || c->quad[0].ngp != 8 || c->quad[1].ngp != 1 || getenv("PYNAMA_NO_KLE_LATTICE")) return PYN_OK;
   KleLatArgs T;
   int mesh_aff = 0;
   PYN_TRY(lat_fill_args(c, T.L, nullptr, nullptr, &mesh_aff));
-  if (!mesh_aff) return PYN_OK;   // general geometry: the patch-plan kernels with quadrature
+  const bool affine = mesh_aff && c->aff_standard && c->aff_rw_standard && !getenv("PYNAMA_NO_AFFINE");
+  // general geometry: the same plan-free four-wave kernel with the closed form of the 2x2x2 rule (standard tables only);
+  // anything else falls through to the patch-plan kernels with the table-driven quadrature
+  const bool general = !affine && c->q1_gauss_standard && c->q1_red_standard && !getenv("PYNAMA_NO_KLE_GENERAL");
+  if (!affine && !general) return PYN_OK;
   T.alpha_d = alpha_d;
   T.alpha_w = alpha_w;
   T.wr = c->quad[1].w;
@@ -1232,11 +1367,16 @@ int pyn_assemble_kle_lattice(pyn_ctx* c, double alpha_d, double alpha_w, double*
   T.Hr = c->quad[1].H;
   T.hcoor = c->quad[1].HrsCoo;
   const char* tl = getenv("PYNAMA_KLE_LATTICE_TILE");
+  if (general) {
+    PYN_TRY((launch_kle_lattice<3, 3, 3, true>(c, T, K, Krhs, Rw)));
+    *handled = true;
+    return PYN_OK;
+  }
   switch (tl ? atoi(tl) : 0) {
-    case 1: PYN_TRY((launch_kle_lattice<6, 2, 2>(c, T, K, Krhs, Rw))); break;
-    case 2: PYN_TRY((launch_kle_lattice<3, 3, 2>(c, T, K, Krhs, Rw))); break;
-    case 3: PYN_TRY((launch_kle_lattice<4, 3, 3>(c, T, K, Krhs, Rw))); break;
-    default: PYN_TRY((launch_kle_lattice<3, 3, 3>(c, T, K, Krhs, Rw))); break;
+    case 1: PYN_TRY((launch_kle_lattice<6, 2, 2, false>(c, T, K, Krhs, Rw))); break;
+    case 2: PYN_TRY((launch_kle_lattice<3, 3, 2, false>(c, T, K, Krhs, Rw))); break;
+    case 3: PYN_TRY((launch_kle_lattice<4, 3, 3, false>(c, T, K, Krhs, Rw))); break;
+    default: PYN_TRY((launch_kle_lattice<3, 3, 3, false>(c, T, K, Krhs, Rw))); break;
   }
   *handled = true;
   return PYN_OK;

@@ -148,7 +148,7 @@ int march_print_stamps(pyn_ctx* c, LatArgs& T, int nblk, int ncol, int zlen) {
       T.dbg[((size_t)blockIdx.x * 32 + (l - zc0 + 1)) * 8 + (k)] = __builtin_amdgcn_s_memtime();           \
   } while (0)
 
-template <int TX, int TY, int WPS>
+template <int TX, int TY, int WPS, bool ROLLED>
 __global__ void __launch_bounds__((TX + 1) * (TY + 1), WPS) assemble_q1_hex_march_kernel(LatArgs T, int zlen, double ws) {
   using MT = MarchTile<TX, TY>;
   using L1 = LatTile<TX, TY, 1>;
@@ -202,7 +202,10 @@ __global__ void __launch_bounds__((TX + 1) * (TY + 1), WPS) assemble_q1_hex_marc
     if (own_b) march_meta_load<TX, TY, NT, 1>(T, x0, y0, l, tid, meta);
     const bool act = lvalid && evalid;
     double L[28];
-    if (act && !(T.ablate & 1)) q1_laplace_lean(P, ws, L);
+    if (act && !(T.ablate & 1)) {
+      if (ROLLED) q1_laplace_lean_rolled(P, ws, L);   // rolled loop over the Gauss points: one point's worth of registers
+      else q1_laplace_lean(P, ws, L);
+    }
     else {
 #pragma unroll
       for (int i = 0; i < 28; ++i) L[i] = 0.0;
@@ -278,7 +281,7 @@ __global__ void __launch_bounds__((TX + 1) * (TY + 1), WPS) assemble_q1_hex_marc
   }
 }
 
-template <int TX, int TY, int WPS>
+template <int TX, int TY, int WPS, bool ROLLED = false>
 int launch_march(pyn_ctx* c, LatArgs& T, int wg_per_cu) {
   using MT = MarchTile<TX, TY>;
   T.ntx = (T.nx + TX - 1) / TX;
@@ -297,7 +300,7 @@ int launch_march(pyn_ctx* c, LatArgs& T, int wg_per_cu) {
   nzc = (T.n_own + zlen - 1) / zlen;
   static bool attr_done = false;
   if (!attr_done) {
-    PYN_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(assemble_q1_hex_march_kernel<TX, TY, WPS>),
+    PYN_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(assemble_q1_hex_march_kernel<TX, TY, WPS, ROLLED>),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)MT::BYTES));
     attr_done = true;
   }
@@ -309,7 +312,7 @@ int launch_march(pyn_ctx* c, LatArgs& T, int wg_per_cu) {
     PYN_HIP(hipMemsetAsync(stamps.p, 0, (size_t)nblk * 32 * 8 * sizeof(unsigned long long), c->stream));
     T.dbg = stamps.as<unsigned long long>();
   }
-  assemble_q1_hex_march_kernel<TX, TY, WPS><<<nblk, MT::NT, MT::BYTES, c->stream>>>(T, zlen, ws);
+  assemble_q1_hex_march_kernel<TX, TY, WPS, ROLLED><<<nblk, MT::NT, MT::BYTES, c->stream>>>(T, zlen, ws);
   PYN_HIP(hipGetLastError());
   if (T.dbg) PYN_TRY(march_print_stamps(c, T, nblk, ncol, zlen));
   return PYN_OK;
@@ -356,6 +359,10 @@ int pyn_assemble_lattice_march(pyn_ctx* c, void* lat_args, int tile) {
     case 2: return launch_march<15, 7, 2>(c, T, 3);
     case 3: return launch_march<31, 7, 1>(c, T, 1);
     case 5: return launch_march<15, 15, 1>(c, T, 1);
-    default: return launch_march<7, 7, 2>(c, T, 7);   // one wave per workgroup, 7 workgroups per CU: fastest measured
+    case 6: return launch_march<7, 7, 3, true>(c, T, 7);
+    case 7: return launch_march<7, 7, 2>(c, T, 7);     // Gauss points unrolled: 256 VGPRs, 9 % slower than the rolled loop
+    case 8: return launch_march<15, 7, 3, true>(c, T, 3);
+    // one wave per workgroup, 7 workgroups per CU, rolled loop over the Gauss points (224 VGPRs): fastest measured
+    default: return launch_march<7, 7, 2, true>(c, T, 7);
   }
 }

@@ -550,6 +550,17 @@ extern "C" int pyn_elem_tables_set(pyn_ctx* c, int which, int ngp, const double*
     c->q1_gauss_standard = pyn_q1_gauss_tables_standard(w, H, Hrs, HrsCoo);
     PYN_TRY(dev_upload(&c->d_aff, aff, (size_t)(6 * 36 + 32 + 9), c->stream));
   }
+  if (which == PYN_Q_RED && c->dim == 3 && c->nn == 8) {
+    // one point at the centroid, weight 8, gradients s_d(a) / 8, values 1 / 8 (corner order of SURVEY.md A.2)?
+    const int CO[3][8] = {{0, 0, 1, 1, 0, 1, 1, 0}, {0, 1, 1, 0, 0, 0, 1, 1}, {0, 0, 0, 0, 1, 1, 1, 1}};
+    bool ok = ngp == 1 && fabs(w[0] - 8.0) < 1e-13;
+    for (int a = 0; a < 8 && ok; ++a) {
+      ok = fabs(H[a] - 0.125) < 1e-14;
+      for (int d = 0; d < 3 && ok; ++d)
+        ok = fabs(Hrs[d * 8 + a] - (2 * CO[d][a] - 1) * 0.125) < 1e-14 && fabs(HrsCoo[d * 8 + a] - (2 * CO[d][a] - 1) * 0.125) < 1e-14;
+    }
+    c->q1_red_standard = ok;
+  }
   PYN_HIP(hipStreamSynchronize(c->stream));
   return PYN_OK;
 }

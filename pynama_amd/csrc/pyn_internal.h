@@ -156,6 +156,7 @@ struct pyn_ctx {
   int mesh_affine = -1;          // every element a parallelepiped? (-1: not checked yet; reset by pyn_mesh_set)
   bool aff_rw_standard = false;  // ... and so is int N_a d N_b (affine Rw path)
   bool aff_standard = false;  // the uploaded tables are those of the trilinear hexahedron in closed form
+  bool q1_red_standard = false;    // reduced rule = the centroid, weight 8, trilinear tables (lean KLE kernel)
   bool q1_gauss_standard = false;  // ... pointwise: 2x2x2 Gauss rule, unit weights (lean general-geometry kernels)
   double* d_aff = nullptr;  // Q1-hex affine tables: [6][36] reference matrices + [4][8] non-affine monomial signs + [3][3] S
 

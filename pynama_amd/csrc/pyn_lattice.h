@@ -174,7 +174,7 @@ __device__ __forceinline__ void lat_integrate(const LatArgs& T, int x0, int y0, 
       for (int a = 0; a < 8; ++a)
 #pragma unroll
         for (int c = 0; c < 3; ++c) P[CZ[a]][CY[a]][CX[a]][c] = X[a][c];
-      q1_laplace_lean(P, 1.0 / 512.0, Lo);
+      q1_laplace_lean_rolled(P, 1.0 / 512.0, Lo);
 #pragma unroll
       for (int a = 0; a < 8; ++a) {
         double d = 0.0;

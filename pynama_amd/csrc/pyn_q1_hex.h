@@ -375,6 +375,87 @@ __device__ __forceinline__ void q1_laplace_lean(const double (&P)[2][2][2][3], c
   q1_laplace_point<+1, +1, +1>(C, ws, L);
 }
 
+// ---- the same point routines with the Gauss point as a RUN-TIME index: a rolled loop over the eight points keeps the register
+// demand at one point's worth (the fully unrolled form lets the scheduler interleave the points: 270+ VGPRs).  The constants of a
+// point (its coordinates, h_d[a], N'_a / 4096) come from a __constant__ table through scalar loads.
+struct Q1PointTab {
+  double xi[3];
+  double h[3][8];     // h_d[a] = s_d(a) prod_{e != d} (1 + s_e(a) xi_e), reference node order
+  double n[8];        // prod_d (1 + s_d(a) xi_d) / 4096
+};
+
+__host__ __device__ constexpr Q1PointTab q1_point_tab(int G) {
+  constexpr int CX[8] = {0, 0, 1, 1, 0, 1, 1, 0};
+  constexpr int CY[8] = {0, 1, 1, 0, 0, 0, 1, 1};
+  constexpr int CZ[8] = {0, 0, 0, 0, 1, 1, 1, 1};
+  Q1PointTab t{};
+  const double sx = ((G & 1) * 2 - 1) * Q1_GP, sy = (((G >> 1) & 1) * 2 - 1) * Q1_GP, sz = (((G >> 2) & 1) * 2 - 1) * Q1_GP;
+  t.xi[0] = sx;
+  t.xi[1] = sy;
+  t.xi[2] = sz;
+  for (int a = 0; a < 8; ++a) {
+    const double px = 1.0 + (2 * CX[a] - 1) * sx, py = 1.0 + (2 * CY[a] - 1) * sy, pz = 1.0 + (2 * CZ[a] - 1) * sz;
+    t.h[0][a] = (2 * CX[a] - 1) * py * pz;
+    t.h[1][a] = (2 * CY[a] - 1) * px * pz;
+    t.h[2][a] = (2 * CZ[a] - 1) * px * py;
+    t.n[a] = px * py * pz * (1.0 / 4096.0);
+  }
+  return t;
+}
+
+__constant__ Q1PointTab Q1_POINTS[8] = {q1_point_tab(0), q1_point_tab(1), q1_point_tab(2), q1_point_tab(3),
+                                         q1_point_tab(4), q1_point_tab(5), q1_point_tab(6), q1_point_tab(7)};
+
+// adj(J') and det' at the point described by tb (uniform)
+__device__ __forceinline__ double q1_point_adj_rt(const double (&C)[2][2][2][3], const Q1PointTab& tb, double (&A)[3][3]) {
+  const double xi = tb.xi[0], eta = tb.xi[1], zeta = tb.xi[2];
+  double r0[3], r1[3], r2[3];
+#pragma unroll
+  for (int c = 0; c < 3; ++c) {
+    const double m = fma(xi, C[1][1][1][c], C[1][1][0][c]);
+    r0[c] = fma(zeta, fma(eta, C[1][1][1][c], C[1][0][1][c]), fma(eta, C[0][1][1][c], C[0][0][1][c]));
+    r1[c] = fma(zeta, m, fma(xi, C[0][1][1][c], C[0][1][0][c]));
+    r2[c] = fma(eta, m, fma(xi, C[1][0][1][c], C[1][0][0][c]));
+  }
+  A[0][0] = r1[1] * r2[2] - r1[2] * r2[1];
+  A[0][1] = r1[2] * r2[0] - r1[0] * r2[2];
+  A[0][2] = r1[0] * r2[1] - r1[1] * r2[0];
+  A[1][0] = r2[1] * r0[2] - r2[2] * r0[1];
+  A[1][1] = r2[2] * r0[0] - r2[0] * r0[2];
+  A[1][2] = r2[0] * r0[1] - r2[1] * r0[0];
+  A[2][0] = r0[1] * r1[2] - r0[2] * r1[1];
+  A[2][1] = r0[2] * r1[0] - r0[0] * r1[2];
+  A[2][2] = r0[0] * r1[1] - r0[1] * r1[0];
+  return r0[0] * A[0][0] + r0[1] * A[0][1] + r0[2] * A[0][2];
+}
+
+// the 28 off-diagonal entries of the element Laplacian, rolled loop over the points
+__device__ __forceinline__ void q1_laplace_lean_rolled(const double (&P)[2][2][2][3], const double ws, double (&L)[28]) {
+  double C[2][2][2][3];
+  q1_haar_coeffs(P, C);
+#pragma unroll
+  for (int i = 0; i < 28; ++i) L[i] = 0.0;
+#pragma nounroll
+  for (int G = 0; G < 8; ++G) {
+    const Q1PointTab& tb = Q1_POINTS[G];
+    double A[3][3];
+    const double det = q1_point_adj_rt(C, tb, A);
+    const double s = ws * q1_rcp(det);
+#pragma unroll
+    for (int x = 0; x < 3; ++x) {
+      double g[8];
+#pragma unroll
+      for (int a = 0; a < 8; ++a) g[a] = fma(A[2][x], tb.h[2][a], fma(A[1][x], tb.h[1][a], A[0][x] * tb.h[0][a]));
+#pragma unroll
+      for (int a = 0; a < 7; ++a) {
+        const double t = s * g[a];
+#pragma unroll
+        for (int b = a + 1; b < 8; ++b) L[q1_off(a, b)] = fma(t, g[b], L[q1_off(a, b)]);
+      }
+    }
+  }
+}
+
 template <int G>   // Gauss point G of the 2x2x2 rule: bit d of G = side of axis d
 __device__ __forceinline__ void q1_laplace_point_idx(const double (&C)[2][2][2][3], const double ws, double (&L)[28]) {
   q1_laplace_point<(G & 1) * 2 - 1, ((G >> 1) & 1) * 2 - 1, ((G >> 2) & 1) * 2 - 1>(C, ws, L);

@@ -12,11 +12,18 @@ with the matrix-free form of the operator when the matrix carries one (``Mat.K``
 assembled matrix then only supplies the Jacobi diagonal and the exit check; the library verifies that both agree.
 
 The reference's hard-wired default is ``preonly`` + ``lu`` (:13-16).  There is no sparse direct
-solver on the device path: that combination is served by Jacobi-PCG driven to round-off
-(rtol 1e-14 on the true residual), which satisfies the reference's own analytic assertions
-(src/tests/test_solver.py:20-62); the substitution is logged.
+solver on the device path: that combination is served by a Krylov solve driven to round-off --
+Jacobi-PCG (rtol 1e-14 on the recurrence residual, the true residual checked at exit) when a
+symmetry probe of the operator passes (``v'Au == u'Av`` on two random vectors, once per operator),
+GMRES(30)+Jacobi otherwise or when PCG breaks down (an indefinite operator, e.g. ``K + Kfs`` with its
+-1 diagonal entries, base_problem.py:229).  A direct solver either solves or raises: so does this
+path -- a negative converged reason or a true residual above 1e-8 raises instead of returning
+garbage.  The substitution is logged; it satisfies the reference's own analytic assertions
+(src/tests/test_solver.py:20-62).
 """
 import logging
+
+import numpy as np
 
 from pynama_amd import _lib
 from pynama_amd.common.options import Options
@@ -36,6 +43,7 @@ class KspSolver(object):
         self.norm_type = "preconditioned"
         self.mat_free = False
         self.info = None
+        self._symmetric = None
 
     # -- PETSc-style setters the reference (or its users) may call
     def setType(self, t):
@@ -76,6 +84,21 @@ class KspSolver(object):
 
     def setOperators(self, mat):
         self.mat = mat
+        self._symmetric = None           # not probed yet
+
+    def _probe_symmetry(self, A):
+        """|v'Au - u'Av| relative to its terms, on two seeded random vectors (two products, once per operator)"""
+        from pynama_amd.vectors import Vec
+        ctx = A.ctx
+        rng = np.random.default_rng(20240229)
+        u, v, Au, Av = (Vec(ctx, A.bc) for _ in range(4))
+        n = ctx.n_owned * A.bc
+        u.setArray(rng.standard_normal(n))
+        v.setArray(rng.standard_normal(n))
+        ctx.spmv(A.id, u.id, Au.id)
+        ctx.spmv(A.id, v.id, Av.id)
+        a, b = v.dot(Au), u.dot(Av)
+        return abs(a - b) <= 1e-10 * (abs(a) + abs(b) + 1e-300)
 
     def setUp(self):
         if self.ksp_type == 'preonly' and self.pc_type not in ('lu', 'cholesky'):
@@ -104,9 +127,22 @@ class KspSolver(object):
                 raise ValueError("-pynama_mat_free: this operator has no matrix-free form (structured Q1 hex meshes only)")
             mf = tag
         if self.ksp_type == 'preonly':
-            self.logger and self.logger.info("preonly/lu requested: device path uses Jacobi-PCG to round-off")
-            info = ctx.solve(A.id, b.id, x.id, method=_lib.KSP_CG, pc=_lib.PC_JACOBI, rtol=1e-14, atol=1e-300,
-                             dtol=1e8, maxit=200000, norm_type=_lib.NORM_UNPRECONDITIONED, matfree=mf)
+            if getattr(self, "_symmetric", None) is None:
+                self._symmetric = A.br == A.bc and self._probe_symmetry(A)
+            info = None
+            if self._symmetric:
+                self.logger and self.logger.info("preonly/lu requested: device path uses Jacobi-PCG to round-off")
+                info = ctx.solve(A.id, b.id, x.id, method=_lib.KSP_CG, pc=_lib.PC_JACOBI, rtol=1e-14, atol=1e-300,
+                                 dtol=1e8, maxit=200000, norm_type=_lib.NORM_UNPRECONDITIONED, matfree=mf)
+            if info is None or info.reason < 0:
+                why = "operator not symmetric" if not self._symmetric else f"PCG ended with reason {info.reason}"
+                self.logger and self.logger.warning(f"preonly/lu requested: {why}; GMRES(30)+Jacobi to round-off instead")
+                info = ctx.solve(A.id, b.id, x.id, method=_lib.KSP_GMRES, pc=_lib.PC_JACOBI, rtol=1e-13, atol=1e-300,
+                                 dtol=1e8, maxit=200000, restart=30, gmres_orthog=0, norm_type=_lib.NORM_UNPRECONDITIONED)
+            if info.reason < 0 or not (info.true_resid <= 1e-8):
+                raise RuntimeError(f"preonly/lu substitute failed: converged reason {info.reason}, true residual "
+                                   f"{info.true_resid:.3e} after {info.iters} iterations (a direct solver would have solved "
+                                   "this system or raised)")
         else:
             info = ctx.solve(A.id, b.id, x.id,
                              method=_lib.KSP_CG if self.ksp_type == 'cg' else _lib.KSP_GMRES,
@@ -114,6 +150,8 @@ class KspSolver(object):
                              rtol=self.rtol, atol=self.atol, dtol=self.divtol, maxit=self.max_it,
                              restart=self.restart, norm_type=_NORMS[self.norm_type], gmres_orthog=self.gmres_orthog,
                              matfree=mf)
+            if info.reason < 0 and self.logger:      # PETSc does not raise either (unless -ksp_error_if_not_converged)
+                self.logger.error(f"KSP did not converge: reason {info.reason} after {info.iters} iterations, residual {info.rnorm:.3e}")
         self.info = info
         return info
 

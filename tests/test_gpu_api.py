@@ -303,3 +303,45 @@ class TestDomainVecHelpers:
         vec = Vec(self.dom.ctx, 2)
         self.dom.applyValuesToVec(self.dom.getAllNodes(), [3, 5], vec)
         np.testing.assert_array_almost_equal(np.array([3, 5] * 9).reshape(9, 2), vec.getArray().reshape(9, 2), decimal=12)
+
+
+def test_preonly_lu_on_a_nonsymmetric_operator_falls_back_to_gmres():
+    """the reference default `-ksp_type preonly -pc_type lu` (ksp_solver.py:13-16) on an operator PCG cannot take: the
+    symmetry probe sends it to GMRES, the answer is the direct solver's (scipy's sparse LU here)"""
+    import scipy.sparse.linalg as spla
+    from pynama_amd.solver.ksp_solver import KspSolver
+    from pynama_amd.vectors import Vec
+    fem = setFemProblem('uniform', lower=[0, 0, 0], upper=[1, 1, 1], nelem=[4, 3, 3], ngl=2)
+    K = fem.mat.K
+    rng = np.random.default_rng(11)
+    d = Vec(K.ctx, K.br)
+    d.setArray(rng.uniform(0.5, 2.0, K.ctx.n_owned * K.br))
+    K.diagonalScale(L=d)                                   # D K: same spectrum class, no longer symmetric
+    A = K.toScipy().tocsc()
+    assert abs(A - A.T).max() > 1e-3
+    b, x = K.createVecLeft(), K.createVecRight()
+    b.setArray(rng.standard_normal(K.ctx.n_owned * K.br))
+    ksp = KspSolver()
+    ksp.createSolver(K, fem.comm)
+    info = ksp(b, x)
+    assert ksp._symmetric is False and info.reason > 0 and info.true_resid < 1e-10
+    want = spla.spsolve(A, b.getArray())
+    assert np.abs(x.getArray() - want).max() < 1e-8 * np.abs(want).max()
+
+
+def test_preonly_lu_raises_when_it_cannot_solve():
+    """a singular operator: LU would raise, so does the substitute (no silent garbage)"""
+    from pynama_amd.solver.ksp_solver import KspSolver
+    from pynama_amd.vectors import Vec
+    fem = setFemProblem('uniform', lower=[0, 0], upper=[1, 1], nelem=[4, 4], ngl=2)
+    K = fem.mat.K
+    z = Vec(K.ctx, K.br)
+    z.setArray(np.where(np.arange(K.ctx.n_owned * K.br) % 7 == 3, 0.0, 1.0))
+    K.diagonalScale(L=z)                                   # some rows wiped out: singular, inconsistent for a random b
+    b, x = K.createVecLeft(), K.createVecRight()
+    b.setArray(np.random.default_rng(2).standard_normal(K.ctx.n_owned * K.br))
+    ksp = KspSolver()
+    ksp.createSolver(K, fem.comm)
+    ksp.max_it = 2000
+    with pytest.raises(RuntimeError, match="preonly/lu substitute failed"):
+        ksp(b, x)

@@ -190,11 +190,10 @@ def test_c5_unstructured_tets_gmsh_gmres(tmp_path):
     f = (1.0 + X[:, 0] + 2.0 * X[:, 1] ** 2 + np.exp(X[:, 0] * X[:, 1] * X[:, 2])) / n ** 3
     f[bm != 0] = 0.0
     ctx.vec_set(u, f)
-    # (GMRES tests its recurrence estimate of the residual; after ~50 restarts it drifts from the true one in
-    # the third digit, so the 1e-10 bar on the TRUE residual is asked with rtol 5e-11)
-    info = ctx.solve(A, u, v, method=_lib.KSP_GMRES, pc=_lib.PC_JACOBI, rtol=5e-11, restart=30, maxit=100000,
+    # (convergence is declared on the residual recomputed at every restart, in the norm asked for: rtol 1e-10 IS 1e-10)
+    info = ctx.solve(A, u, v, method=_lib.KSP_GMRES, pc=_lib.PC_JACOBI, rtol=1e-10, restart=30, maxit=100000,
                      norm_type=_lib.NORM_UNPRECONDITIONED)
-    assert info.reason == 2 and info.true_resid <= 1e-10
+    assert info.reason == 2 and info.true_resid <= 1e-10 * (1 + 1e-6)
     xg = ctx.vec_get(v, 1)
     info = ctx.solve(A, u, v, method=_lib.KSP_CG, pc=_lib.PC_JACOBI, rtol=1e-12, norm_type=_lib.NORM_UNPRECONDITIONED)
     assert info.reason == 2
