@@ -150,6 +150,11 @@ int pyn_patch_plan_set_kind(pyn_ctx* ctx, int kind, int n_patch, const int32_t* 
 int pyn_mat_create(pyn_ctx* ctx, int br, int bc, int* mat_id);      /* mat_generator.py:95-99 */
 int pyn_mat_destroy(pyn_ctx* ctx, int mat_id);                      /* Mat.destroy(): values, solver image and Jacobi data are released, the handle dies */
 int pyn_mat_zero(pyn_ctx* ctx, int mat_id);
+/* Host insertion path, Mat.setValues(rows, cols, vals, addv) (src/cases/base_problem.py:531-547, src/matrices/mat_generator.py:
+ * 113-118, 157-170): scalar DOF indices (node * block + component, LOCAL numbering), vals row-major [nrows][ncols];
+ * insert != 0: INSERT_VALUES.  Entries outside the node graph are an error; rows of other ranks are dropped. */
+int pyn_mat_add_values(pyn_ctx* ctx, int mat_id, int nrows, const int32_t* rows, int ncols, const int32_t* cols, const double* vals,
+                       int insert);
 int pyn_mat_get_values(pyn_ctx* ctx, int mat_id, double* val);      /* layout above */
 int pyn_mat_get_diagonal(pyn_ctx* ctx, int mat_id, int vec_id);
 int pyn_mat_axpy(pyn_ctx* ctx, int y_mat, double a, int x_mat);     /* Y += a X (base_problem.py:318) */

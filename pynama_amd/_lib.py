@@ -75,6 +75,7 @@ SIGNATURES = {
     "pyn_mat_create": [_P, _I, _I, C.POINTER(_I)],
     "pyn_mat_destroy": [_P, _I],
     "pyn_mat_zero": [_P, _I],
+    "pyn_mat_add_values": [_P, _I, _I, _pi32, _I, _pi32, _pf64, _I],
     "pyn_mat_get_values": [_P, _I, _pf64],
     "pyn_mat_get_diagonal": [_P, _I, _I],
     "pyn_mat_axpy": [_P, _I, _D, _I],
@@ -333,6 +334,16 @@ class Context:
 
     def mat_row_scale(self, mid, vid):
         _check(self.lib.pyn_mat_row_scale(self.h, mid, vid))
+
+    def mat_add_values(self, mid, rows, cols, vals, insert=False):
+        """dense block into the matrix at scalar DOF indices (Mat.setValues); a scalar `vals` fills the block"""
+        rows, cols = _i32(np.atleast_1d(rows)), _i32(np.atleast_1d(cols))
+        v = np.asarray(vals, dtype=np.float64)
+        if v.size == 1:
+            v = np.full(rows.size * cols.size, float(v.reshape(-1)[0]))
+        v = np.ascontiguousarray(v.reshape(-1))
+        assert v.size == rows.size * cols.size, "vals must hold len(rows) x len(cols) entries"
+        _check(self.lib.pyn_mat_add_values(self.h, mid, rows.size, rows, cols.size, cols, v, 1 if insert else 0))
 
     def mat_destroy(self, mid):
         if self.h:

@@ -622,6 +622,63 @@ extern "C" int pyn_mat_destroy(pyn_ctx* c, int id) {
   return PYN_OK;
 }
 
+// Host insertion path: a dense block of values into the device matrix (PETSc MatSetValues with ADD_VALUES / INSERT_VALUES).
+// One thread per (row, column) entry: the column's node is located in the row's sorted column list by bisection; entries
+// outside the graph raise the flag (PETSc: "new nonzero caused a malloc"); rows this rank does not own are dropped (the
+// device path is owner-computes: there is no off-process stash).
+__global__ void mat_add_values_kernel(const int32_t* __restrict__ rowptr, const int32_t* __restrict__ colidx, double* __restrict__ val,
+                                      int64_t n_owned, int br, int bc, int nr, const int32_t* __restrict__ rows, int nc,
+                                      const int32_t* __restrict__ cols, const double* __restrict__ v, int insert, int* __restrict__ bad) {
+  for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < nr * nc; e += gridDim.x * blockDim.x) {
+    const int r = rows[e / nc], cidx = cols[e % nc];
+    if (r < 0 || cidx < 0) continue;                 // PETSc: negative indices are ignored
+    const int64_t i = r / br;
+    const int p = r - (int)i * br, j = cidx / bc, q = cidx - j * bc;
+    if (i >= n_owned) continue;
+    const int lo = rowptr[i], len = rowptr[i + 1] - lo;
+    int l = 0, h = len;
+    while (l < h) {
+      const int m = (l + h) >> 1;
+      if (colidx[lo + m] < j) l = m + 1;
+      else h = m;
+    }
+    if (l >= len || colidx[lo + l] != j) {
+      atomicExch(bad, 1);
+      continue;
+    }
+    double* dst = val + ((int64_t)lo * br + (int64_t)p * len + l) * bc + q;
+    if (insert) *dst = v[e];
+    else atomicAdd(dst, v[e]);
+  }
+}
+
+extern "C" int pyn_mat_add_values(pyn_ctx* c, int id, int nr, const int32_t* rows, int nc, const int32_t* cols, const double* vals,
+                                  int insert) {
+  PYN_TRY(pyn_check_mat(c, id, "pyn_mat_add_values"));
+  PYN_CHECK(rows && cols && vals && nr > 0 && nc > 0 && (int64_t)nr * nc <= (1 << 24), "bad block");
+  DMat& m = c->mats[id];
+  PYN_HIP(hipSetDevice(c->device));
+  const size_t bytes = (size_t)(nr + nc) * sizeof(int32_t) + (size_t)nr * nc * sizeof(double) + 16;
+  DevTmp buf;
+  PYN_HIP(buf.alloc(bytes));
+  double* dv = buf.as<double>();
+  int32_t* dr = reinterpret_cast<int32_t*>(dv + (size_t)nr * nc);
+  int32_t* dc = dr + nr;
+  int* dbad = reinterpret_cast<int*>(dc + nc);
+  PYN_HIP(hipMemcpyAsync(dv, vals, (size_t)nr * nc * sizeof(double), hipMemcpyHostToDevice, c->stream));
+  PYN_HIP(hipMemcpyAsync(dr, rows, nr * sizeof(int32_t), hipMemcpyHostToDevice, c->stream));
+  PYN_HIP(hipMemcpyAsync(dc, cols, nc * sizeof(int32_t), hipMemcpyHostToDevice, c->stream));
+  PYN_HIP(hipMemsetAsync(dbad, 0, sizeof(int), c->stream));
+  m.touch();
+  mat_add_values_kernel<<<std::min((nr * nc + 255) / 256, 1024), 256, 0, c->stream>>>(c->d_rowptr, c->d_colidx, m.val, c->n_owned, m.br, m.bc, nr, dr,
+                                                                                nc, dc, dv, insert, dbad);
+  int bad = 0;
+  PYN_HIP(hipMemcpyAsync(&bad, dbad, sizeof(int), hipMemcpyDeviceToHost, c->stream));
+  PYN_HIP(hipStreamSynchronize(c->stream));
+  PYN_CHECK(!bad, "pyn_mat_add_values: an entry lies outside the node graph of the mesh (no new nonzeros can be allocated)");
+  return PYN_OK;
+}
+
 extern "C" int pyn_mat_zero(pyn_ctx* c, int id) {
   PYN_TRY(pyn_check_mat(c, id, "pyn_mat_zero"));
   DMat& m = c->mats[id];

@@ -107,39 +107,59 @@ __global__ void __launch_bounds__(256) sell_fill_block_lds_kernel(const int32_t*
   }
 }
 
-// one single-wave workgroup per slice (many small workgroups keep every CU busy); the slice's CSR
-// chunk is contiguous -> staged through LDS with coalesced loads, written back as 512-B k-columns
+// One WAVE per slice, independent waves (single-wave workgroups: 11 fit a CU's LDS; no workgroup barrier: a slice's staging area in LDS belongs to
+// its wave, and the LDS executes a wave's instructions in order).  The slice's CSR chunk is contiguous: staged through LDS
+// with coalesced loads -- all of a batch in flight before the first LDS write -- and written back as 512-B k-columns.  The
+// row offsets of the 64 rows come from ONE coalesced pair of loads (lane = row), so a slice costs two dependent global
+// latencies (offsets, values) instead of three.
 template <bool WITH_COLS>
 __global__ void __launch_bounds__(64) sell_fill_kernel(const int32_t* __restrict__ rowptr, const int32_t* __restrict__ colidx,
-                                                       const double* __restrict__ val, int64_t n_rows, int64_t n_slices,
-                                                       const int64_t* __restrict__ sptr, const int* __restrict__ sw,
-                                                       int maxw, double* __restrict__ sval, int32_t* __restrict__ scol) {
+                                                        const double* __restrict__ val, int64_t n_rows, int64_t n_slices,
+                                                        const int64_t* __restrict__ sptr, const int* __restrict__ sw,
+                                                        int maxw, double* __restrict__ sval, int32_t* __restrict__ scol) {
   extern __shared__ __align__(16) unsigned char sm[];
-  const int lane = threadIdx.x;
-  double* lv = reinterpret_cast<double*>(sm);
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const size_t per_wave = (size_t)SH * maxw * (WITH_COLS ? 12 : 8);
+  double* lv = reinterpret_cast<double*>(sm + wv * per_wave);
   int32_t* lc = reinterpret_cast<int32_t*>(lv + (size_t)SH * maxw);
-  for (int64_t s = blockIdx.x; s < n_slices; s += gridDim.x) {
-    const int64_t r0 = s * SH, r1 = r0 + SH < n_rows ? r0 + SH : n_rows;
-    const int lo0 = rowptr[r0];
-    const int cnt = rowptr[r1] - lo0;
-    for (int i = lane; i < cnt; i += 64) {
-      lv[i] = val[lo0 + i];
-      if (WITH_COLS) lc[i] = colidx[lo0 + i];
+  const int nwb = blockDim.x >> 6;
+  const int64_t w0 = (int64_t)blockIdx.x * nwb + wv, nw = (int64_t)gridDim.x * nwb;
+  for (int64_t s = w0; s < n_slices; s += nw) {
+    const int64_t row = s * SH + lane;
+    const int a = rowptr[row < n_rows ? row : n_rows], b = rowptr[row + 1 < n_rows ? row + 1 : n_rows];
+    const int lo0 = __builtin_amdgcn_readfirstlane(a);
+    const int cnt = __builtin_amdgcn_readlane(b, 63) - lo0;
+    const int lo = a - lo0, len = b - a;
+    constexpr int U = 8;
+    for (int i0 = 0; i0 < cnt; i0 += 64 * U) {
+      double v[U];
+      int32_t cc[U];
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const int i = i0 + 64 * u + lane;
+        v[u] = i < cnt ? val[lo0 + i] : 0.0;
+        if (WITH_COLS) cc[u] = i < cnt ? colidx[lo0 + i] : 0;
+      }
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const int i = i0 + 64 * u + lane;
+        if (i < cnt) {
+          lv[i] = v[u];
+          if (WITH_COLS) lc[i] = cc[u];
+        }
+      }
     }
-    __syncthreads();
-    const int64_t row = r0 + lane;
-    int lo = 0, len = 0;
-    if (row < n_rows) {
-      lo = rowptr[row] - lo0;
-      len = rowptr[row + 1] - rowptr[row];
-    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");   // the LDS writes above are ordered before the reads below
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     const int64_t base = sptr[s];
     const int wd = sw[s];
     for (int k = 0; k < wd; ++k) {
       sval[base + (int64_t)k * SH + lane] = k < len ? lv[lo + k] : 0.0;
       if (WITH_COLS) scol[base + (int64_t)k * SH + lane] = k < len ? lc[lo + k] : (row < n_rows ? (int32_t)row : 0);
     }
-    __syncthreads();
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");   // ... and these reads before the next slice's writes
+    __builtin_amdgcn_wave_barrier();
   }
 }
 

@@ -104,6 +104,81 @@ def _morton_order(xyz):
     return np.argsort(key, kind="stable")
 
 
+def _lift_high_order(conn, xyz, ngl, dim):
+    """Corner-node quadrilateral / hexahedral mesh -> ngl^dim nodes per cell in the reference's local order (vertices, edges,
+    faces, interior; src/elements/spectral.py:346-431), shared entities numbered once.  What src/domain/indices.py:66-88 does
+    with DMPlex's edge / face entities and their orientations is done with exact integer keys: a node on an edge is (the edge's
+    two vertex ids, its distance from the smaller one); a node on a face is (the face's four vertex ids, its distances from the
+    smallest vertex along the two face axes, the axis towards the smaller neighbour first); interior nodes belong to their
+    cell.  Coordinates: the multilinear map of the corners at the GLL points (HCooOp, src/domain/dmplex.py:66-95).
+    Returns (conn [E, ngl^dim], xyz [N, dim], {"ext_nodes": [F, ngl^(dim-1)] nodes of every exterior facet, "ext_corners":
+    [F, 2^(dim-1)] their corner ids})."""
+    from itertools import product
+
+    from pynama_amd.elements.spectral import Spectral, _local_lattice
+    E, m = conn.shape[0], ngl - 1
+    lat = np.array(_local_lattice(ngl, dim))                 # tensor position of every local node
+    clat = np.array(_local_lattice(2, dim))                  # ... of the corners ({0, 1}^dim)
+    corner_at = {tuple(int(v) for v in c): k for k, c in enumerate(clat)}
+    nn = lat.shape[0]
+    keys = np.zeros((E, nn, 7), dtype=np.int64)
+    el = np.arange(E, dtype=np.int64)
+    for ln in range(nn):
+        p = lat[ln]
+        free = [d for d in range(dim) if 0 < p[d] < m]
+        if not free:                                         # vertex
+            keys[:, ln, 0], keys[:, ln, 1] = 0, conn[:, corner_at[tuple(int(v) // m for v in p)]]
+            continue
+        if len(free) == dim:                                 # interior of the cell
+            keys[:, ln, 0], keys[:, ln, 1], keys[:, ln, 2] = 3, el, ln
+            continue
+        combos = list(product((0, 1), repeat=len(free)))     # corners of the edge / face the node sits on
+        bits = np.array(combos)
+        ids = np.empty((E, len(combos)), dtype=np.int64)
+        for q, cb in enumerate(combos):
+            c = [int(v) // m for v in p]
+            for d, b in zip(free, cb):
+                c[d] = b
+            ids[:, q] = conn[:, corner_at[tuple(c)]]
+        o = np.argmin(ids, axis=1)                           # the smallest vertex of the entity: its origin
+        obit = bits[o]                                       # [E, len(free)]
+        dist = np.abs(np.array([p[d] for d in free])[None, :] - obit * m)
+        srt = np.sort(ids, axis=1)
+        keys[:, ln, 0] = len(free)
+        keys[:, ln, 1:1 + srt.shape[1]] = srt
+        if len(free) == 1:
+            keys[:, ln, 5] = dist[:, 0]
+        else:                                                # face: the axis towards the smaller neighbour of the origin first
+            nb = np.empty((E, 2), dtype=np.int64)
+            for a in range(2):
+                flip = obit.copy()
+                flip[:, a] ^= 1
+                nb[:, a] = ids[el, flip[:, 0] * 2 + flip[:, 1]]
+            swap = nb[:, 1] < nb[:, 0]
+            keys[:, ln, 5] = np.where(swap, dist[:, 1], dist[:, 0])
+            keys[:, ln, 6] = np.where(swap, dist[:, 0], dist[:, 1])
+    uniq, inv = np.unique(keys.reshape(-1, 7), axis=0, return_inverse=True)
+    conn_ho = inv.reshape(E, nn)
+    nv = int((uniq[:, 0] == 0).sum())
+    assert np.array_equal(uniq[:nv, 1], np.arange(nv)), "every vertex of the file must belong to a cell"
+    H = np.asarray(Spectral(ngl, dim).HCooOp)                # [nn, 2^dim]: corner basis at the nodal points
+    xyz_ho = np.empty((uniq.shape[0], dim))
+    xyz_ho[conn_ho.ravel()] = np.einsum("gc,ecd->egd", H, xyz[conn[:, :2 ** dim]]).reshape(-1, dim)
+    xyz_ho[:nv] = xyz[:nv]                                   # vertices keep the file's coordinates bit for bit
+    # exterior facets (belong to one cell) with all their nodes
+    fn, fc = [], []
+    for d in range(dim):
+        for side in (0, 1):
+            loc = np.nonzero(lat[:, d] == side * m)[0]
+            cor = [k for k, c in enumerate(clat) if c[d] == side]
+            fn.append(conn_ho[:, loc])
+            fc.append(conn[:, cor])
+    fn, fc = np.concatenate(fn), np.concatenate(fc)
+    _, first, counts = np.unique(np.sort(fc, axis=1), axis=0, return_index=True, return_counts=True)
+    sel = first[counts == 1]
+    return conn_ho, xyz_ho, {"ext_nodes": fn[sel], "ext_corners": fc[sel]}
+
+
 class DMPlexDom(object):
     def __init__(self, **kwargs):
         self.comm = kwargs.get('comm') or get_world()
@@ -264,15 +339,20 @@ class DMPlexDom(object):
         blocks over the ranks, every rank keeps the cells touching an owned node (owner-computes) and the
         ghost nodes are addressed through an index list."""
         from pynama_amd.domain.gmsh import exterior_facets
-        if ngl != 2:
-            raise NotImplementedError("imported meshes carry corner nodes only: ngl must be 2")
         rank, size = self.comm.rank, self.comm.size
         self.ngl = ngl
         self.cellType = self._msh["cell"]
         conn = self._msh["conn"].astype(np.int64)
         xyz = self._msh["xyz"]
-        n = xyz.shape[0]
         facets = self._msh["facets"]
+        ho = None
+        if ngl != 2:
+            if self.cellType != "tensor":
+                raise NotImplementedError("high-order nodes are generated on quadrilateral / hexahedral cells only")
+            # the file carries corner nodes: edge / face / interior nodes are generated here, as IndicesManager does from the
+            # DMPlex entities (src/domain/indices.py:66-88)
+            conn, xyz, ho = _lift_high_order(conn, xyz, ngl, self.dim)
+        n = xyz.shape[0]
         if self.reorder == "morton":
             new_of_old = np.empty(n, dtype=np.int64)
             new_of_old[_morton_order(xyz)] = np.arange(n)
@@ -280,7 +360,15 @@ class DMPlexDom(object):
             conn = new_of_old[conn]
             facets = [(p, new_of_old[f]) for p, f in facets]
         self.nNodesGlobal = n
-        ext = exterior_facets(conn, self.dim)
+        if ho is not None:
+            # exterior facets with ALL their nodes (corners + the generated edge / face nodes), in the new numbering
+            ext = (new_of_old[ho["ext_nodes"]] if self.reorder == "morton" else ho["ext_nodes"])
+            if facets:     # physical tags of the file's boundary facets (corner tuples) -> every node of that facet
+                tag_of = {tuple(sorted(int(v) for v in f)): p for p, f in facets}
+                cor = new_of_old[ho["ext_corners"]] if self.reorder == "morton" else ho["ext_corners"]
+                facets = [(tag_of.get(tuple(sorted(int(v) for v in c)), 0), nodes) for c, nodes in zip(cor, ext)]
+        else:
+            ext = exterior_facets(conn, self.dim)
         ext_mask = np.zeros(n, dtype=bool)
         ext_mask[ext.ravel()] = True
         # named borders: physical tag k of a boundary facet <-> namingConvention[k-1] ("Face Sets", dmplex.py:168-171);

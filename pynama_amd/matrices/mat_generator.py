@@ -82,6 +82,25 @@ class DeviceMat:
         self.ctx.mat_axpy(out.id, 1.0, other.id)
         return out
 
+    def setValues(self, rows, cols, values, addv=None):
+        """PETSc.Mat.setValues: a dense block of values at scalar DOF indices (node * block + component), added when `addv`
+        is true (base_problem.py:531-547, mat_generator.py:113-118, 157-170).  The compatibility path for code written against
+        the reference's per-cell loops: one small upload + launch per call; the fused assemblies (Mat.assembleKLE,
+        Operators.assembleOperators) are the fast path."""
+        r0 = getattr(self.ctx, "row_start", 0)
+        rows = np.atleast_1d(np.asarray(rows, dtype=np.int64)) - r0 * self.br
+        cols = np.atleast_1d(np.asarray(cols, dtype=np.int64))
+        if r0:
+            raise NotImplementedError("Mat.setValues with global indices on more than one rank: use the fused assemblies")
+        self.ctx.mat_add_values(self.id, rows, cols, values, insert=not addv)
+        self._host_values = True
+
+    def setValue(self, row, col, value, addv=None):
+        self.setValues([row], [col], [value], addv)
+
+    def zeroEntries(self):
+        self.ctx.mat_zero(self.id)
+
     def diagonalScale(self, L=None, R=None):
         if R is not None:
             raise NotImplementedError("column scaling is not used by the reference path")
@@ -97,10 +116,6 @@ class DeviceMat:
         nnz = self.ctx.nnzb * self.br * self.bc
         return {"memory": nnz * 8 + self.ctx.nnzb * 4, "nz_allocated": nnz, "nz_used": nnz, "nz_unneeded": 0}
 
-    def setValues(self, rows, cols, vals, addv=True):
-        raise NotImplementedError(
-            "per-cell Mat.setValues (base_problem.py:531-547) is replaced by the fused device pass "
-            "Mat.assembleKLE(); there is no host insertion path")
 
     def toScipy(self):
         """host copy as scipy CSR (diagnostics / tests only)"""
@@ -190,8 +205,12 @@ class Mat:
         return np.repeat(d_nnz * dim1, dim2), np.repeat(o_nnz * dim1, dim2)
 
     def setIndices2One(self, indices2one):
-        """Unit diagonal on imposed DOFs (:113-118).  Already applied on the device by
-        assembleKLE (bc_identity kernel); kept for call-site compatibility."""
+        """Unit diagonal on imposed DOFs (:113-118).  Already applied on the device by the fused assembleKLE; inserted here
+        when the matrices were filled through the host insertion path."""
+        if getattr(self.K, "_host_values", False):     # matrices filled through Mat.setValues (per-cell loop of the reference)
+            for indd in np.asarray(indices2one, dtype=np.int64):
+                self.Krhs.setValues(indd, indd, 1, addv=True)
+                self.K.setValues(indd, indd, 1, addv=True)
         self.Krhs.assemble()
         self.K.assemble()
 
@@ -256,7 +275,36 @@ class Operators(Mat):
         return v
 
     def setValues(self, localOperators, nodes):
-        raise NotImplementedError("per-cell Operators.setValues is replaced by Operators.assembleOperators(elem)")
+        """per-cell insertion of the reference (mat_generator.py:157-170): the blocks of one cell into Curl / SrT / DivSrT and
+        the lumped weights.  Compatibility path (Operators.assembleOperators does all cells in three device passes); call
+        `createAll`, `setValues` per cell, `assembleAll`."""
+        locSrT, locDivSrT, locCurl, locWei = localOperators
+        nodes = np.asarray(list(nodes), dtype=np.int64)
+        if self.Curl is None:
+            self.Curl = DeviceMat(self.ctx, self.dim_w, self.dim, "Curl")
+            self.SrT = DeviceMat(self.ctx, self.dim_s, self.dim, "SrT")
+            self.DivSrT = DeviceMat(self.ctx, self.dim, self.dim_s, "DivSrT")
+            self._wsum = np.zeros(self.ctx.n_owned)
+        iv = (nodes[:, None] * self.dim + np.arange(self.dim)).ravel()
+        iw = (nodes[:, None] * self.dim_w + np.arange(self.dim_w)).ravel()
+        isr = (nodes[:, None] * self.dim_s + np.arange(self.dim_s)).ravel()
+        self.Curl.setValues(iw, iv, locCurl, True)
+        self.SrT.setValues(isr, iv, locSrT, True)
+        self.DivSrT.setValues(iv, isr, locDivSrT, True)
+        np.add.at(self._wsum, nodes, np.asarray(locWei, dtype=float).ravel())
 
     def assembleAll(self):
-        return None
+        """reciprocal lumped weights as row scaling (mat_generator.py:172-190) -- only after per-cell setValues; the fused
+        assembleOperators has applied it already"""
+        w = getattr(self, "_wsum", None)
+        if w is None:
+            return None
+        self.weights = w
+        for m in (self.SrT, self.DivSrT, self.Curl):
+            wv = Vec(self.ctx, m.br)
+            wv.setArray(np.repeat(w, m.br))
+            wv.reciprocal()
+            m.diagonalScale(L=wv)
+            m.assemble()
+        self.mats = [self.Curl, self.DivSrT, self.SrT]
+        self._wsum = None

@@ -345,3 +345,76 @@ def test_preonly_lu_raises_when_it_cannot_solve():
     ksp.max_it = 2000
     with pytest.raises(RuntimeError, match="preonly/lu substitute failed"):
         ksp(b, x)
+
+
+def test_reference_style_cell_loop_through_setValues():
+    """A case written against the reference's per-cell insertion API (Mat.setValues(rows, cols, vals, addv=True),
+    base_problem.py:499-552, mat_generator.py:113-118) runs unchanged: the loop below restates FreeSlip.buildKLEMats cell by
+    cell -- element matrices from Spectral.getElemKLEMatrices, Dirichlet elimination by index sets -- and must produce the
+    matrices of the fused device pass."""
+    from cases.uniform import UniformFlow
+
+    class CellLoop(UniformFlow):
+        def buildKLEMats(self):
+            bc = set(int(v) for v in self.dom.getNodesFromLabel("External Boundary", shared=True))
+            for cell in range(self.dom.cellStart, self.dom.cellEnd):
+                locK, locRw, _ = self.elemType.getElemKLEMatrices(self.dom.getCellCornersCoords(cell))
+                nodes = list(self.dom.getGlobalNodesFromCell(cell, shared=True))
+                vel, w = np.asarray(self.dom.getVelocityIndex(nodes)), np.asarray(self.dom.getVorticityIndex(nodes))
+                fixed = np.array([k * self.dim + d for k, nd in enumerate(nodes) if nd in bc for d in range(self.dim)], dtype=int)
+                free = np.setdiff1d(np.arange(len(vel)), fixed)
+                if fixed.size:
+                    self.mat.Krhs.setValues(vel[free], vel[fixed], -locK[np.ix_(free, fixed)], addv=True)
+                self.mat.K.setValues(vel[free], vel[free], locK[np.ix_(free, free)], addv=True)
+                self.mat.Rw.setValues(vel[free], w, locRw[free, :], addv=True)
+            self.mat.setIndices2One(self.mat.globalIndicesDIR)
+            self.mat.assembleAll()
+
+    with open(os.path.join(CASES, 'uniform.yaml')) as f:
+        cfg = yaml.load(f, Loader=yaml.Loader)
+    kw = dict(case='uniform', lower=[0, 0], upper=[1, 0.8], nelem=[5, 4], ngl=3)
+    fused, loop = UniformFlow(cfg, **kw), CellLoop(cfg, **kw)
+    for fem in (fused, loop):
+        fem.setUp()
+    for name in ("K", "Krhs", "Rw"):
+        a, b = getattr(fused.mat, name).toScipy(), getattr(loop.mat, name).toScipy()
+        assert abs(a - b).max() < 2e-13 * abs(a).max(), name
+    # ... and solves like it
+    loop.setUpSolver()
+    exactVel, exactVort = loop.generateExactVecs()
+    loop.solveKLE(time=0.0, vort=exactVort)
+    assert (exactVel - loop.vel).norm(norm_type=2) < 1e-12
+    # a new nonzero outside the graph is an error, not a silent drop
+    with pytest.raises(Exception, match="outside the node graph"):
+        loop.mat.K.setValues([0], [2 * (loop.dom.ctx.n_owned - 1)], [1.0], addv=True)
+
+
+@pytest.mark.parametrize("nelem,upper,ngl", [([5, 4], [1.0, 0.8], 3), ([5, 4], [1.0, 0.8], 5), ([3, 3, 2], [1.0, 0.8, 1.2], 3)])
+def test_gmsh_mesh_high_order(tmp_path, nelem, upper, ngl):
+    """High-order elements on an IMPORTED mesh (SURVEY.md 8 f3 + f4; src/domain/indices.py:66-88 handles any ngl on Gmsh
+    quad / hex meshes): the corner-node file is lifted to ngl^dim nodes per cell, K / Krhs / Rw equal the oracle's matrices
+    on the same connectivity, and the uniform field is reproduced to the reference's bar."""
+    from oracle import fem_oracle as fo
+    from cases.uniform import UniformFlow
+    from tests.util import mat_to_scipy, sp_rel_err
+    path = str(tmp_path / "box.msh")
+    box, perm, conn, xyz = _write_permuted_box(path, nelem, upper)
+    with open(os.path.join(CASES, 'uniform.yaml')) as f:
+        cfg = yaml.load(f, Loader=yaml.Loader)
+    cfg["domain"] = {"ngl": ngl, "gmsh-file": path}
+    fem = UniformFlow(cfg, case="uniform")
+    fem.setUp()
+    fem.setUpSolver()
+    dim = len(nelem)
+    dom = fem.dom
+    assert dom.conn.shape[1] == ngl ** dim and dom.xyz.shape[0] == int(np.prod([n * (ngl - 1) + 1 for n in nelem]))
+    mesh = fo.BoxMesh(dim, ngl, tuple(nelem), box.lattice, dom.conn, dom.xyz, np.nonzero(dom.boundaryMaskLocal())[0], {})
+    ref = fo.assemble_kle_freeslip(mesh, fo.Tables(ngl, dim))
+    ctx = fem.dom.ctx
+    dw = 1 if dim == 2 else 3
+    assert sp_rel_err(mat_to_scipy(ctx, fem.mat.K.id, dim, dim), ref["K"]) < 1e-12
+    assert sp_rel_err(mat_to_scipy(ctx, fem.mat.Krhs.id, dim, dim), ref["Krhs"]) < 1e-12
+    assert sp_rel_err(mat_to_scipy(ctx, fem.mat.Rw.id, dim, dw), ref["Rw"]) < 1e-12
+    exactVel, exactVort = fem.generateExactVecs()
+    fem.solveKLE(time=0.0, vort=exactVort)
+    assert (exactVel - fem.vel).norm(norm_type=2) < 1e-10
