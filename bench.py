@@ -522,7 +522,12 @@ def main():
                                       "metric prescribes; `format_actually_read` prices the bytes this kernel really streams"),
             "roofline_assembly": roofline(asm_kernel + " (zero + integration + scatter, one launch"
                                           + (": parallelepiped closed form, exact on the uniform box)" if asm_kernel.endswith("lattice_kernel") else ")"),
-                                          B_asm * share, asm_mean, traffic=tr_asm, traffic_source=src_asm),
+                                          B_asm * share, asm_mean, traffic=tr_asm, traffic_source=src_asm,
+                                          bytes_actually_moved_model={
+                                              "bytes_per_launch": (8.0 * nnz_global + 25.0 * n_node_global + 8.0 * n_node_global) * share,
+                                              "frac": (8.0 * nnz_global + 33.0 * n_node_global) * share / (asm_mean * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                                              "model": "values written (8 nnz) + coordinates and flags read (25 N) + 1/diagonal written (8 N); the "
+                                                       "lattice kernels read neither rowptr nor colidx (4 nnz + 4 N of the algorithmic count)"}),
             "roofline_assembly_general": general,
             "roofline_cg_iteration": {"bound": "hbm", "achieved": cg_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                       "frac": cg_gbs / HBM_PEAK_GBS, "algorithmic_bytes_per_iteration": B_cg * share},

@@ -163,10 +163,11 @@ __global__ void __launch_bounds__(TILE_THREADS, AFF ? 3 : 2) assemble_q1_hex_lat
       lat_integrate<TX, TY, TZ>(T, x0, y0, z0, acc, tid, TILE_THREADS);
   }
   const int anybc = __syncthreads_or(lat_meta_commit<TX, TY, TZ, TILE_THREADS>(T, z0, tid, meta, rlo, zrd, nbc));
+  lat_emit_dinv<TX, TY, TZ>(T, x0, y0, z0, acc, rlo, anybc ? nbc : nullptr, tid, TILE_THREADS);
   if (lat_tile_plain<TX, TY, TZ>(T, x0, y0, z0, zrd, anybc) && T.ablate != 4)
-    lat_store_plain<TX, TY, TZ>(T, acc, rlo, tid, TILE_THREADS, x0, y0, z0);
+    lat_store_plain<TX, TY, TZ>(T, acc, rlo, tid, TILE_THREADS);
   else
-    lat_store<TX, TY, TZ>(T, x0, y0, acc, rlo, zrd, nbc, tid, TILE_THREADS, z0);
+    lat_store<TX, TY, TZ>(T, x0, y0, acc, rlo, zrd, nbc, tid, TILE_THREADS);
 }
 
 // y_e = L_e x_e for a parallelepiped WITHOUT forming L_e: in the Haar basis of each axis ((v0, v1) -> (s, d) = (v0 + v1,

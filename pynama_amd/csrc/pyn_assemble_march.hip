@@ -56,11 +56,43 @@ struct MarchMeta {
   int r[NRW];
 };
 
-template <int TX, int TY, int NT, int NDOF>
-__device__ __forceinline__ void march_meta_load(const LatArgs& T, int x0, int y0, int l, int t, MarchMeta<TX, TY, NT, NDOF>& M) {
+// the layer-independent half of the index arithmetic (a column keeps its x, y footprint while it marches): in-plane node
+// offset / plane selector of every flag slot of this lane, in-row part of the closed-form row offset of its rows
+template <int TX, int TY, int NT>
+struct MarchMetaConst {
   using L = LatTile<TX, TY, 1>;
-  using MM = MarchMeta<TX, TY, NT, NDOF>;
+  static constexpr int NF = (L::NB + NT - 1) / NT, NRW = (L::NR + NT - 1) / NT;
+  int off[NF];       // y nx + x of the flag's node, -1: outside the mesh / beyond the box
+  int qz[NF];        // 0, 1, 2: plane l - 1, l, l + 1
+  int c1[NRW];       // (3 y - (y > 0)) sx + cy (3 x - (x > 0)), -1: no such row
+};
+
+template <int TX, int TY, int NT>
+__device__ __forceinline__ void march_meta_const(const LatArgs& T, int x0, int y0, int t, MarchMetaConst<TX, TY, NT>& K) {
+  using L = LatTile<TX, TY, 1>;
+  using MK = MarchMetaConst<TX, TY, NT>;
   const int nx = T.nx, ny = T.ny;
+#pragma unroll
+  for (int j = 0; j < MK::NF; ++j) {
+    const int i = t + j * NT;
+    const int qx = i % L::BX, qy = (i / L::BX) % L::BY;
+    const int x = x0 - 1 + qx, y = y0 - 1 + qy;
+    K.qz[j] = i / (L::BX * L::BY);
+    K.off[j] = (i < L::NB && x >= 0 && x < nx && y >= 0 && y < ny) ? y * nx + x : -1;
+  }
+  const int sx = 3 * nx - 2;
+#pragma unroll
+  for (int j = 0; j < MK::NRW; ++j) {
+    const int s = t + j * NT;
+    const int x = x0 + s % TX, y = y0 + s / TX;
+    const int cy = 3 - (y == 0) - (y == ny - 1);
+    K.c1[j] = (s < L::NR && x < nx && y < ny) ? (3 * y - (y > 0)) * sx + cy * (3 * x - (x > 0)) : -1;
+  }
+}
+
+template <int TX, int TY, int NT, int NDOF>
+__device__ __forceinline__ void march_meta_load(const LatArgs& T, const MarchMetaConst<TX, TY, NT>& K, int l, MarchMeta<TX, TY, NT, NDOF>& M) {
+  using MM = MarchMeta<TX, TY, NT, NDOF>;
   int base[3];
 #pragma unroll
   for (int qz = 0; qz < 3; ++qz) {
@@ -70,24 +102,21 @@ __device__ __forceinline__ void march_meta_load(const LatArgs& T, int x0, int y0
   M.ok = 0;
 #pragma unroll
   for (int j = 0; j < MM::NF; ++j) {
-    const int i = t + j * NT;
-    const int qx = i % L::BX, qy = (i / L::BX) % L::BY, qz = i / (L::BX * L::BY);
-    const int x = x0 - 1 + qx, y = y0 - 1 + qy;
-    const int b = qz == 0 ? base[0] : (qz == 1 ? base[1] : base[2]);
-    const bool ok = i < L::NB && x >= 0 && x < nx && y >= 0 && y < ny && b >= 0;
+    const int b = K.qz[j] == 0 ? base[0] : (K.qz[j] == 1 ? base[1] : base[2]);
+    const bool ok = K.off[j] >= 0 && b >= 0;
     M.ok |= (ok ? 1u : 0u) << j;
-    const int64_t node = ok ? (int64_t)b + y * nx + x : 0;
+    const int64_t node = ok ? (int64_t)b + K.off[j] : 0;
 #pragma unroll
     for (int q = 0; q < NDOF; ++q) M.raw[j][q] = T.bcmask ? T.bcmask[node * NDOF + q] : (unsigned char)0;
   }
+  // closed-form row offsets (lat_rowptr_std): (3 zo - (bot && zo > 0)) sy sx + cz c1 -- the marching kernels run on verified
+  // index arithmetic only (std_lat)
+  const int sx = 3 * T.nx - 2, sy = 3 * T.ny - 2;
+  const bool bot = T.p_own0 == 0, top = T.p_own0 + T.n_own == T.npl;
+  const int cz = 3 - (bot && l == 0) - (top && l == T.n_own - 1);
+  const int az = (3 * l - (bot && l > 0)) * sy * sx;
 #pragma unroll
-  for (int j = 0; j < MM::NRW; ++j) {
-    const int s = t + j * NT;
-    const int rx = s % TX, ry = s / TX;
-    const int x = x0 + rx, y = y0 + ry;
-    const bool ok = s < L::NR && x < nx && y < ny && l < T.n_own;
-    M.r[j] = ok ? lat_rowptr_std(T, x, y, l) : -1;   // the marching kernels run on verified index arithmetic only (std_lat)
-  }
+  for (int j = 0; j < MM::NRW; ++j) M.r[j] = (K.c1[j] >= 0 && l < T.n_own) ? az + cz * K.c1[j] : -1;
 }
 
 template <int TX, int TY, int NT, int NDOF>
@@ -175,6 +204,8 @@ __global__ void __launch_bounds__((TX + 1) * (TY + 1), WPS) assemble_q1_hex_marc
       const int rx = lx - 1 + i, ry = ly - 1 + j;
       ro[j][i] = (evalid && rx >= 0 && rx < TX && ry >= 0 && ry < TY) ? (ry * TX + rx) * 27 : -1;
     }
+  MarchMetaConst<TX, TY, NT> mconst;
+  march_meta_const<TX, TY, NT>(T, x0, y0, tid, mconst);
   for (int i = tid; i < 2 * MT::ACC; i += NT) lds[i] = 0.0;
   if (tid < 2) reinterpret_cast<int*>(nbc + ((L1::NB + 3) & ~3))[tid] = 0;
   double P[2][2][2][3] = {};   // [k][j][i][c]: bottom / top plane of the current layer
@@ -199,7 +230,7 @@ __global__ void __launch_bounds__((TX + 1) * (TY + 1), WPS) assemble_q1_hex_marc
     MARCH_STAMP(0);
     march_load_plane(T, min(gl + 2, T.npl - 1), n00, Pn);   // unconditional (clamped): in flight during the arithmetic
     MarchMeta<TX, TY, NT, 1> meta;
-    if (own_b) march_meta_load<TX, TY, NT, 1>(T, x0, y0, l, tid, meta);
+    if (own_b) march_meta_load<TX, TY, NT, 1>(T, mconst, l, meta);
     const bool act = lvalid && evalid;
     double L[28];
     if (act && !(T.ablate & 1)) {
@@ -271,10 +302,12 @@ __global__ void __launch_bounds__((TX + 1) * (TY + 1), WPS) assemble_q1_hex_marc
     if (tid == 0) anyflag[(l + 1) & 1] = 0;
     if (own_b && !(T.ablate & 8)) {
       double* buf = lds + (l & 1) * MT::ACC;
+      lat_emit_dinv<TX, TY, 1>(T, x0, y0, l, buf, rlo, anybc ? nbc : nullptr, tid, NT);
+      if (NT > 64 && T.dinv) __syncthreads();   // the stores below clear the accumulators other waves' lanes have just read
       if (lat_tile_plain<TX, TY, 1>(T, x0, y0, l, zrd, anybc) && T.ablate != 4)
-        lat_store_plain<TX, TY, 1, true>(T, buf, rlo, tid, NT, x0, y0, l);
+        lat_store_plain<TX, TY, 1, true>(T, buf, rlo, tid, NT);
       else
-        lat_store<TX, TY, 1, true>(T, x0, y0, buf, rlo, zrd, nbc, tid, NT, l);
+        lat_store<TX, TY, 1, true>(T, x0, y0, buf, rlo, zrd, nbc, tid, NT);
     }
     MARCH_STAMP(6);
     if (T.dbg && tid == 0 && l - zc0 + 1 < 32) T.dbg[((size_t)blockIdx.x * 32 + (l - zc0 + 1)) * 8 + 7] = __builtin_amdgcn_s_memrealtime();

@@ -208,12 +208,28 @@ __device__ __forceinline__ void lat_integrate(const LatArgs& T, int x0, int y0, 
   }
 }
 
+// Jacobi data on the way out: 1 / diagonal of every row of the tile, ONE lane per row and ONE division per lane (owned rows
+// carry the ids (zo ny + y) nx + x; imposed rows are identity rows).  Called between the barrier that completes the
+// accumulators and the store phase; `nbc` null: no imposed node in the node box.
+template <int TX, int TY, int TZ>
+__device__ __forceinline__ void lat_emit_dinv(const LatArgs& T, int x0, int y0, int z0, const double* acc, const int* rlo,
+                                              const unsigned char* nbc, int t, int nt) {
+  using LT = LatTile<TX, TY, TZ>;
+  if (!T.dinv) return;
+  for (int s = t; s < LT::NR; s += nt) {
+    if (rlo[s] < 0) continue;
+    const int rx = s % TX, ry = (s / TX) % TY, rz = s / (TX * TY);
+    const bool fr = nbc && nbc[((rz + 1) * LT::BY + ry + 1) * LT::BX + rx + 1];
+    T.dinv[((int64_t)(z0 + rz) * T.ny + (y0 + ry)) * T.nx + x0 + rx] = fr ? 1.0 : 1.0 / acc[s * 27 + 13];
+  }
+}
+
 // write every row of the tile once (half a wave per row, UNROLL rows in flight): A gets the free columns,
 // Arhs the imposed ones (negated), imposed rows become identity rows (mat_generator.py:113-118).
 // ZERO: clear each accumulator after reading it (the z-marching kernels reuse the buffer for the next plane).
 template <int TX, int TY, int TZ, bool ZERO = false>
 __device__ __forceinline__ void lat_store(const LatArgs& T, int x0, int y0, double* acc, const int* rlo, const int* zrd,
-                                          const unsigned char* nbc, int t, int nt, int z0 = 0) {
+                                          const unsigned char* nbc, int t, int nt) {
   using LT = LatTile<TX, TY, TZ>;
   const int nx = T.nx, ny = T.ny;
   double* __restrict__ outA = T.A;
@@ -262,11 +278,6 @@ __device__ __forceinline__ void lat_store(const LatArgs& T, int x0, int y0, doub
       if (lo[u] >= 0) {
         outA[lo[u]] = va;
         if (outR) outR[lo[u]] = vr;
-        if (T.dinv && diag[u]) {   // Jacobi data on the way out (owned rows carry the ids (zo ny + y) nx + x)
-          const int s = min(s0 + u * NH, LT::NR - 1);
-          const int rx = s % TX, ry = (s / TX) % TY, rz = s / (TX * TY);
-          T.dinv[((int64_t)(z0 + rz) * ny + (y0 + ry)) * nx + x0 + rx] = 1.0 / va;
-        }
         if (ZERO) acc[ai[u]] = 0.0;   // every accumulated slot is some row's CSR entry: this clears the whole buffer
       }
     }
@@ -278,8 +289,7 @@ __device__ __forceinline__ void lat_store(const LatArgs& T, int x0, int y0, doub
 // one contiguous run of TX*27 doubles both in LDS and in the CSR value array.  Straight coalesced copy.
 constexpr int ZCODE_STD = 3 | (0 << 2) | (1 << 4) | (2 << 6);
 template <int TX, int TY, int TZ, bool ZERO = false>
-__device__ __forceinline__ void lat_store_plain(const LatArgs& T, double* acc, const int* rlo, int t, int nt, int x0 = 0, int y0 = 0,
-                                                int z0 = 0) {
+__device__ __forceinline__ void lat_store_plain(const LatArgs& T, double* acc, const int* rlo, int t, int nt) {
   constexpr int LINE = TX * 27, NL = TY * TZ, PER = (LINE + 63) / 64;
   double* __restrict__ outA = T.A;
   double* __restrict__ outR = T.Arhs;
@@ -299,8 +309,6 @@ __device__ __forceinline__ void lat_store_plain(const LatArgs& T, double* acc, c
       if (i < LINE) {
         outA[base + i] = v[j];
         if (outR) outR[base + i] = 0.0;
-        if (T.dinv && i % 27 == 13)   // the diagonal entry of row i / 27 of this x-line
-          T.dinv[((int64_t)(z0 + l / TY) * T.ny + (y0 + l % TY)) * T.nx + x0 + i / 27] = 1.0 / v[j];
       }
     }
   }
