@@ -101,8 +101,14 @@ def test_rejects_unsupported(tmp_path):
     r = str(tmp_path / "b.msh")
     write_msh(r, box.xyz, box.conn)
     d = DMPlexDom(fileName=r, comm=Comm())
-    with pytest.raises(NotImplementedError, match="ngl must be 2"):
-        d.setFemIndexing(3)
+    d.setFemIndexing(3)                      # quadrilaterals / hexahedra take any ngl (tests/test_highorder_import_host.py)
+    assert d.conn.shape == (4, 9) and d.xyz.shape[0] == 25
+    from pynama_amd.domain.gmsh import write_msh as _w
+    tri = fo.simplex_box_mesh([2, 2], [0, 0], [1, 1])
+    t = str(tmp_path / "t.msh")
+    _w(t, tri.xyz, tri.conn)
+    with pytest.raises(NotImplementedError, match="quadrilateral / hexahedral"):
+        DMPlexDom(fileName=t, comm=Comm()).setFemIndexing(3)
 
 
 @pytest.mark.parametrize("cell,nelem,size", [("tet", [4, 3, 5], 3), ("hex", [4, 4, 6], 2), ("tri", [7, 6], 4), ("tet", [5, 5, 5], 5)])
