@@ -200,10 +200,11 @@ def config_poisson(_lib, DMPlexDom, Spectral, nelem, cg_iters, name):
     return out
 
 
-def config_kle(_lib, DMPlexDom, Spectral, n, cg_iters):
+def config_kle(_lib, DMPlexDom, Spectral, n, cg_iters, jitter=0.0):
     """C3: 3 DOFs per node on the 128^3 mesh -- the reference's KLE system stands in for 'linear elasticity' (SURVEY.md 0.3:
-    the reference has no elasticity form; K is its vector-valued stiffness with 3x3 blocks)"""
-    dom = DMPlexDom(boxMesh={"nelem": [n, n, n], "lower": [0, 0, 0], "upper": [1, 1, 1]})
+    the reference has no elasticity form; K is its vector-valued stiffness with 3x3 blocks).  jitter > 0: general geometry
+    (every cell integrated with 8 + 1 Gauss points, as spectral.py:117-156 does)"""
+    dom = DMPlexDom(boxMesh={"nelem": [n, n, n], "lower": [0, 0, 0], "upper": [1, 1, 1]}, jitter=jitter)
     dom.setFemIndexing(2)
     ctx = dom.ctx
     for t in Spectral(2, 3).deviceTables():
@@ -225,11 +226,14 @@ def config_kle(_lib, DMPlexDom, Spectral, n, cg_iters):
         info = ctx.solve(K, vr, vx, fixed_iters=cg_iters, profile=1)
     chk = ctx.solve(K, vr, vx, rtol=1e-10, maxit=20000, norm_type=_lib.NORM_UNPRECONDITIONED)
     err = float(np.abs(ctx.vec_get(vx, 3).reshape(-1, 3) - [1.0, 0.0, 0.0]).max())
-    out = {"config": f"C3: 3D KLE (3 DOF/node, alpha_d 1e3, alpha_w 1e2) on {n}^3 Q1 hex, uniform-flow boundary data", "n_elem": n ** 3,
+    out = {"config": f"C3: 3D KLE (3 DOF/node, alpha_d 1e3, alpha_w 1e2) on {n}^3 Q1 hex, uniform-flow boundary data"
+                     + (f", nodes jittered by {jitter} h (general geometry)" if jitter else ""), "n_elem": n ** 3,
            "n_dof": 3 * n_rows, "nnz_blocks": nnz, "assembly_ms_K_Krhs_Rw": med,
            "element_dofs_per_s": n ** 3 * 24 / (med * 1e-3),
            "assembly_frac_of_hbm_peak": B_asm / (med * 1e-3) / 1e9 / HBM_PEAK_GBS,
-           "kernel": "assemble_q1_hex_kle_lattice_kernel (closed-form blocks on parallelepipeds, four waves per tile)",
+           "kernel": "assemble_q1_hex_kle_lattice_kernel (four waves per tile; "
+                     + ("general geometry: closed form of the 2x2x2 rule, Gauss points split over the waves for K, node columns for Rw)"
+                        if jitter else "closed-form blocks on parallelepipeds)"),
            "cg_iters_per_s": cg_iters / (info.solve_ms * 1e-3), "block_spmv_ms": info.spmv_ms,
            "spmv_frac_of_hbm_peak": B_spmv / (info.spmv_ms * 1e-3) / 1e9 / HBM_PEAK_GBS if info.spmv_ms > 0 else None,
            "cg_iteration_frac_of_hbm_peak": B_cg / (info.solve_ms / cg_iters * 1e-3) / 1e9 / HBM_PEAK_GBS,
@@ -465,6 +469,7 @@ def main():
                         ("C2", lambda: config_poisson(_lib, DMPlexDom, Spectral, [128, 128, 128], 100,
                                                        "C2: 3D Poisson on 128^3 Q1 hex, FP64 assembly + Jacobi-PCG")),
                         ("C3", lambda: config_kle(_lib, DMPlexDom, Spectral, 128, 50)),
+                        ("C3_general_geometry", lambda: config_kle(_lib, DMPlexDom, Spectral, 128, 50, jitter=0.2)),
                         ("C5", lambda: config_tets(_lib, DMPlexDom, 94, 300))):
             try:
                 extra[key] = fn()

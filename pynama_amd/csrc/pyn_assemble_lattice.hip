@@ -896,40 +896,59 @@ __device__ __forceinline__ void kle_lat_rows(const KleLatArgs& T, const double (
 //   Gr      = adj(J'_0) s / det'_0,  c_r = w_r det'_0 / 512                            (reduced rule: the centroid)
 // for the two node rows {A0, A0+1} this wave adds.  Every wave recomputes the geometry of its element (54 + 72 of its ~190
 // FP64 instructions per Gauss point): the node rows are what is split four ways, as in the closed-form kernel.
-template <bool RW, int A0>
-__device__ __forceinline__ void kle_gen_point(const double (&C)[2][2][2][3], const Q1PointTab& tb, double (&Lab)[2][8], double (&Tv)[3][2][8]) {
+// One Gauss point.  K (RW = false): this wave's two node ROWS {A0, A0+1}: Lab[h][b] += s g[a_h] . g[b] (all gradients needed).
+// Rw (RW = true): this wave's two node COLUMNS {A0, A0+1}: Tc[m][a][h] += N'_a g_m[b_h] -- only the gradients of its two
+// columns are formed (18 instead of 72 FP64 instructions per point), the determinant cancels and is never computed.
+// Rw, one Gauss point: this wave's two node COLUMNS {A0, A0+1}: Tc[m][a][h] += N'_a g_m[b_h] -- only the gradients of its two
+// columns are formed (18 instead of 72 FP64 instructions per point); the determinant cancels and is never computed.
+template <int A0>
+__device__ __forceinline__ void kle_gen_point_rw(const double (&C)[2][2][2][3], const Q1PointTab& tb, double (&Tc)[3][8][2]) {
   double A[3][3];
-  const double det = q1_point_adj_rt(C, tb, A);
-  const double s = RW ? 0.0 : (1.0 / 512.0) * q1_rcp(det);
+  (void)q1_point_adj_rt(C, tb, A);
 #pragma unroll
-  for (int x = 0; x < 3; ++x) {
-    double g[8];
-#pragma unroll
-    for (int a = 0; a < 8; ++a) g[a] = fma(A[2][x], tb.h[2][a], fma(A[1][x], tb.h[1][a], A[0][x] * tb.h[0][a]));
+  for (int m = 0; m < 3; ++m)
 #pragma unroll
     for (int h = 0; h < 2; ++h) {
-      const int a = A0 + h;
-      if (!RW) {
+      const int b = A0 + h;
+      const double gb = fma(A[2][m], tb.h[2][b], fma(A[1][m], tb.h[1][b], A[0][m] * tb.h[0][b]));
+#pragma unroll
+      for (int a = 0; a < 8; ++a) Tc[m][a][h] = fma(tb.n[a], gb, Tc[m][a][h]);   // tb.n = N'_a / 4096 at this point
+    }
+}
+
+// K: the scalar Laplacian part L_ab of the element is shared by the four waves -- wave w integrates the Gauss points
+// {2w, 2w+1} (28 off-diagonal entries), the partial sums meet in LDS (Lsh[28][64 elements], ds_add_f64), every wave then reads the
+// two node rows it adds.  Per wave 2 instead of 8 geometry evaluations (126 FP64 instructions each).
+__device__ __forceinline__ void kle_gen_partial_L(const double (&C)[2][2][2][3], int g0, double (&Lo)[28]) {
+#pragma unroll
+  for (int i = 0; i < 28; ++i) Lo[i] = 0.0;
+#pragma nounroll
+  for (int G = g0; G < g0 + 2; ++G) {
+    const Q1PointTab& tb = Q1_POINTS[G];
+    double A[3][3];
+    const double det = q1_point_adj_rt(C, tb, A);
+    const double s = (1.0 / 512.0) * q1_rcp(det);
+#pragma unroll
+    for (int x = 0; x < 3; ++x) {
+      double g[8];
+#pragma unroll
+      for (int a = 0; a < 8; ++a) g[a] = fma(A[2][x], tb.h[2][a], fma(A[1][x], tb.h[1][a], A[0][x] * tb.h[0][a]));
+#pragma unroll
+      for (int a = 0; a < 7; ++a) {
         const double t = s * g[a];
 #pragma unroll
-        for (int b = 0; b < 8; ++b) Lab[h][b] = fma(t, g[b], Lab[h][b]);
-      } else {
-        const double na = tb.n[a];   // N'_a / 4096 at this point
-#pragma unroll
-        for (int b = 0; b < 8; ++b) Tv[x][h][b] = fma(na, g[b], Tv[x][h][b]);
+        for (int b = a + 1; b < 8; ++b) Lo[q1_off(a, b)] = fma(t, g[b], Lo[q1_off(a, b)]);
       }
     }
   }
 }
 
 template <int TX, int TY, int TZ, bool RW, int A0>
-__device__ __forceinline__ void kle_lat_rows_general(const KleLatArgs& T, const double (&P)[2][2][2][3], int lx, int ly, int lz, int z0,
-                                                     double* acc) {
+__device__ __forceinline__ void kle_lat_rows_general(const KleLatArgs& T, const double (&C)[2][2][2][3], const double* Lsh, int lane, int lx,
+                                                     int ly, int lz, int z0, double* acc) {
   constexpr int CX[8] = {0, 0, 1, 1, 0, 1, 1, 0};
   constexpr int CY[8] = {0, 1, 1, 0, 0, 0, 1, 1};
   constexpr int CZ[8] = {0, 0, 0, 0, 1, 1, 1, 1};
-  double C[2][2][2][3];
-  q1_haar_coeffs(P, C);
   // reduced rule: the centroid (xi = 0): J'_0 rows are the first-order Haar coefficients
   double Gr[3][8], cr;
   {
@@ -959,26 +978,42 @@ __device__ __forceinline__ void kle_lat_rows_general(const KleLatArgs& T, const 
         Gr[x][a] = ((2 * CX[a] - 1) * A[0][x] + (2 * CY[a] - 1) * A[1][x] + (2 * CZ[a] - 1) * A[2][x]) * ri;
   }
   const double caw = cr * T.alpha_w, cad = cr * T.alpha_d;
-  double Lab[2][8], Tv[3][2][8];
+  double Lab[2][8], Tc[3][8][2];
 #pragma unroll
   for (int h = 0; h < 2; ++h)
 #pragma unroll
     for (int b = 0; b < 8; ++b) {
       Lab[h][b] = 0.0;
-      Tv[0][h][b] = Tv[1][h][b] = Tv[2][h][b] = 0.0;
+      Tc[0][b][h] = Tc[1][b][h] = Tc[2][b][h] = 0.0;
     }
+  if (RW) {
 #pragma nounroll
-  for (int G = 0; G < 8; ++G) kle_gen_point<RW, A0>(C, Q1_POINTS[G], Lab, Tv);
+    for (int G = 0; G < 8; ++G) kle_gen_point_rw<A0>(C, Q1_POINTS[G], Tc);
+  } else {     // this wave's two rows of the shared element Laplacian; the diagonal from the zero row sums
 #pragma unroll
-  for (int h = 0; h < 2; ++h) {
-    const int a = A0 + h;
-    const int rx = lx - 1 + CX[a], ry = ly - 1 + CY[a], rz = lz - 1 + CZ[a];
-    if (rx < 0 || rx >= TX || ry < 0 || ry >= TY || rz < 0 || rz >= TZ || z0 + rz >= T.L.n_own) continue;
-    double* rowp = acc + ((rz * TY + ry) * TX + rx) * 243;
+    for (int h = 0; h < 2; ++h) {
+      const int a = A0 + h;
+      double d = 0.0;
 #pragma unroll
-    for (int b = 0; b < 8; ++b) {
-      const int kk = (CZ[b] - CZ[a] + 1) * 9 + (CY[b] - CY[a] + 1) * 3 + (CX[b] - CX[a] + 1);
-      if (!RW) {
+      for (int b = 0; b < 8; ++b)
+        if (b != a) {
+          const double v = Lsh[(a < b ? q1_off(a, b) : q1_off(b, a)) * 64 + lane];
+          Lab[h][b] = v;
+          d -= v;
+        }
+      Lab[h][a] = d;
+    }
+  }
+  if (!RW) {
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      const int a = A0 + h;
+      const int rx = lx - 1 + CX[a], ry = ly - 1 + CY[a], rz = lz - 1 + CZ[a];
+      if (rx < 0 || rx >= TX || ry < 0 || ry >= TY || rz < 0 || rz >= TZ || z0 + rz >= T.L.n_own) continue;
+      double* rowp = acc + ((rz * TY + ry) * TX + rx) * 243;
+#pragma unroll
+      for (int b = 0; b < 8; ++b) {
+        const int kk = (CZ[b] - CZ[a] + 1) * 9 + (CY[b] - CY[a] + 1) * 3 + (CX[b] - CX[a] + 1);
         const double s_ab = Gr[0][a] * Gr[0][b] + Gr[1][a] * Gr[1][b] + Gr[2][a] * Gr[2][b];
         const double diag = Lab[h][b] + caw * s_ab;
 #pragma unroll
@@ -989,11 +1024,22 @@ __device__ __forceinline__ void kle_lat_rows_general(const KleLatArgs& T, const 
             if (pp == q) v += diag;
             atomicAdd(&rowp[(pp * 27 + kk) * 3 + q], v);
           }
-      } else {
+      }
+    }
+  } else {
+#pragma unroll
+    for (int a = 0; a < 8; ++a) {     // every node row of the element, this wave's two columns
+      const int rx = lx - 1 + CX[a], ry = ly - 1 + CY[a], rz = lz - 1 + CZ[a];
+      if (rx < 0 || rx >= TX || ry < 0 || ry >= TY || rz < 0 || rz >= TZ || z0 + rz >= T.L.n_own) continue;
+      double* rowp = acc + ((rz * TY + ry) * TX + rx) * 243;
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        const int b = A0 + h;
+        const int kk = (CZ[b] - CZ[a] + 1) * 9 + (CY[b] - CY[a] + 1) * 3 + (CX[b] - CX[a] + 1);
         const double hb = T.Hr[b];
 #pragma unroll
         for (int m = 0; m < 3; ++m) {
-          const double wv = Tv[m][h][b] - caw * Gr[m][a] * hb;
+          const double wv = Tc[m][a][h] - caw * Gr[m][a] * hb;
           const int P1 = (m + 1) % 3, P2 = (m + 2) % 3;
           atomicAdd(&rowp[(P2 * 27 + kk) * 3 + P1], wv);
           atomicAdd(&rowp[(P1 * 27 + kk) * 3 + P2], -wv);
@@ -1001,6 +1047,13 @@ __device__ __forceinline__ void kle_lat_rows_general(const KleLatArgs& T, const 
       }
     }
   }
+}
+
+// LDS of the KLE lattice kernels: acc[NR][243] doubles | rlo, zrd, nbc (META_INTS ints) | Lsh[28][64] doubles (general-geometry K)
+template <int TX, int TY, int TZ>
+__host__ __device__ constexpr int KLE_LSH_OFF() {
+  using LT = LatTile<TX, TY, TZ>;
+  return LT::NR * 243 + (LT::META_INTS + 1) / 2;
 }
 
 template <int TX, int TY, int TZ, bool RW, bool GEN>
@@ -1024,14 +1077,18 @@ __global__ void __launch_bounds__(256, GEN ? 2 : 3) assemble_q1_hex_kle_lattice_
   __syncthreads();
 
   const double* __restrict__ S = L.q.aff + 248;
-  for (int t = lane; t < LT::NE && L.ablate != 1; t += 64) {
+  // ---- general geometry: every wave sees the same elements (lane = element); uniform trip count, barriers inside
+  double* Lsh = reinterpret_cast<double*>(lds) + KLE_LSH_OFF<TX, TY, TZ>();   // [28][64]: the element Laplacians of this batch (K only)
+  for (int t0 = 0; GEN && t0 < LT::NE && L.ablate != 1; t0 += 64) {
+    const int t = t0 + lane;
     const int lx = t % LT::EX, ly = (t / LT::EX) % LT::EY, lz = t / (LT::EX * LT::EY);
     const int gx = x0 - 1 + lx, gy = y0 - 1 + ly, gl = L.p_own0 + z0 - 1 + lz;
-    if (gx < 0 || gx >= nx - 1 || gy < 0 || gy >= ny - 1 || gl < 0 || gl >= L.npl - 1) continue;
-    const int n00 = gy * nx + gx;
-    const double* q0 = L.xyz + (int64_t)(lat_plane(L, gl) + n00) * 3;
-    const double* qz = L.xyz + (int64_t)(lat_plane(L, gl + 1) + n00) * 3;
-    if (GEN) {   // general geometry: all eight corners, quadrature in closed form
+    const bool valid = t < LT::NE && gx >= 0 && gx < nx - 1 && gy >= 0 && gy < ny - 1 && gl >= 0 && gl < L.npl - 1;
+    double C[2][2][2][3];
+    if (valid) {
+      const int n00 = gy * nx + gx;
+      const double* q0 = L.xyz + (int64_t)(lat_plane(L, gl) + n00) * 3;
+      const double* qz = L.xyz + (int64_t)(lat_plane(L, gl + 1) + n00) * 3;
       double P[2][2][2][3];
 #pragma unroll
       for (int j = 0; j < 2; ++j)
@@ -1042,14 +1099,36 @@ __global__ void __launch_bounds__(256, GEN ? 2 : 3) assemble_q1_hex_kle_lattice_
             P[0][j][i][cc] = q0[(j * nx + i) * 3 + cc];
             P[1][j][i][cc] = qz[(j * nx + i) * 3 + cc];
           }
-      switch (part) {
-        case 0: kle_lat_rows_general<TX, TY, TZ, RW, 0>(T, P, lx, ly, lz, z0, acc); break;
-        case 1: kle_lat_rows_general<TX, TY, TZ, RW, 2>(T, P, lx, ly, lz, z0, acc); break;
-        case 2: kle_lat_rows_general<TX, TY, TZ, RW, 4>(T, P, lx, ly, lz, z0, acc); break;
-        default: kle_lat_rows_general<TX, TY, TZ, RW, 6>(T, P, lx, ly, lz, z0, acc); break;
-      }
-      continue;
+      q1_haar_coeffs(P, C);
     }
+    if (!RW) {
+      for (int i = tid; i < 28 * 64; i += 256) Lsh[i] = 0.0;
+      __syncthreads();
+      if (valid) {
+        double Lo[28];
+        kle_gen_partial_L(C, 2 * part, Lo);
+#pragma unroll
+        for (int i = 0; i < 28; ++i) atomicAdd(&Lsh[i * 64 + lane], Lo[i]);
+      }
+      __syncthreads();
+    }
+    if (valid) {
+      switch (part) {
+        case 0: kle_lat_rows_general<TX, TY, TZ, RW, 0>(T, C, Lsh, lane, lx, ly, lz, z0, acc); break;
+        case 1: kle_lat_rows_general<TX, TY, TZ, RW, 2>(T, C, Lsh, lane, lx, ly, lz, z0, acc); break;
+        case 2: kle_lat_rows_general<TX, TY, TZ, RW, 4>(T, C, Lsh, lane, lx, ly, lz, z0, acc); break;
+        default: kle_lat_rows_general<TX, TY, TZ, RW, 6>(T, C, Lsh, lane, lx, ly, lz, z0, acc); break;
+      }
+    }
+    if (!RW && t0 + 64 < LT::NE) __syncthreads();   // the next batch clears Lsh
+  }
+  for (int t = lane; !GEN && t < LT::NE && L.ablate != 1; t += 64) {
+    const int lx = t % LT::EX, ly = (t / LT::EX) % LT::EY, lz = t / (LT::EX * LT::EY);
+    const int gx = x0 - 1 + lx, gy = y0 - 1 + ly, gl = L.p_own0 + z0 - 1 + lz;
+    if (gx < 0 || gx >= nx - 1 || gy < 0 || gy >= ny - 1 || gl < 0 || gl >= L.npl - 1) continue;
+    const int n00 = gy * nx + gx;
+    const double* q0 = L.xyz + (int64_t)(lat_plane(L, gl) + n00) * 3;
+    const double* qz = L.xyz + (int64_t)(lat_plane(L, gl + 1) + n00) * 3;
     double E[3][3];
 #pragma unroll
     for (int x = 0; x < 3; ++x) {
@@ -1327,7 +1406,8 @@ static int launch_kle_lattice(pyn_ctx* c, KleLatArgs& T, double* K, double* Krhs
   T.L.ntx = (T.L.nx + TX - 1) / TX;
   T.L.nty = (T.L.ny + TY - 1) / TY;
   const int n_tiles = T.L.ntx * T.L.nty * ((T.L.n_own + TZ - 1) / TZ);
-  const size_t lds = (size_t)LT::NR * 243 * sizeof(double) + LT::META_INTS * sizeof(int);
+  const size_t lds = GEN ? ((size_t)KLE_LSH_OFF<TX, TY, TZ>() + 28 * 64) * sizeof(double)
+                         : (size_t)LT::NR * 243 * sizeof(double) + LT::META_INTS * sizeof(int);
   static bool attr_done = false;
   if (!attr_done) {
     PYN_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(assemble_q1_hex_kle_lattice_kernel<TX, TY, TZ, false, GEN>),

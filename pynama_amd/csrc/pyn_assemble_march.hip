@@ -395,6 +395,9 @@ int pyn_assemble_lattice_march(pyn_ctx* c, void* lat_args, int tile) {
     case 6: return launch_march<7, 7, 3, true>(c, T, 7);
     case 7: return launch_march<7, 7, 2>(c, T, 7);     // Gauss points unrolled: 256 VGPRs, 9 % slower than the rolled loop
     case 8: return launch_march<15, 7, 3, true>(c, T, 3);
+    case 9: return launch_march<15, 7, 2, true>(c, T, 3);
+    case 10: return launch_march<15, 15, 1, true>(c, T, 1);
+    case 11: return launch_march<15, 11, 2, true>(c, T, 2);
     // one wave per workgroup, 7 workgroups per CU, rolled loop over the Gauss points (224 VGPRs): fastest measured
     default: return launch_march<7, 7, 2, true>(c, T, 7);
   }
