@@ -241,6 +241,8 @@ __global__ void __launch_bounds__(TILE_THREADS, 2) assemble_q1_hex_tiled_kernel(
         for (int i = 0; i < 36; ++i) L[i] = X[i % 8][i % 3];
       } else if (T.aff && __all(element_is_affine(T, X) ? 1 : 0)) {
         affine_laplace(T, X, L);  // whole wave on parallelepipeds (uniform box meshes)
+      } else if (T.lean) {        // (uniform) standard tables: closed form of the same rule (pyn_q1_hex.h)
+        q1_laplace_lean36(X, L);
       } else {
 #pragma nounroll
         for (int g = 0; g < 8; ++g) gauss_point(T, g, X, L);
@@ -539,6 +541,7 @@ struct KleArgs {
   const double* aff;
   int ablate;    // diagnostics (PYNAMA_KLE_ABLATE): 1 = no element phase, 2 = element phase without the scatter map reads
   int aff_rw;    // the closed-form int N_a d N_b table was verified: affine elements skip the Gauss loop of Rw
+  int lean;      // standard 2x2x2 Gauss tables: general elements take q1_laplace_lean36 for the Laplacian part
   double alpha_d, alpha_w;
   double* K;     // WHICH 0: K     | WHICH 1: Rw
   double* Krhs;  // WHICH 0: Krhs (may be null)
@@ -660,6 +663,8 @@ __global__ void __launch_bounds__(KLE_THREADS, 2) assemble_q1_hex_kle_tiled_kern
         S.aff = T.aff;
         if (T.aff && __all(element_is_affine(S, X) ? 1 : 0)) {
           affine_laplace(S, X, L);
+        } else if (T.lean) {
+          q1_laplace_lean36(X, L);
         } else {
 #pragma nounroll
           for (int g = 0; g < 8; ++g) gauss_point(S, g, X, L);
@@ -1208,6 +1213,7 @@ static int assemble_kle_tiled(pyn_ctx* c, double alpha_d, double alpha_w, double
   T.hcoor = c->quad[1].HrsCoo;
   T.aff = getenv("PYNAMA_NO_AFFINE") ? nullptr : c->d_aff;
   T.aff_rw = (T.aff && c->aff_rw_standard) ? 1 : 0;
+  T.lean = c->q1_gauss_standard && !getenv("PYNAMA_NO_LEAN") ? 1 : 0;
   {
     const char* ab = getenv("PYNAMA_KLE_ABLATE");
     T.ablate = ab ? atoi(ab) : 0;
@@ -1320,6 +1326,7 @@ int pyn_assemble_q1_tiled(pyn_ctx* c, int form, double alpha_d, double alpha_w, 
   T.hrs = c->quad[0].Hrs;
   T.hcoo = c->quad[0].HrsCoo;
   T.aff = getenv("PYNAMA_NO_AFFINE") ? nullptr : c->d_aff;
+  T.lean = c->q1_gauss_standard && !getenv("PYNAMA_NO_LEAN") ? 1 : 0;
   T.A = K;
   T.Arhs = Krhs;
   size_t lds = (size_t)P.maxrows * P.maxlen * sizeof(double) + (size_t)P.maxrows * 3 * sizeof(int);

@@ -168,23 +168,8 @@ __device__ __forceinline__ void lat_integrate(const LatArgs& T, int x0, int y0, 
       X[a][2] = q[2];
     }
     double L[36];
-    if (T.lean) {   // (uniform) closed form of the same 8-point rule: 1,770 instead of 2,540 FP64 instructions
-      double P[2][2][2][3], Lo[28];
-#pragma unroll
-      for (int a = 0; a < 8; ++a)
-#pragma unroll
-        for (int c = 0; c < 3; ++c) P[CZ[a]][CY[a]][CX[a]][c] = X[a][c];
-      q1_laplace_lean_rolled(P, 1.0 / 512.0, Lo);
-#pragma unroll
-      for (int a = 0; a < 8; ++a) {
-        double d = 0.0;
-#pragma unroll
-        for (int b = 0; b < 8; ++b)
-          if (b != a) d -= q1_sym(Lo, a, b);
-        L[tri(a, a)] = d;
-#pragma unroll
-        for (int b = a + 1; b < 8; ++b) L[tri(a, b)] = Lo[q1_off(a, b)];
-      }
+    if (T.lean) {   // (uniform) closed form of the same 8-point rule: 1,900 instead of 2,540 FP64 instructions
+      q1_laplace_lean36(X, L);
     } else if (T.q.aff && __all(element_is_affine(T.q, X) ? 1 : 0)) {
       affine_laplace(T.q, X, L);
     } else {

@@ -29,6 +29,7 @@ struct TileArgs {
   const double* hrs;    // [8][3][8]  reference gradients of the nodal basis at the Gauss points
   const double* hcoo;   // [8][3][8]  reference gradients of the geometry (corner) basis
   const double* aff;    // [6][36] affine reference matrices + [4][8] monomial signs (null: shortcut off)
+  int lean = 0;         // the uploaded tables are the standard 2x2x2 Gauss tables: general elements take q1_laplace_lean36
   double* A;            // values for free columns
   double* Arhs;         // -values for imposed columns (may be null)
 };
@@ -462,5 +463,29 @@ __device__ __forceinline__ void q1_laplace_point_idx(const double (&C)[2][2][2][
 }
 
 __device__ __forceinline__ double q1_sym(const double (&L)[28], int a, int b) { return a < b ? L[q1_off(a, b)] : L[q1_off(b, a)]; }
+
+// the packed upper triangle L[36] (index tri(a, b)) of the element Laplacian from corner coordinates X[a][c] in the reference
+// node order: lean closed form of the 2x2x2 rule, diagonal from the zero row sums
+__device__ __forceinline__ void q1_laplace_lean36(const double (&X)[8][3], double (&L)[36]) {
+  constexpr int CX[8] = {0, 0, 1, 1, 0, 1, 1, 0};
+  constexpr int CY[8] = {0, 1, 1, 0, 0, 0, 1, 1};
+  constexpr int CZ[8] = {0, 0, 0, 0, 1, 1, 1, 1};
+  double P[2][2][2][3], Lo[28];
+#pragma unroll
+  for (int a = 0; a < 8; ++a)
+#pragma unroll
+    for (int c = 0; c < 3; ++c) P[CZ[a]][CY[a]][CX[a]][c] = X[a][c];
+  q1_laplace_lean_rolled(P, 1.0 / 512.0, Lo);
+#pragma unroll
+  for (int a = 0; a < 8; ++a) {
+    double d = 0.0;
+#pragma unroll
+    for (int b = 0; b < 8; ++b)
+      if (b != a) d -= q1_sym(Lo, a, b);
+    L[tri(a, a)] = d;
+#pragma unroll
+    for (int b = a + 1; b < 8; ++b) L[tri(a, b)] = Lo[q1_off(a, b)];
+  }
+}
 
 }  // namespace

@@ -1278,3 +1278,26 @@ def test_assembly_emits_jacobi_diagonal(lib, jitter, tile):
             os.environ.pop("PYNAMA_NO_ASM_DINV", None)
             os.environ.pop("PYNAMA_LATTICE_TILE", None)
     assert np.abs(xs[0] - xs[1]).max() <= 1e-13 * np.abs(xs[1]).max()
+
+
+@pytest.mark.parametrize("tile", ["0", "1", "2", "5", "7", "9"])
+def test_march_kernel_shapes_vs_oracle(lib, tile):
+    """every shape of the z-marching general-geometry kernel (PYNAMA_MARCH_TILE: one-wave 7x7 columns, two- to four-wave
+    15x7 / 15x11 / 15x15 columns, rolled and unrolled Gauss loops) against the oracle: boundary columns, partial columns
+    (the mesh is no multiple of any shape), interior Dirichlet nodes, Arhs"""
+    mesh = fo.box_mesh([19, 17, 23], [0, 0, 0], [1.0, 0.9, 1.2], 2, jitter=0.25)
+    rng = np.random.default_rng(17)
+    some = np.unique(np.concatenate([mesh.boundary, rng.choice(mesh.n_node, size=60, replace=False)]))
+    ref = fo.assemble_scalar(mesh, fo.Tables(2, 3), "laplace", dirichlet=some)
+    os.environ["PYNAMA_MARCH_TILE"] = tile
+    os.environ["PYNAMA_MARCH_ZLEN"] = "5"          # several z-chunks per column
+    try:
+        ctx = make_ctx(lib, mesh, 2, bc_ndof=1, bc_nodes=some)
+        A, Arhs = ctx.mat_create(1, 1), ctx.mat_create(1, 1)
+        ctx.assemble_scalar(lib.FORM_LAPLACE, A, Arhs)
+        assert sp_rel_err(mat_to_scipy(ctx, A, 1, 1), ref["A"]) < FP_TOL
+        assert sp_rel_err(mat_to_scipy(ctx, Arhs, 1, 1), ref["Arhs"]) < FP_TOL
+        ctx.close()
+    finally:
+        os.environ.pop("PYNAMA_MARCH_TILE", None)
+        os.environ.pop("PYNAMA_MARCH_ZLEN", None)
