@@ -266,6 +266,13 @@ typedef struct pyn_solve_info {
  * (src/solver/ksp_solver.py:9-19, call site base_problem.py:481). */
 int pyn_solve(pyn_ctx* ctx, int mat_id, int b_vec, int x_vec, const pyn_solve_opts* opts,
               pyn_solve_info* info);
+/* Direct solve of a SMALL system: dense LU with partial pivoting, the factors cached in the matrix until its values change.
+ * Stands for the reference's hard-wired `-ksp_type preonly -pc_type lu` (src/solver/ksp_solver.py:13-16, makefile:7: PETSc
+ * factors at KSPSetUp, every later call is two triangular solves) at the sizes the reference's own tests use it
+ * (src/tests/test_solver.py).  One rank, rows <= pyn_direct_max_rows(); info->iters = 1 and info->reason =
+ * PYN_CONVERGED_ITS as PETSc reports for preonly; info->true_resid as in pyn_solve.  A zero pivot is PYN_EINVAL. */
+int pyn_direct_max_rows(void);
+int pyn_solve_direct(pyn_ctx* ctx, int mat_id, int b_vec, int x_vec, pyn_solve_info* info);
 
 /* ---- timers -------------------------------------------------------------------------------
  * Device time (HIP events on the context stream) of the last call of each phase, in ms.

@@ -103,6 +103,8 @@ SIGNATURES = {
     "pyn_matfree_apply": [_P, _I, _I, _I],
     "pyn_matfree_set": [_P, _I, _D, _D],
     "pyn_solve": [_P, _I, _I, _I, C.POINTER(SolveOpts), C.POINTER(SolveInfo)],
+    "pyn_direct_max_rows": [],
+    "pyn_solve_direct": [_P, _I, _I, _I, C.POINTER(SolveInfo)],
     "pyn_timers_get": [_P, _pf64, _I],
 }
 
@@ -465,6 +467,15 @@ class Context:
                       rtol, atol, dtol)
         info = SolveInfo()
         _check(self.lib.pyn_solve(self.h, mid, b, x, C.byref(o), C.byref(info)))
+        return info
+
+    def direct_max_rows(self):
+        return int(self.lib.pyn_direct_max_rows())
+
+    def solve_direct(self, mid, b, x) -> SolveInfo:
+        """dense LU with partial pivoting (small systems, one rank); the factors stay cached until the matrix changes"""
+        info = SolveInfo()
+        _check(self.lib.pyn_solve_direct(self.h, mid, b, x, C.byref(info)))
         return info
 
     def timers(self):

@@ -177,7 +177,7 @@ int march_print_stamps(pyn_ctx* c, LatArgs& T, int nblk, int ncol, int zlen) {
       T.dbg[((size_t)blockIdx.x * 32 + (l - zc0 + 1)) * 8 + (k)] = __builtin_amdgcn_s_memtime();           \
   } while (0)
 
-template <int TX, int TY, int WPS, bool ROLLED>
+template <int TX, int TY, int WPS, int ROLLED>   // ROLLED: 0 pointwise unrolled, 1 pointwise rolled, 2 sum-factorised
 __global__ void __launch_bounds__((TX + 1) * (TY + 1), WPS) assemble_q1_hex_march_kernel(LatArgs T, int zlen, double ws) {
   using MT = MarchTile<TX, TY>;
   using L1 = LatTile<TX, TY, 1>;
@@ -234,7 +234,8 @@ __global__ void __launch_bounds__((TX + 1) * (TY + 1), WPS) assemble_q1_hex_marc
     const bool act = lvalid && evalid;
     double L[28];
     if (act && !(T.ablate & 1)) {
-      if (ROLLED) q1_laplace_lean_rolled(P, ws, L);   // rolled loop over the Gauss points: one point's worth of registers
+      if (ROLLED == 2) q1_laplace_sumfac(P, ws, L);
+      else if (ROLLED == 1) q1_laplace_lean_rolled(P, ws, L);   // rolled loop over the Gauss points: one point's worth of registers
       else q1_laplace_lean(P, ws, L);
     }
     else {
@@ -314,7 +315,7 @@ __global__ void __launch_bounds__((TX + 1) * (TY + 1), WPS) assemble_q1_hex_marc
   }
 }
 
-template <int TX, int TY, int WPS, bool ROLLED = false>
+template <int TX, int TY, int WPS, int ROLLED = 0>
 int launch_march(pyn_ctx* c, LatArgs& T, int wg_per_cu) {
   using MT = MarchTile<TX, TY>;
   T.ntx = (T.nx + TX - 1) / TX;
@@ -398,7 +399,10 @@ int pyn_assemble_lattice_march(pyn_ctx* c, void* lat_args, int tile) {
     case 9: return launch_march<15, 7, 2, true>(c, T, 3);
     case 10: return launch_march<15, 15, 1, true>(c, T, 1);
     case 11: return launch_march<15, 11, 2, true>(c, T, 2);
+    case 12: return launch_march<7, 7, 2, true>(c, T, 7);   // the default shape with the pointwise (rolled) element routine
+    case 13: return launch_march<15, 7, 2, 2>(c, T, 3);
+    case 14: return launch_march<15, 15, 1, 2>(c, T, 1);
     // one wave per workgroup, 7 workgroups per CU, rolled loop over the Gauss points (224 VGPRs): fastest measured
-    default: return launch_march<7, 7, 2, true>(c, T, 7);
+    default: return launch_march<7, 7, 2, 2>(c, T, 7);
   }
 }

@@ -129,6 +129,7 @@ extern "C" int pyn_ctx_destroy(pyn_ctx* c) {
     (void)hipFree(m.val);
     (void)hipFree(m.sell_val);
     (void)hipFree(m.dinv);
+    m.release_lu();
   }
   pyn_sell_drop_structure(c);
   for (auto& v : c->vecs) (void)hipFree(v.d);
@@ -618,6 +619,7 @@ extern "C" int pyn_mat_destroy(pyn_ctx* c, int id) {
   (void)hipFree(m.val);
   (void)hipFree(m.sell_val);
   (void)hipFree(m.dinv);
+  m.release_lu();
   m = DMat();   // live = false: the handle is dead, its slot is not reused (handles stay stable)
   return PYN_OK;
 }

@@ -1,0 +1,221 @@
+// Direct solve for SMALL systems: dense LU with partial pivoting on the device.
+//
+// The reference's hard-wired default is `-ksp_type preonly -pc_type lu` (src/solver/ksp_solver.py:13-16, makefile:7): PETSc
+// factors K once at KSPSetUp and every solveKLE is two triangular solves.  A sparse direct solver is outside this build's hot
+// path; what the reference's own tests and cases exercise with that default are systems of 10^2..10^3 unknowns (src/tests/
+// test_solver.py: 882, 882 and 1,029 DOFs), and for those a dense factorisation IS a direct solve: block CSR -> dense n x n,
+// right-looking LU with partial pivoting (one pivot search, one row swap, one rank-1 update launch per column), factors cached
+// per matrix version, forward / backward substitution in one workgroup.  n <= PYN_DIRECT_MAX_N (8,192: 512 MB of factors); larger
+// systems take the Krylov substitute of KspSolver (pynama_amd/solver/ksp_solver.py).  One rank only.
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+
+#include "pyn_internal.h"
+
+namespace {
+
+constexpr int64_t PYN_DIRECT_MAX_N = 8192;
+
+__global__ void dense_from_bcsr_kernel(const int32_t* __restrict__ rowptr, const int32_t* __restrict__ colidx, const double* __restrict__ val,
+                                       int64_t n_nodes, int b, double* __restrict__ D, int64_t n) {
+  // one thread per stored scalar entry of node row i: layout val[(rowptr[i]*b + p*len + k)*b + q]
+  for (int64_t i = blockIdx.x; i < n_nodes; i += gridDim.x) {
+    const int lo = rowptr[i], len = rowptr[i + 1] - lo;
+    for (int e = threadIdx.x; e < len * b * b; e += blockDim.x) {
+      const int p = e / (len * b), rem = e - p * len * b, k = rem / b, q = rem - k * b;
+      D[(i * b + p) * n + (int64_t)colidx[lo + k] * b + q] = val[((int64_t)lo * b) * b + e];
+    }
+  }
+}
+
+// pivot of column k: row of the largest |D[i][k]|, i >= k (one workgroup)
+__global__ void __launch_bounds__(256) lu_pivot_kernel(const double* __restrict__ D, int64_t n, int k, int* __restrict__ piv, int* __restrict__ flag) {
+  __shared__ double sv[256];
+  __shared__ int si[256];
+  double best = -1.0;
+  int bi = k;
+  for (int i = k + threadIdx.x; i < n; i += 256) {
+    const double a = fabs(D[(int64_t)i * n + k]);
+    if (a > best) {
+      best = a;
+      bi = i;
+    }
+  }
+  sv[threadIdx.x] = best;
+  si[threadIdx.x] = bi;
+  __syncthreads();
+  for (int s = 128; s > 0; s >>= 1) {
+    if (threadIdx.x < s && (sv[threadIdx.x + s] > sv[threadIdx.x] ||
+                            (sv[threadIdx.x + s] == sv[threadIdx.x] && si[threadIdx.x + s] < si[threadIdx.x]))) {
+      sv[threadIdx.x] = sv[threadIdx.x + s];
+      si[threadIdx.x] = si[threadIdx.x + s];
+    }
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) {
+    piv[k] = si[0];
+    if (!(sv[0] > 0.0)) *flag = k + 1;   // singular (or NaN) column
+  }
+}
+
+__global__ void lu_swap_kernel(double* __restrict__ D, int64_t n, int k, const int* __restrict__ piv) {
+  const int p = piv[k];
+  if (p == k) return;
+  for (int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; j < n; j += (int64_t)gridDim.x * blockDim.x) {
+    const double a = D[(int64_t)k * n + j];
+    D[(int64_t)k * n + j] = D[(int64_t)p * n + j];
+    D[(int64_t)p * n + j] = a;
+  }
+}
+
+// multipliers of column k, stored in place
+__global__ void lu_scale_kernel(double* __restrict__ D, int64_t n, int k) {
+  const double inv = 1.0 / D[(int64_t)k * n + k];
+  for (int64_t i = k + 1 + (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) D[i * n + k] *= inv;
+}
+
+// trailing update D[i][j] -= l_ik D[k][j],  i, j > k  (16 x 16 tiles; a 64-lane wave covers 4 rows x 16 columns)
+__global__ void __launch_bounds__(256) lu_update_kernel(double* __restrict__ D, int64_t n, int k) {
+  const int64_t j = k + 1 + (int64_t)blockIdx.x * 16 + (threadIdx.x & 15);
+  const int64_t i = k + 1 + (int64_t)blockIdx.y * 16 + (threadIdx.x >> 4);
+  if (i >= n || j >= n) return;
+  D[i * n + j] = fma(-D[i * n + k], D[(int64_t)k * n + j], D[i * n + j]);
+}
+
+// the interchanges of the factorisation as one gather: (P b)[i] = b[perm[i]]  (once per factorisation, one thread)
+__global__ void lu_perm_kernel(const int* __restrict__ piv, int n, int* __restrict__ perm) {
+  for (int i = 0; i < n; ++i) perm[i] = i;
+  for (int k = 0; k < n; ++k) {
+    const int p = piv[k];
+    if (p != k) {
+      const int a = perm[k];
+      perm[k] = perm[p];
+      perm[p] = a;
+    }
+  }
+}
+
+// x = U^-1 L^-1 P b in one workgroup of 1,024 threads (n <= 8,192: at most 8 rows per thread)
+__global__ void __launch_bounds__(1024) lu_solve_kernel(const double* __restrict__ D, const int* __restrict__ perm, int64_t n, const double* __restrict__ b,
+                                                        double* __restrict__ x, double* __restrict__ w) {
+  const int t = threadIdx.x;
+  for (int64_t i = t; i < n; i += 1024) w[i] = b[perm[i]];
+  __syncthreads();
+  for (int64_t k = 0; k < n; ++k) {     // forward: unit lower triangle
+    const double wk = w[k];
+    for (int64_t i = k + 1 + t; i < n; i += 1024) w[i] = fma(-D[i * n + k], wk, w[i]);
+    __syncthreads();
+  }
+  for (int64_t k = n - 1; k >= 0; --k) {   // backward
+    if (t == 0) w[k] /= D[k * n + k];
+    __syncthreads();
+    const double wk = w[k];
+    for (int64_t i = t; i < k; i += 1024) w[i] = fma(-D[i * n + k], wk, w[i]);
+    __syncthreads();
+  }
+  for (int64_t i = t; i < n; i += 1024) x[i] = w[i];
+}
+
+// out[0] = ||b - w||^2, out[1] = ||b||^2 (one workgroup)
+__global__ void __launch_bounds__(1024) direct_resid_kernel(const double* __restrict__ w, const double* __restrict__ b, int64_t n, double* __restrict__ out) {
+  __shared__ double sr[1024], sb[1024];
+  double r = 0.0, q = 0.0;
+  for (int64_t i = threadIdx.x; i < n; i += 1024) {
+    const double d = b[i] - w[i];
+    r = fma(d, d, r);
+    q = fma(b[i], b[i], q);
+  }
+  sr[threadIdx.x] = r;
+  sb[threadIdx.x] = q;
+  __syncthreads();
+  for (int s = 512; s > 0; s >>= 1) {
+    if (threadIdx.x < s) {
+      sr[threadIdx.x] += sr[threadIdx.x + s];
+      sb[threadIdx.x] += sb[threadIdx.x + s];
+    }
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) {
+    out[0] = sr[0];
+    out[1] = sb[0];
+  }
+}
+
+}  // namespace
+
+// factors of A, cached in the matrix until its values change
+static int direct_factor(pyn_ctx* c, DMat& A) {
+  const int64_t n = c->n_owned * A.br;
+  if (A.lu_valid && A.lu_n == n) return PYN_OK;
+  if (A.lu_n != n) A.release_lu();
+  if (!A.lu) PYN_HIP(hipMalloc((void**)&A.lu, (size_t)n * n * sizeof(double)));
+  if (!A.lu_piv) PYN_HIP(hipMalloc((void**)&A.lu_piv, (size_t)(2 * n + 1) * sizeof(int)));
+  A.lu_n = n;
+  hipStream_t s = c->stream;
+  PYN_HIP(hipMemsetAsync(A.lu, 0, (size_t)n * n * sizeof(double), s));
+  int* flag = A.lu_piv + n;
+  PYN_HIP(hipMemsetAsync(flag, 0, sizeof(int), s));
+  dense_from_bcsr_kernel<<<(int)std::min<int64_t>(c->n_owned, 4096), 256, 0, s>>>(c->d_rowptr, c->d_colidx, A.val, c->n_owned, A.br, A.lu, n);
+  for (int k = 0; k < (int)n; ++k) {
+    lu_pivot_kernel<<<1, 256, 0, s>>>(A.lu, n, k, A.lu_piv, flag);
+    lu_swap_kernel<<<(int)((n + 255) / 256), 256, 0, s>>>(A.lu, n, k, A.lu_piv);
+    const int m = (int)(n - k - 1);
+    if (m > 0) {
+      lu_scale_kernel<<<(m + 255) / 256, 256, 0, s>>>(A.lu, n, k);
+      lu_update_kernel<<<dim3((m + 15) / 16, (m + 15) / 16), 256, 0, s>>>(A.lu, n, k);
+    }
+  }
+  lu_perm_kernel<<<1, 1, 0, s>>>(A.lu_piv, (int)n, A.lu_piv + n + 1);
+  int h = 0;
+  PYN_HIP(hipMemcpyAsync(&h, flag, sizeof(int), hipMemcpyDeviceToHost, s));
+  PYN_HIP(hipStreamSynchronize(s));
+  PYN_HIP(hipGetLastError());
+  PYN_CHECK(h == 0, "direct solve: zero pivot in column %d of %lld (the matrix is singular)", h - 1, (long long)n);
+  A.lu_valid = true;
+  return PYN_OK;
+}
+
+extern "C" int pyn_direct_max_rows(void) { return (int)PYN_DIRECT_MAX_N; }
+
+extern "C" int pyn_solve_direct(pyn_ctx* c, int mat_id, int bv, int xv, pyn_solve_info* info) {
+  PYN_TRY(pyn_check_mat(c, mat_id, "pyn_solve_direct"));
+  PYN_TRY(pyn_check_vec(c, bv, "pyn_solve_direct b"));
+  PYN_TRY(pyn_check_vec(c, xv, "pyn_solve_direct x"));
+  PYN_CHECK(info, "NULL argument");
+  PYN_CHECK(bv != xv, "b and x must differ");
+  DMat& A = c->mats[mat_id];
+  PYN_CHECK(A.br == A.bc, "matrix must be square");
+  PYN_CHECK(c->vecs[bv].bs == A.br && c->vecs[xv].bs == A.br, "vector block size mismatch");
+  PYN_CHECK(c->nranks == 1 && c->n_ghost == 0, "the dense direct solve runs on one rank");
+  const int64_t n = c->n_owned * A.br;
+  PYN_CHECK(n <= PYN_DIRECT_MAX_N, "direct solve: %lld rows exceed the dense limit of %lld (use the Krylov solvers)", (long long)n,
+            (long long)PYN_DIRECT_MAX_N);
+  PYN_HIP(hipSetDevice(c->device));
+  memset(info, 0, sizeof(*info));
+  PYN_HIP(hipEventRecord(c->ev0, c->stream));
+  PYN_TRY(direct_factor(c, A));
+  PYN_TRY(pyn_ensure_work(c, (size_t)2 * n * sizeof(double)));
+  double* b = c->vecs[bv].d;
+  double* x = c->vecs[xv].d;
+  lu_solve_kernel<<<1, 1024, 0, c->stream>>>(A.lu, A.lu_piv + n + 1, n, b, x, c->d_work);
+  PYN_HIP(hipEventRecord(c->ev1, c->stream));
+  // true residual through the sparse matrix
+  double* w = c->d_work + n;
+  PYN_TRY(pyn_spmv_raw(c, A, x, w));
+  direct_resid_kernel<<<1, 1024, 0, c->stream>>>(w, b, n, c->d_scal);
+  PYN_HIP(hipMemcpyAsync(c->h_scal, c->d_scal, 2 * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+  PYN_HIP(hipStreamSynchronize(c->stream));
+  PYN_HIP(hipGetLastError());
+  const double rr = c->h_scal[0], bb = c->h_scal[1];
+  float ms = 0;
+  PYN_HIP(hipEventElapsedTime(&ms, c->ev0, c->ev1));
+  info->solve_ms = ms;
+  info->iters = 1;                       // PETSc reports one "iteration" for preonly
+  info->true_resid = bb > 0 ? sqrt(rr / bb) : sqrt(rr);
+  info->rnorm = sqrt(rr);
+  info->rnorm0 = sqrt(bb);
+  info->reason = (info->true_resid == info->true_resid) ? PYN_CONVERGED_ITS : PYN_DIVERGED_NANORINF;
+  c->timers[PYN_T_SOLVE] = ms;
+  return PYN_OK;
+}

@@ -82,8 +82,20 @@ struct DMat {
   bool sell_valid = false;
   double* dinv = nullptr;      // 1 / diagonal per scalar row (Jacobi), written by the lattice assemblies in their store
   bool dinv_valid = false;     // phase, else extracted once per matrix version (pyn_dinv_ensure)
+  double* lu = nullptr;        // dense LU factors of small systems (pyn_direct.hip), [n][n] row-major, multipliers in place
+  int* lu_piv = nullptr;       // [n] row interchanges + [1] singular-column flag + [n] the same as a gather
+  int64_t lu_n = 0;            // order the two buffers were sized for
+  bool lu_valid = false;
   bool live = false;
-  void touch() { sell_valid = dinv_valid = false; }   // the values are about to change
+  void touch() { sell_valid = dinv_valid = lu_valid = false; }   // the values are about to change
+  void release_lu() {
+    (void)hipFree(lu);
+    (void)hipFree(lu_piv);
+    lu = nullptr;
+    lu_piv = nullptr;
+    lu_n = 0;
+    lu_valid = false;
+  }
 };
 
 struct PatchPlan {

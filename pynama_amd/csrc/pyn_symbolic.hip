@@ -39,6 +39,7 @@ static int pyn_symbolic_reset_dependents(pyn_ctx* c) {
     (void)hipFree(m.val);
     (void)hipFree(m.sell_val);
     (void)hipFree(m.dinv);
+    m.release_lu();
   }
   c->mats.clear();
   pyn_sell_drop_structure(c);

@@ -11,8 +11,11 @@ Mirrors ``src/solver/ksp_solver.py:6-19`` (``KspSolver(KSP)``: ``createSolver(ma
 with the matrix-free form of the operator when the matrix carries one (``Mat.K`` on structured Q1 hex meshes) -- the
 assembled matrix then only supplies the Jacobi diagonal and the exit check; the library verifies that both agree.
 
-The reference's hard-wired default is ``preonly`` + ``lu`` (:13-16).  There is no sparse direct
-solver on the device path: that combination is served by a Krylov solve driven to round-off --
+The reference's hard-wired default is ``preonly`` + ``lu`` (:13-16).  Systems of up to ``-pynama_direct_max_rows`` rows
+(default 4096; one rank) ARE solved directly: ``pyn_solve_direct`` factors the matrix densely with partial pivoting once
+per matrix version and every call is two triangular solves -- the sizes at which the reference's own tests use the default
+(src/tests/test_solver.py: 882 .. 1,029 unknowns).  There is no sparse direct solver on the device path: above that size
+(or on several ranks) the combination is served by a Krylov solve driven to round-off --
 Jacobi-PCG (rtol 1e-14 on the recurrence residual, the true residual checked at exit) when a
 symmetry probe of the operator passes (``v'Au == u'Av`` on two random vectors, once per operator),
 GMRES(30)+Jacobi otherwise or when PCG breaks down (an indefinite operator, e.g. ``K + Kfs`` with its
@@ -42,6 +45,7 @@ class KspSolver(object):
         self.gmres_orthog = 1            # KSPGMRES default: classical Gram-Schmidt, refine_never
         self.norm_type = "preconditioned"
         self.mat_free = False
+        self.direct_max_rows = 4096      # preonly/lu: dense LU up to this many rows, the Krylov substitute above
         self.info = None
         self._symmetric = None
 
@@ -73,6 +77,7 @@ class KspSolver(object):
         self.restart = o.getInt('ksp_gmres_restart', self.restart)
         self.norm_type = o.getString('ksp_norm_type', self.norm_type)
         self.mat_free = o.hasName('pynama_mat_free') and str(o.getString('pynama_mat_free', '1')).lower() not in ('0', 'false', 'no')
+        self.direct_max_rows = o.getInt('pynama_direct_max_rows', self.direct_max_rows)
         if o.hasName('ksp_gmres_modifiedgramschmidt'):
             self.gmres_orthog = 2
         else:
@@ -126,7 +131,14 @@ class KspSolver(object):
             if tag is None:
                 raise ValueError("-pynama_mat_free: this operator has no matrix-free form (structured Q1 hex meshes only)")
             mf = tag
-        if self.ksp_type == 'preonly':
+        n_rows = ctx.n_owned * A.br
+        if (self.ksp_type == 'preonly' and not self.mat_free and A.br == A.bc and ctx.nranks == 1 and ctx.n_ghost == 0
+                and n_rows <= min(self.direct_max_rows, ctx.direct_max_rows())):
+            info = ctx.solve_direct(A.id, b.id, x.id)          # raises on a zero pivot
+            if info.reason < 0 or not (info.true_resid <= 1e-8):
+                raise RuntimeError(f"preonly/lu: dense LU of {n_rows} rows left a true residual of {info.true_resid:.3e} "
+                                   "(the matrix is singular to working precision)")
+        elif self.ksp_type == 'preonly':
             if getattr(self, "_symmetric", None) is None:
                 self._symmetric = A.br == A.bc and self._probe_symmetry(A)
             info = None

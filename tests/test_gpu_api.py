@@ -323,6 +323,7 @@ def test_preonly_lu_on_a_nonsymmetric_operator_falls_back_to_gmres():
     b.setArray(rng.standard_normal(K.ctx.n_owned * K.br))
     ksp = KspSolver()
     ksp.createSolver(K, fem.comm)
+    ksp.direct_max_rows = 0                                # the path systems above the dense-LU limit take
     info = ksp(b, x)
     assert ksp._symmetric is False and info.reason > 0 and info.true_resid < 1e-10
     want = spla.spsolve(A, b.getArray())
@@ -343,8 +344,73 @@ def test_preonly_lu_raises_when_it_cannot_solve():
     ksp = KspSolver()
     ksp.createSolver(K, fem.comm)
     ksp.max_it = 2000
+    ksp.direct_max_rows = 0
     with pytest.raises(RuntimeError, match="preonly/lu substitute failed"):
         ksp(b, x)
+    ksp.direct_max_rows = 4096                             # the dense LU meets a zero pivot
+    with pytest.raises(Exception, match="zero pivot|singular"):
+        ksp(b, x)
+
+
+def test_preonly_lu_direct_on_small_systems():
+    """the reference default on the sizes its tests use it (test_solver.py): a DIRECT solve, dense LU with partial pivoting --
+    nonsymmetric and indefinite operators with zero diagonal entries included; answer = scipy's sparse LU; the factors are
+    reused until the matrix changes"""
+    import scipy.sparse.linalg as spla
+    from pynama_amd.solver.ksp_solver import KspSolver
+    from pynama_amd.vectors import Vec
+    fem = setFemProblem('uniform', lower=[0, 0, 0], upper=[1, 1, 1], nelem=[5, 4, 3], ngl=2, jitter=0.2)
+    K = fem.mat.K
+    ctx = K.ctx
+    n = ctx.n_owned * K.br
+    rng = np.random.default_rng(5)
+    d = Vec(ctx, K.br)
+    d.setArray(rng.uniform(0.5, 2.0, n) * rng.choice([-1.0, 1.0], n))
+    K.diagonalScale(L=d)                                   # nonsymmetric, indefinite
+    A0 = K.toScipy().tocsr()
+    A0.eliminate_zeros()
+    i = int(np.argmax(np.diff(A0.indptr)))                 # a row of an interior node (not an identity row of the Dirichlet set)
+    K.setValue(i, i, -A0[i, i], addv=True)                 # one diagonal entry cancelled: elimination without pivoting breaks
+    K.assemble()
+    A = K.toScipy().tocsc()
+    assert abs(A[i, i]) < 1e-14 and abs(A - A.T).max() > 1e-3
+    b, x = K.createVecLeft(), K.createVecRight()
+    ksp = KspSolver()
+    ksp.createSolver(K, fem.comm)
+    lu = spla.splu(A)
+    for trial in range(3):
+        b.setArray(rng.standard_normal(n))
+        info = ksp(b, x)
+        want = lu.solve(b.getArray())
+        assert info.iters == 1 and info.reason > 0 and info.true_resid < 1e-12, (info.iters, info.reason, info.true_resid)
+        assert np.abs(x.getArray() - want).max() < 1e-10 * np.abs(want).max()
+    # a changed matrix is factored again
+    K.setValue(i, i, A0[i, i], addv=True)                  # (the diagonal entry back: the Jacobi substitute below needs it)
+    K.diagonalScale(L=d)
+    A = K.toScipy().tocsc()
+    info = ksp(b, x)
+    want = spla.spsolve(A, b.getArray())
+    assert np.abs(x.getArray() - want).max() < 1e-10 * np.abs(want).max()
+    # above the limit the library refuses; KspSolver then takes the Krylov substitute
+    ksp.direct_max_rows = 10
+    info = ksp(b, x)
+    assert info.iters > 1
+
+
+def test_solve_direct_abi_checks():
+    from pynama_amd import _lib
+    fem = setFemProblem('uniform', nelem=[3, 3], ngl=3)
+    K = fem.mat.K
+    b, x = K.createVecLeft(), K.createVecRight()
+    b.set(1.0)
+    with pytest.raises(_lib.PynamaHipError, match="differ"):
+        K.ctx.solve_direct(K.id, b.id, b.id)
+    assert K.ctx.direct_max_rows() == 8192
+    info = K.ctx.solve_direct(K.id, b.id, x.id)
+    assert info.true_resid < 1e-13
+    y = K.createVecLeft()
+    K.mult(x, y)
+    assert np.abs(y.getArray() - 1.0).max() < 1e-12
 
 
 def test_reference_style_cell_loop_through_setValues():

@@ -1280,7 +1280,7 @@ def test_assembly_emits_jacobi_diagonal(lib, jitter, tile):
     assert np.abs(xs[0] - xs[1]).max() <= 1e-13 * np.abs(xs[1]).max()
 
 
-@pytest.mark.parametrize("tile", ["0", "1", "2", "5", "7", "9"])
+@pytest.mark.parametrize("tile", ["0", "1", "2", "5", "7", "9", "12", "13", "14"])
 def test_march_kernel_shapes_vs_oracle(lib, tile):
     """every shape of the z-marching general-geometry kernel (PYNAMA_MARCH_TILE: one-wave 7x7 columns, two- to four-wave
     15x7 / 15x11 / 15x15 columns, rolled and unrolled Gauss loops) against the oracle: boundary columns, partial columns
