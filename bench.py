@@ -160,10 +160,11 @@ def general_geometry_leg(_lib, DMPlexDom, Spectral, n, traffic, reps=5):
     B_asm, _, _ = algorithmic_bytes(n ** 3, (n + 1) ** 3, nnz)
     kern = "assemble_q1_hex_march_kernel"
     tb, src = traffic.get(kern)
-    out = roofline(kern + " (z-marching quadrature path: lean closed form of the 2x2x2 rule per element, LDS rows, x-line stores)",
+    out = roofline(kern + " (z-marching quadrature path: sum-factorised closed form of the 2x2x2 rule per element, LDS rows, x-line stores)",
                    B_asm, med, min_ms=best, element_dofs_per_s=n ** 3 * 8 / (med * 1e-3), traffic=tb, traffic_source=src,
                    mesh=f"{n}^3 Q1 hex, nodes jittered by 0.2 h (general geometry, every element integrated with 8 Gauss points)",
-                   bound_note="FP64 VALU: about 1,770 FP64 instructions per element against 387 B of compulsory traffic")
+                   bound_note="FP64 VALU and the store path together: about 1,050 FP64 instructions per element (1.31 elements integrated per "
+                              "element of the mesh) against 387 B of compulsory traffic; VALU alone 0.57 ms, stores alone 0.76 ms (DESIGN.md 5b)")
     ctx.close()
     return out
 
@@ -217,6 +218,10 @@ def config_kle(_lib, DMPlexDom, Spectral, n, cg_iters, jitter=0.0):
     med, best = median_assembly(ctx, lambda: ctx.assemble_kle(1e3, 1e2, K, Krhs, Rw, -1), 3)
     B_asm1, B_spmv, B_cg = algorithmic_bytes(n ** 3, n_rows, nnz, ndof=3)
     B_asm = 3 * B_asm1                      # three block matrices leave the assembly: K, Krhs, Rw (4.46 GB each)
+    # ... of which the timed calls do not write Krhs again where it is known to be zero (rows away from imposed nodes: the matrix was
+    # assembled for the same Dirichlet set by the warm-up call); the fraction on the bytes that DO move is reported next to the model's
+    n_bnd_nodes = int(bm[:dom.nOwned].astype(bool).sum())
+    B_moved = 2 * B_asm1 + 8.0 * 9 * 27 * 8 * n_bnd_nodes    # K and Rw in full; Krhs: about the 3x3x3 tiles that touch the boundary
     vel = np.zeros((dom.nOwned, 3))
     vel[bm[:dom.nOwned] != 0] = [1.0, 0.0, 0.0]
     vv, vr, vx = ctx.vec_create(3), ctx.vec_create(3), ctx.vec_create(3)
@@ -231,6 +236,10 @@ def config_kle(_lib, DMPlexDom, Spectral, n, cg_iters, jitter=0.0):
            "n_dof": 3 * n_rows, "nnz_blocks": nnz, "assembly_ms_K_Krhs_Rw": med,
            "element_dofs_per_s": n ** 3 * 24 / (med * 1e-3),
            "assembly_frac_of_hbm_peak": B_asm / (med * 1e-3) / 1e9 / HBM_PEAK_GBS,
+           "assembly_frac_on_bytes_moved": B_moved / (med * 1e-3) / 1e9 / HBM_PEAK_GBS,
+           "assembly_note": "assembly_frac_of_hbm_peak uses SURVEY.md 8d's model (three block matrices written once each = "
+                            f"{B_asm / 1e9:.2f} GB); the timed calls leave the zero blocks of Krhs unwritten (same Dirichlet set as the "
+                            f"warm-up call), about {B_moved / 1e9:.2f} GB move",
            "kernel": "assemble_q1_hex_kle_lattice_kernel (four waves per tile; "
                      + ("general geometry: closed form of the 2x2x2 rule, Gauss points split over the waves for K, node columns for Rw)"
                         if jitter else "closed-form blocks on parallelepipeds)"),

@@ -331,6 +331,9 @@ class Context:
         _check(self.lib.pyn_mat_get_values(self.h, mid, v))
         return v
 
+    def mat_zero(self, mid):
+        _check(self.lib.pyn_mat_zero(self.h, mid))
+
     def mat_axpy(self, y, a, x):
         _check(self.lib.pyn_mat_axpy(self.h, y, a, x))
 

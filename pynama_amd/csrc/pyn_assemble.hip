@@ -1023,6 +1023,14 @@ int launch_generic(pyn_ctx* c, AsmArgs& A, int64_t n_work) {
 int pyn_assemble_q1_tiled(pyn_ctx* c, int form, double alpha_d, double alpha_w, double* K, double* Krhs, double* Rw,
                           double* Rd, bool* handled);
 
+// Does the imposed-column matrix `id` already hold zeros wherever the current Dirichlet set leaves zeros (DMat::rhs_clean)?  Read
+// BEFORE mat_ptr marks the matrix as changing.
+static bool rhs_is_clean(pyn_ctx* c, int id) {
+  if (id < 0 || id >= (int)c->mats.size() || !c->mats[id].live || getenv("PYNAMA_RHS_FULL_WRITE")) return false;
+  const int64_t s = c->mats[id].rhs_clean;
+  return s == PYN_RHS_ANY || s == c->bc_stamp;
+}
+
 static int mat_ptr(pyn_ctx* c, int id, int br, int bc, const char* name, double** out) {
   *out = nullptr;
   if (id < 0) return PYN_OK;
@@ -1090,11 +1098,15 @@ extern "C" int pyn_assemble_kle(pyn_ctx* c, double alpha_d, double alpha_w, int 
   PYN_HIP(hipSetDevice(c->device));
   const int dim = c->dim, dw = dim == 2 ? 1 : 3;
   double *pK, *pKr, *pRw, *pRd;
+  c->asm_rhs_clean = Krhs != K && rhs_is_clean(c, Krhs);
   PYN_TRY(mat_ptr(c, K, dim, dim, "K", &pK));
   PYN_TRY(mat_ptr(c, Krhs, dim, dim, "Krhs", &pKr));
   PYN_TRY(mat_ptr(c, Rw, dim, dw, "Rw", &pRw));
   PYN_TRY(mat_ptr(c, Rd, dim, 1, "Rd", &pRd));
-  return run_assembly(c, PYN_FORM_KLE, alpha_d, alpha_w, pK, pKr, pRw, pRd, variant);
+  const int rc = run_assembly(c, PYN_FORM_KLE, alpha_d, alpha_w, pK, pKr, pRw, pRd, variant);
+  c->asm_rhs_clean = false;
+  if (rc == PYN_OK && pKr && pK) c->mats[Krhs].rhs_clean = c->bc_stamp;   // exactly the imposed-column matrix of this Dirichlet set
+  return rc;
 }
 
 extern "C" int pyn_assemble_kle_noslip(pyn_ctx* c, double alpha_d, double alpha_w, const int* mat_ids /*[8]*/) {
@@ -1141,6 +1153,7 @@ extern "C" int pyn_assemble_scalar(pyn_ctx* c, int form, int Aid, int Arhs, int 
   PYN_CHECK(form == PYN_FORM_LAPLACE || form == PYN_FORM_MASS_NODAL || form == PYN_FORM_MASS_FULL, "bad scalar form");
   PYN_HIP(hipSetDevice(c->device));
   double *pA, *pAr;
+  c->asm_rhs_clean = Arhs != Aid && rhs_is_clean(c, Arhs);
   PYN_TRY(mat_ptr(c, Aid, 1, 1, "A", &pA));
   PYN_TRY(mat_ptr(c, Arhs, 1, 1, "Arhs", &pAr));
   // the Jacobi data of A: kernels that see whole rows (lattice store phases) write 1 / diagonal on the way out
@@ -1154,6 +1167,8 @@ extern "C" int pyn_assemble_scalar(pyn_ctx* c, int form, int Aid, int Arhs, int 
   const int rc = run_assembly(c, form, 0.0, 0.0, pA, pAr, nullptr, nullptr, variant);
   if (rc == PYN_OK && c->asm_dinv && c->asm_dinv_written) c->mats[Aid].dinv_valid = true;
   c->asm_dinv = nullptr;
+  c->asm_rhs_clean = false;
+  if (rc == PYN_OK && pAr && pA) c->mats[Arhs].rhs_clean = c->bc_stamp;
   return rc;
 }
 

@@ -1175,7 +1175,7 @@ __global__ void __launch_bounds__(256, GEN ? 2 : 3) assemble_q1_hex_kle_lattice_
       const int64_t base = (int64_t)rlo[l * TX] * 9;
       for (int i = lane; i < LINE; i += 64) {
         outA[base + i] = acc[l * LINE + i];
-        if (!RW && outR) outR[base + i] = 0.0;
+        if (!RW && outR && !L.rhs_clean) outR[base + i] = 0.0;
       }
     }
     return;
@@ -1376,6 +1376,7 @@ static int lat_fill_args(pyn_ctx* c, LatArgs& T, double* A, double* Arhs, int* m
   T.A = A;
   T.Arhs = Arhs;
   T.dinv = nullptr;
+  T.rhs_clean = c->asm_rhs_clean ? 1 : 0;
   const char* ab = getenv("PYNAMA_LATTICE_ABLATE");  // diagnostics: 1 = no element phase, 4 = no plain-tile store path
   T.ablate = ab ? atoi(ab) : 0;
   T.lean = c->q1_gauss_standard && !getenv("PYNAMA_NO_LEAN") ? 1 : 0;

@@ -606,6 +606,7 @@ extern "C" int pyn_mat_create(pyn_ctx* c, int br, int bc, int* mat_id) {
   size_t n = (size_t)c->nnzb * br * bc;
   PYN_HIP(hipMalloc((void**)&m.val, n * sizeof(double)));
   PYN_HIP(hipMemsetAsync(m.val, 0, n * sizeof(double), c->stream));
+  m.rhs_clean = PYN_RHS_ANY;
   m.live = true;
   c->mats.push_back(m);
   *mat_id = (int)c->mats.size() - 1;
@@ -686,6 +687,7 @@ extern "C" int pyn_mat_zero(pyn_ctx* c, int id) {
   DMat& m = c->mats[id];
   PYN_HIP(hipMemsetAsync(m.val, 0, (size_t)c->nnzb * m.br * m.bc * sizeof(double), c->stream));
   m.touch();
+  m.rhs_clean = PYN_RHS_ANY;
   return PYN_OK;
 }
 

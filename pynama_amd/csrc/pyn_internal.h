@@ -86,8 +86,15 @@ struct DMat {
   int* lu_piv = nullptr;       // [n] row interchanges + [1] singular-column flag + [n] the same as a gather
   int64_t lu_n = 0;            // order the two buffers were sized for
   bool lu_valid = false;
+  // "imposed-column" matrices (Krhs / Arhs of an assembly) are zero except in rows next to imposed nodes.  rhs_clean records for
+  // which Dirichlet set (pyn_ctx::bc_stamp) the stored values are known to be exactly that matrix -- or all zero (PYN_RHS_ANY: a fresh
+  // or zeroed matrix fits every set); the lattice kernels then leave the zero blocks of tiles without imposed nodes unwritten.
+  int64_t rhs_clean = -2;      // PYN_RHS_UNKNOWN
   bool live = false;
-  void touch() { sell_valid = dinv_valid = lu_valid = false; }   // the values are about to change
+  void touch() {               // the values are about to change
+    sell_valid = dinv_valid = lu_valid = false;
+    rhs_clean = -2;
+  }
   void release_lu() {
     (void)hipFree(lu);
     (void)hipFree(lu_piv);
@@ -134,6 +141,7 @@ struct DVec {
   bool live = false;
 };
 
+constexpr int64_t PYN_RHS_UNKNOWN = -2, PYN_RHS_ANY = -1;   // DMat::rhs_clean
 constexpr int PYN_MAX_PARTIALS = 2048;  // grid cap of every reducing kernel
 
 struct pyn_ctx {
@@ -215,6 +223,7 @@ struct pyn_ctx {
   // 1/diagonal target of the scalar assembly in flight (the K matrix's DMat::dinv) and whether a kernel filled it
   double* asm_dinv = nullptr;
   bool asm_dinv_written = false;
+  bool asm_rhs_clean = false;   // the Krhs / Arhs target of the assembly in flight holds zeros wherever this Dirichlet set leaves zeros
   // element-local scratch for pyn_elem_local
   double* d_eloc = nullptr;
   size_t eloc_bytes = 0;

@@ -36,6 +36,8 @@ struct LatArgs {
   double* A;
   double* Arhs;
   double* dinv = nullptr;              // 1 / diagonal per owned row, written with the rows (may be null)
+  int rhs_clean = 0;                   // Arhs already holds zeros wherever this Dirichlet set leaves zeros (DMat::rhs_clean): tiles without
+                                       // an imposed node in their node box do not write their (all-zero) Arhs rows again
   unsigned long long* dbg = nullptr;   // diagnostics (PYNAMA_MARCH_STAMPS): per-phase s_memtime stamps of the marching kernels
 };
 
@@ -293,7 +295,7 @@ __device__ __forceinline__ void lat_store_plain(const LatArgs& T, double* acc, c
       const int i = lane + 64 * j;
       if (i < LINE) {
         outA[base + i] = v[j];
-        if (outR) outR[base + i] = 0.0;
+        if (outR && !T.rhs_clean) outR[base + i] = 0.0;
       }
     }
   }

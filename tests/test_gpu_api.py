@@ -453,6 +453,11 @@ def test_reference_style_cell_loop_through_setValues():
     # a new nonzero outside the graph is an error, not a silent drop
     with pytest.raises(Exception, match="outside the node graph"):
         loop.mat.K.setValues([0], [2 * (loop.dom.ctx.n_owned - 1)], [1.0], addv=True)
+    # Mat.zeroEntries (PETSc's MatZeroEntries: the pattern stays, the values go)
+    loop.mat.Rw.zeroEntries()
+    assert abs(loop.mat.Rw.toScipy()).max() == 0.0
+    loop.mat.Rw.setValue(0, 0, 2.5, addv=True)
+    assert loop.mat.Rw.toScipy()[0, 0] == 2.5
 
 
 @pytest.mark.parametrize("nelem,upper,ngl", [([5, 4], [1.0, 0.8], 3), ([5, 4], [1.0, 0.8], 5), ([3, 3, 2], [1.0, 0.8, 1.2], 3)])

@@ -1301,3 +1301,59 @@ def test_march_kernel_shapes_vs_oracle(lib, tile):
     finally:
         os.environ.pop("PYNAMA_MARCH_TILE", None)
         os.environ.pop("PYNAMA_MARCH_ZLEN", None)
+
+
+@pytest.mark.parametrize("form", ["kle", "scalar_uniform", "scalar_jitter"])
+def test_imposed_column_matrices_rewritten_only_where_needed(lib, form):
+    """Krhs / Arhs are zero except next to imposed nodes; the lattice kernels leave the zero rows of tiles without imposed nodes
+    unwritten when the matrix is known to hold zeros there (fresh / zeroed matrix, or the last assembly used the same Dirichlet
+    set: DMat::rhs_clean).  Every sequence that could leave stale entries behind -- another Dirichlet set, values added behind the
+    library's back through the ABI, a matrix that served another purpose -- must still end in exactly the generic kernel's matrix."""
+    kle = form == "kle"
+    nd = 3 if kle else 1
+    mesh = fo.box_mesh([14, 12, 13], [0, 0, 0], [1.0, 0.9, 1.1], 2, jitter=0.2 if form == "scalar_jitter" else 0.0)
+    rng = np.random.default_rng(23)
+    setA = np.zeros((mesh.n_node, nd), np.uint8)
+    setA[mesh.boundary] = 1
+    setB = np.zeros((mesh.n_node, nd), np.uint8)
+    setB[rng.choice(mesh.n_node, size=40, replace=False)] = 1
+    ctx = make_ctx(lib, mesh, 2)
+    assert ctx.mesh_topology()[0] == "lattice"
+    M, Mr, G, Gr = (ctx.mat_create(nd, nd) for _ in range(4))
+    W = ctx.mat_create(3, 3) if kle else -1
+
+    def assemble(main, rhs, variant):
+        if kle:
+            ctx.assemble_kle(1e3, 1e2, main, rhs, W if variant else -1, -1, variant=variant)
+        else:
+            ctx.assemble_scalar(lib.FORM_LAPLACE, main, rhs, variant=variant)
+
+    def check(tag):
+        assemble(M, Mr, 1)                          # lattice kernels
+        assemble(G, Gr, 0)                          # generic kernel: zero fill + atomics
+        a, b = ctx.mat_values(Mr, nd, nd), ctx.mat_values(Gr, nd, nd)
+        assert np.abs(a - b).max() <= FP_TOL * np.abs(b).max(), tag
+        a, b = ctx.mat_values(M, nd, nd), ctx.mat_values(G, nd, nd)
+        assert np.abs(a - b).max() <= FP_TOL * np.abs(b).max(), tag
+
+    ctx.bc_set(nd, setA)
+    check("fresh matrix")
+    check("same Dirichlet set again")
+    ctx.bc_set(nd, setB)
+    check("another Dirichlet set: the entries next to the old one must go")
+    ctx.bc_set(nd, setA)
+    check("back to the first set")
+    ctx.mat_axpy(Mr, 1.0, M)                        # the matrix served another purpose
+    check("after mat_axpy")
+    n = mesh.n_node * nd
+    mid = (n // 2 // nd) * nd
+    ctx.mat_add_values(Mr, [mid], [mid], [[3.0]], insert=False)   # an entry in the middle of the box
+    check("after host insertion")
+    ctx.mat_zero(Mr)
+    check("after mat_zero")
+    os.environ["PYNAMA_RHS_FULL_WRITE"] = "1"
+    try:
+        check("full write forced")
+    finally:
+        del os.environ["PYNAMA_RHS_FULL_WRITE"]
+    ctx.close()
