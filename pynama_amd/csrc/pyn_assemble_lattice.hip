@@ -601,6 +601,8 @@ struct KleLatArgs {
   LatArgs L;              // A = K or Rw, Arhs = Krhs (K only, may be null); bcmask per DOF (3 per node)
   double alpha_d, alpha_w;
   const double *wr, *hrsr, *Hr, *hcoor;   // reduced (centroid) rule
+  const double* Lel = nullptr;            // general geometry, K: [28][ne] off-diagonal element Laplacians (kle_elem_laplace_kernel)
+  int64_t ne = 0;                         // elements of this rank's lattice (nx-1)(ny-1)(npl-1)
 };
 
 // ---- matrix-free KLE operator: y = K x (3 DOFs per node) without the assembled matrix --------------------------------
@@ -889,18 +891,14 @@ __device__ __forceinline__ void kle_lat_rows(const KleLatArgs& T, const double (
   }
 }
 
-// General geometry (any trilinear hexahedron): the same block formulas with the element quantities from the lean closed form of
-// the 2x2x2 rule (pyn_q1_hex.h) instead of the parallelepiped integrals --
+// General geometry (any trilinear hexahedron): the same block formulas with the element quantities from the closed forms of the
+// 2x2x2 rule (pyn_q1_hex.h) instead of the parallelepiped integrals --
 //   L_ab    = sum_g (w_g / 512) / det'_g  g_g[a] . g_g[b],                g = adj(J') h  (unnormalised gradients, G = g / det')
 //   T_m[ab] = sum_g w_g detJ_g H_a(g) G_mb(g) = (1 / 4096) sum_g N'_a(g) g_g,m[b]      (the determinant cancels)
 //   Gr      = adj(J'_0) s / det'_0,  c_r = w_r det'_0 / 512                            (reduced rule: the centroid)
-// for the two node rows {A0, A0+1} this wave adds.  Every wave recomputes the geometry of its element (54 + 72 of its ~190
-// FP64 instructions per Gauss point): the node rows are what is split four ways, as in the closed-form kernel.
-// One Gauss point.  K (RW = false): this wave's two node ROWS {A0, A0+1}: Lab[h][b] += s g[a_h] . g[b] (all gradients needed).
-// Rw (RW = true): this wave's two node COLUMNS {A0, A0+1}: Tc[m][a][h] += N'_a g_m[b_h] -- only the gradients of its two
-// columns are formed (18 instead of 72 FP64 instructions per point), the determinant cancels and is never computed.
-// Rw, one Gauss point: this wave's two node COLUMNS {A0, A0+1}: Tc[m][a][h] += N'_a g_m[b_h] -- only the gradients of its two
-// columns are formed (18 instead of 72 FP64 instructions per point); the determinant cancels and is never computed.
+// K (RW = false): L_ab comes from the per-element pre-pass below; the wave adds its two node ROWS {A0, A0+1}.
+// Rw (RW = true), one Gauss point: this wave's two node COLUMNS {A0, A0+1}: Tc[m][a][h] += N'_a g_m[b_h] -- only the gradients of its
+// two columns are formed (18 instead of 72 FP64 instructions per point); the determinant cancels and is never computed.
 template <int A0>
 __device__ __forceinline__ void kle_gen_point_rw(const double (&C)[2][2][2][3], const Q1PointTab& tb, double (&Tc)[3][8][2]) {
   double A[3][3];
@@ -916,35 +914,35 @@ __device__ __forceinline__ void kle_gen_point_rw(const double (&C)[2][2][2][3], 
     }
 }
 
-// K: the scalar Laplacian part L_ab of the element is shared by the four waves -- wave w integrates the Gauss points
-// {2w, 2w+1} (28 off-diagonal entries), the partial sums meet in LDS (Lsh[28][64 elements], ds_add_f64), every wave then reads the
-// two node rows it adds.  Per wave 2 instead of 8 geometry evaluations (126 FP64 instructions each).
-__device__ __forceinline__ void kle_gen_partial_L(const double (&C)[2][2][2][3], int g0, double (&Lo)[28]) {
+// K: the scalar Laplacian part L_ab of an element does not depend on the tile that adds it.  It is integrated ONCE per element by
+// a pre-pass (one element per lane, sum-factorised 2x2x2 rule, 28 off-diagonal entries, structure-of-arrays [28][ne]: 224 B per
+// element) and read by the (up to eight) tiles whose rows the element touches -- the tile kernel then is the parallelepiped
+// kernel plus 14 loads per wave, without the LDS exchange, its barriers and the 2.4-fold redundant integration of the first version.
+__global__ void __launch_bounds__(256) kle_elem_laplace_kernel(LatArgs L, double* __restrict__ Lel, int64_t ne) {
+  const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (e >= ne) return;
+  const int ex = L.nx - 1, ey = L.ny - 1;
+  const int ix = (int)(e % ex), iy = (int)((e / ex) % ey), gl = (int)(e / ((int64_t)ex * ey));
+  const int n00 = iy * L.nx + ix;
+  const double* q0 = L.xyz + (int64_t)(lat_plane(L, gl) + n00) * 3;
+  const double* qz = L.xyz + (int64_t)(lat_plane(L, gl + 1) + n00) * 3;
+  double P[2][2][2][3], Lo[28];
 #pragma unroll
-  for (int i = 0; i < 28; ++i) Lo[i] = 0.0;
-#pragma nounroll
-  for (int G = g0; G < g0 + 2; ++G) {
-    const Q1PointTab& tb = Q1_POINTS[G];
-    double A[3][3];
-    const double det = q1_point_adj_rt(C, tb, A);
-    const double s = (1.0 / 512.0) * q1_rcp(det);
+  for (int j = 0; j < 2; ++j)
 #pragma unroll
-    for (int x = 0; x < 3; ++x) {
-      double g[8];
+    for (int i = 0; i < 2; ++i)
 #pragma unroll
-      for (int a = 0; a < 8; ++a) g[a] = fma(A[2][x], tb.h[2][a], fma(A[1][x], tb.h[1][a], A[0][x] * tb.h[0][a]));
-#pragma unroll
-      for (int a = 0; a < 7; ++a) {
-        const double t = s * g[a];
-#pragma unroll
-        for (int b = a + 1; b < 8; ++b) Lo[q1_off(a, b)] = fma(t, g[b], Lo[q1_off(a, b)]);
+      for (int cc = 0; cc < 3; ++cc) {
+        P[0][j][i][cc] = q0[(j * L.nx + i) * 3 + cc];
+        P[1][j][i][cc] = qz[(j * L.nx + i) * 3 + cc];
       }
-    }
-  }
+  q1_laplace_sumfac(P, 1.0 / 512.0, Lo);
+#pragma unroll
+  for (int i = 0; i < 28; ++i) Lel[(int64_t)i * ne + e] = Lo[i];
 }
 
 template <int TX, int TY, int TZ, bool RW, int A0>
-__device__ __forceinline__ void kle_lat_rows_general(const KleLatArgs& T, const double (&C)[2][2][2][3], const double* Lsh, int lane, int lx,
+__device__ __forceinline__ void kle_lat_rows_general(const KleLatArgs& T, const double (&C)[2][2][2][3], const double (&Lv)[2][8], int lx,
                                                      int ly, int lz, int z0, double* acc) {
   constexpr int CX[8] = {0, 0, 1, 1, 0, 1, 1, 0};
   constexpr int CY[8] = {0, 1, 1, 0, 0, 0, 1, 1};
@@ -997,7 +995,7 @@ __device__ __forceinline__ void kle_lat_rows_general(const KleLatArgs& T, const 
 #pragma unroll
       for (int b = 0; b < 8; ++b)
         if (b != a) {
-          const double v = Lsh[(a < b ? q1_off(a, b) : q1_off(b, a)) * 64 + lane];
+          const double v = Lv[h][b];
           Lab[h][b] = v;
           d -= v;
         }
@@ -1049,15 +1047,8 @@ __device__ __forceinline__ void kle_lat_rows_general(const KleLatArgs& T, const 
   }
 }
 
-// LDS of the KLE lattice kernels: acc[NR][243] doubles | rlo, zrd, nbc (META_INTS ints) | Lsh[28][64] doubles (general-geometry K)
-template <int TX, int TY, int TZ>
-__host__ __device__ constexpr int KLE_LSH_OFF() {
-  using LT = LatTile<TX, TY, TZ>;
-  return LT::NR * 243 + (LT::META_INTS + 1) / 2;
-}
-
 template <int TX, int TY, int TZ, bool RW, bool GEN>
-__global__ void __launch_bounds__(256, GEN ? 2 : 3) assemble_q1_hex_kle_lattice_kernel(KleLatArgs T) {
+__global__ void __launch_bounds__(256, GEN && RW ? 2 : 3) assemble_q1_hex_kle_lattice_kernel(KleLatArgs T) {
   using LT = LatTile<TX, TY, TZ>;
   constexpr int ROW = 243, ACC = LT::NR * ROW;
   extern __shared__ __align__(16) double lds[];
@@ -1077,50 +1068,46 @@ __global__ void __launch_bounds__(256, GEN ? 2 : 3) assemble_q1_hex_kle_lattice_
   __syncthreads();
 
   const double* __restrict__ S = L.q.aff + 248;
-  // ---- general geometry: every wave sees the same elements (lane = element); uniform trip count, barriers inside
-  double* Lsh = reinterpret_cast<double*>(lds) + KLE_LSH_OFF<TX, TY, TZ>();   // [28][64]: the element Laplacians of this batch (K only)
-  for (int t0 = 0; GEN && t0 < LT::NE && L.ablate != 1; t0 += 64) {
-    const int t = t0 + lane;
+  // ---- general geometry: every wave sees the same elements (lane = element)
+  for (int t = lane; GEN && t < LT::NE && L.ablate != 1; t += 64) {
     const int lx = t % LT::EX, ly = (t / LT::EX) % LT::EY, lz = t / (LT::EX * LT::EY);
     const int gx = x0 - 1 + lx, gy = y0 - 1 + ly, gl = L.p_own0 + z0 - 1 + lz;
-    const bool valid = t < LT::NE && gx >= 0 && gx < nx - 1 && gy >= 0 && gy < ny - 1 && gl >= 0 && gl < L.npl - 1;
-    double C[2][2][2][3];
-    if (valid) {
-      const int n00 = gy * nx + gx;
-      const double* q0 = L.xyz + (int64_t)(lat_plane(L, gl) + n00) * 3;
-      const double* qz = L.xyz + (int64_t)(lat_plane(L, gl + 1) + n00) * 3;
-      double P[2][2][2][3];
-#pragma unroll
-      for (int j = 0; j < 2; ++j)
-#pragma unroll
-        for (int i = 0; i < 2; ++i)
-#pragma unroll
-          for (int cc = 0; cc < 3; ++cc) {
-            P[0][j][i][cc] = q0[(j * nx + i) * 3 + cc];
-            P[1][j][i][cc] = qz[(j * nx + i) * 3 + cc];
-          }
-      q1_haar_coeffs(P, C);
-    }
+    if (gx < 0 || gx >= nx - 1 || gy < 0 || gy >= ny - 1 || gl < 0 || gl >= L.npl - 1) continue;
+    const int n00 = gy * nx + gx;
+    const double* q0 = L.xyz + (int64_t)(lat_plane(L, gl) + n00) * 3;
+    const double* qz = L.xyz + (int64_t)(lat_plane(L, gl + 1) + n00) * 3;
+    // K: the element's Laplacian entries were integrated once by kle_elem_laplace_kernel (element id = x + (nx-1)(y + (ny-1) layer));
+    // this wave's two rows {2 part, 2 part + 1}, requested together with the corner coordinates (one memory latency, not two)
+    double Lv[2][8];
     if (!RW) {
-      for (int i = tid; i < 28 * 64; i += 256) Lsh[i] = 0.0;
-      __syncthreads();
-      if (valid) {
-        double Lo[28];
-        kle_gen_partial_L(C, 2 * part, Lo);
+      const double* Le = T.Lel + ((int64_t)gl * (ny - 1) + gy) * (nx - 1) + gx;
 #pragma unroll
-        for (int i = 0; i < 28; ++i) atomicAdd(&Lsh[i * 64 + lane], Lo[i]);
-      }
-      __syncthreads();
+      for (int h = 0; h < 2; ++h)
+#pragma unroll
+        for (int bb = 0; bb < 8; ++bb) {
+          const int a = 2 * part + h;
+          const int lo = min(a, bb), hi = max(a, bb);
+          const int off = lo * 7 - (lo * (lo - 1)) / 2 + (hi - lo - 1);     // q1_off(lo, hi)
+          Lv[h][bb] = a == bb ? 0.0 : Le[(int64_t)off * T.ne];
+        }
     }
-    if (valid) {
-      switch (part) {
-        case 0: kle_lat_rows_general<TX, TY, TZ, RW, 0>(T, C, Lsh, lane, lx, ly, lz, z0, acc); break;
-        case 1: kle_lat_rows_general<TX, TY, TZ, RW, 2>(T, C, Lsh, lane, lx, ly, lz, z0, acc); break;
-        case 2: kle_lat_rows_general<TX, TY, TZ, RW, 4>(T, C, Lsh, lane, lx, ly, lz, z0, acc); break;
-        default: kle_lat_rows_general<TX, TY, TZ, RW, 6>(T, C, Lsh, lane, lx, ly, lz, z0, acc); break;
-      }
+    double P[2][2][2][3], C[2][2][2][3];
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int cc = 0; cc < 3; ++cc) {
+          P[0][j][i][cc] = q0[(j * nx + i) * 3 + cc];
+          P[1][j][i][cc] = qz[(j * nx + i) * 3 + cc];
+        }
+    q1_haar_coeffs(P, C);
+    switch (part) {
+      case 0: kle_lat_rows_general<TX, TY, TZ, RW, 0>(T, C, Lv, lx, ly, lz, z0, acc); break;
+      case 1: kle_lat_rows_general<TX, TY, TZ, RW, 2>(T, C, Lv, lx, ly, lz, z0, acc); break;
+      case 2: kle_lat_rows_general<TX, TY, TZ, RW, 4>(T, C, Lv, lx, ly, lz, z0, acc); break;
+      default: kle_lat_rows_general<TX, TY, TZ, RW, 6>(T, C, Lv, lx, ly, lz, z0, acc); break;
     }
-    if (!RW && t0 + 64 < LT::NE) __syncthreads();   // the next batch clears Lsh
   }
   for (int t = lane; !GEN && t < LT::NE && L.ablate != 1; t += 64) {
     const int lx = t % LT::EX, ly = (t / LT::EX) % LT::EY, lz = t / (LT::EX * LT::EY);
@@ -1407,8 +1394,7 @@ static int launch_kle_lattice(pyn_ctx* c, KleLatArgs& T, double* K, double* Krhs
   T.L.ntx = (T.L.nx + TX - 1) / TX;
   T.L.nty = (T.L.ny + TY - 1) / TY;
   const int n_tiles = T.L.ntx * T.L.nty * ((T.L.n_own + TZ - 1) / TZ);
-  const size_t lds = GEN ? ((size_t)KLE_LSH_OFF<TX, TY, TZ>() + 28 * 64) * sizeof(double)
-                         : (size_t)LT::NR * 243 * sizeof(double) + LT::META_INTS * sizeof(int);
+  const size_t lds = (size_t)LT::NR * 243 * sizeof(double) + LT::META_INTS * sizeof(int);
   static bool attr_done = false;
   if (!attr_done) {
     PYN_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(assemble_q1_hex_kle_lattice_kernel<TX, TY, TZ, false, GEN>),
@@ -1418,6 +1404,20 @@ static int launch_kle_lattice(pyn_ctx* c, KleLatArgs& T, double* K, double* Krhs
     attr_done = true;
   }
   if (K) {
+    if (GEN) {   // the element Laplacians, once per element
+      const int64_t ne = (int64_t)(T.L.nx - 1) * (T.L.ny - 1) * (T.L.npl - 1);
+      const size_t need = (size_t)28 * ne * sizeof(double);
+      if (need > c->kle_lel_bytes) {
+        if (c->d_kle_lel) PYN_HIP(hipFree(c->d_kle_lel));
+        c->d_kle_lel = nullptr;
+        c->kle_lel_bytes = 0;
+        PYN_HIP(hipMalloc((void**)&c->d_kle_lel, need));
+        c->kle_lel_bytes = need;
+      }
+      kle_elem_laplace_kernel<<<(int)((ne + 255) / 256), 256, 0, c->stream>>>(T.L, c->d_kle_lel, ne);
+      T.Lel = c->d_kle_lel;
+      T.ne = ne;
+    }
     T.L.A = K;
     T.L.Arhs = Krhs;
     assemble_q1_hex_kle_lattice_kernel<TX, TY, TZ, false, GEN><<<n_tiles, 256, lds, c->stream>>>(T);

@@ -152,6 +152,7 @@ extern "C" int pyn_ctx_destroy(pyn_ctx* c) {
   (void)hipFree(c->d_flag);
   (void)hipFree(c->d_work);
   (void)hipFree(c->d_eloc);
+  (void)hipFree(c->d_kle_lel);
   (void)hipHostFree(c->h_scal);
   (void)hipHostFree(c->h_flag);
   for (auto e : c->prof_ev) (void)hipEventDestroy(e);

@@ -224,6 +224,9 @@ struct pyn_ctx {
   double* asm_dinv = nullptr;
   bool asm_dinv_written = false;
   bool asm_rhs_clean = false;   // the Krhs / Arhs target of the assembly in flight holds zeros wherever this Dirichlet set leaves zeros
+  // general-geometry KLE: off-diagonal element Laplacians [28][ne] between the pre-pass and the tile kernel (grown on demand)
+  double* d_kle_lel = nullptr;
+  size_t kle_lel_bytes = 0;
   // element-local scratch for pyn_elem_local
   double* d_eloc = nullptr;
   size_t eloc_bytes = 0;

@@ -1,59 +1,49 @@
 #!/usr/bin/env python3
-"""C3 of BASELINE.json: 3D KLE (3 DOF/node) on an n^3 Q1 hex box, uniform-flow boundary data.
-usage: kle_case.py [nel] [cg_iters]"""
+"""128^3 KLE assembly (K + Krhs + Rw) under the diagnostic switches, same process: time per call of the whole assembly and of K / Rw alone.
+usage: kle_case.py [nel] [reps] [jitter]   (PYNAMA_LATTICE_ABLATE / PYNAMA_KLE_LATTICE_TILE are read per call by the library)"""
 import os
 import sys
-import time
 
 import numpy as np
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-from pynama_amd import _lib  # noqa: E402
 from pynama_amd.domain.dmplex import DMPlexDom  # noqa: E402
 from pynama_amd.elements.spectral import Spectral  # noqa: E402
 
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 128
-iters = int(sys.argv[2]) if len(sys.argv) > 2 else 50
-dom = DMPlexDom(boxMesh={"nelem": [n, n, n], "lower": [0, 0, 0], "upper": [1, 1, 1]}, jitter=float(os.environ.get("PYNAMA_JITTER", "0")))
+reps = int(sys.argv[2]) if len(sys.argv) > 2 else 5
+jit = float(sys.argv[3]) if len(sys.argv) > 3 else 0.0
+dom = DMPlexDom(boxMesh={"nelem": [n, n, n], "lower": [0, 0, 0], "upper": [1, 1, 1]}, jitter=jit)
 dom.setFemIndexing(2)
 ctx = dom.ctx
 for t in Spectral(2, 3).deviceTables():
     ctx.tables_set(*t)
 bm = dom.boundaryMaskLocal()
 ctx.bc_set(3, np.repeat(bm[:, None], 3, axis=1))
-t0 = time.time()
 ctx.csr_symbolic()
-print("symbolic ms", ctx.timers()["symbolic_ms"])
 K, Krhs, Rw = ctx.mat_create(3, 3), ctx.mat_create(3, 3), ctx.mat_create(3, 3)
-if os.environ.get("PYNAMA_KLE_TILE"):       # explicit patch plan -> patch-plan kernels; default: the library's choice
-    tile = tuple(int(v) for v in os.environ["PYNAMA_KLE_TILE"].split(","))
-    ctx.patch_plan_set(*dom.patchPlan(tile), kind=1)
-for _ in range(2):
-    ctx.assemble_kle(1e3, 1e2, K, Krhs, Rw, -1, variant=int(os.environ.get('PYNAMA_VARIANT', '1')))
-    print("assemble_kle ms", ctx.timers()["assemble_ms"])
-vel = np.zeros((dom.nOwned, 3))
-vel[bm != 0] = [1.0, 0.0, 0.0]
-vv, vr, vx = ctx.vec_create(3), ctx.vec_create(3), ctx.vec_create(3)
-ctx.vec_set(vv, vel.ravel())
-ctx.spmv(Krhs, vv, vr)
-print("spmv 3x3 ms", ctx.timers()["spmv_ms"])
-info = ctx.solve(K, vr, vx, fixed_iters=iters, profile=1)
-print("cg ms/iter", info.solve_ms / info.iters, "spmv_ms", info.spmv_ms)
-info = ctx.solve(K, vr, vx, rtol=1e-10, norm_type=_lib.NORM_UNPRECONDITIONED, maxit=20000)
-ctx.matfree_kle_set(1e3, 1e2)
-vy = ctx.vec_create(3)
-for _ in range(3):
-    ctx.matfree_apply(vr, vy, op=_lib.MATFREE_KLE)
-print("matrix-free K product ms", ctx.timers()["spmv_ms"])
-ctx.spmv(K, vr, vv)
-y0, y1 = ctx.vec_get(vv, 3), ctx.vec_get(vy, 3)
-print("  vs assembled K product", ctx.timers()["spmv_ms"], "ms, max rel diff", np.abs(y0 - y1).max() / np.abs(y0).max())
-for _ in range(2):
-    im = ctx.solve(K, vr, vy, fixed_iters=iters, profile=1, matfree=_lib.MATFREE_KLE)
-print("matrix-free cg ms/iter", im.solve_ms / im.iters, "product ms", im.spmv_ms)
-im = ctx.solve(K, vr, vy, rtol=1e-10, norm_type=_lib.NORM_UNPRECONDITIONED, maxit=20000, matfree=_lib.MATFREE_KLE)
-print("matrix-free solve its", im.iters, "reason", im.reason, "true_resid (assembled K)", im.true_resid, "ms", im.solve_ms)
-x = ctx.vec_get(vx, 3).reshape(-1, 3)
-print("solve its", info.iters, "reason", info.reason, "true_resid", info.true_resid, "ms", info.solve_ms,
-      "max err vs exact", np.abs(x - [1.0, 0.0, 0.0]).max())
+
+
+def timed(env, k, kr, rw):
+    for a, b in env.items():
+        os.environ[a] = b
+    try:
+        ts = []
+        for _ in range(reps + 1):
+            ctx.assemble_kle(1e3, 1e2, k, kr, rw, -1)
+            ts.append(ctx.timers()["assemble_ms"])
+        return float(np.median(ts[1:]))
+    finally:
+        for a in env:
+            del os.environ[a]
+
+
+cases = [("full", {}), ("no element phase", {"PYNAMA_LATTICE_ABLATE": "1"}), ("all tiles through the CSR-slot store", {"PYNAMA_LATTICE_ABLATE": "4"}),
+         ("Krhs written in full", {"PYNAMA_RHS_FULL_WRITE": "1"})]
+for tl in os.environ.get("KLE_TILES", "").split(","):
+    if tl:
+        cases.append((f"tile {tl}", {"PYNAMA_KLE_LATTICE_TILE": tl}))
+for name, env in cases:
+    print(f"{name:40s} K+Krhs+Rw {timed(env, K, Krhs, Rw):.3f} ms | K+Krhs {timed(env, K, Krhs, -1):.3f} | K {timed(env, K, -1, -1):.3f} | Rw {timed(env, -1, -1, Rw):.3f}",
+          flush=True)
 ctx.close()
