@@ -307,6 +307,8 @@ __global__ void __launch_bounds__((TX + 1) * (TY + 1), WPS) assemble_q1_hex_marc
       if (NT > 64 && T.dinv) __syncthreads();   // the stores below clear the accumulators other waves' lanes have just read
       if (lat_tile_plain<TX, TY, 1>(T, x0, y0, l, zrd, anybc) && T.ablate != 4)
         lat_store_plain<TX, TY, 1, true>(T, buf, rlo, tid, NT);
+      else if (zrd[0] == ZCODE_STD && T.ablate != 4 && T.ablate != 16)   // boundary column, interior plane: masked x-line copies + the face rows
+        lat_store_lines<TX, TY, true>(T, x0, y0, buf, rlo, zrd, nbc, anybc, tid, NT);
       else
         lat_store<TX, TY, 1, true>(T, x0, y0, buf, rlo, zrd, nbc, tid, NT);
     }

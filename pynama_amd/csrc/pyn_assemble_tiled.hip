@@ -1294,7 +1294,7 @@ int pyn_assemble_q1_tiled(pyn_ctx* c, int form, double alpha_d, double alpha_w, 
     PYN_TRY(pyn_assemble_lattice(c, K, Krhs, handled));
     if (*handled) return PYN_OK;
   }
-  if (form == PYN_FORM_KLE && K && !Rd && !c->plan[1].user) {
+  if (form == PYN_FORM_KLE && (K || (Rw && !Krhs)) && !Rd && !c->plan[1].user) {   // (Rw alone is a legal request of the ABI)
     PYN_TRY(pyn_assemble_kle_lattice(c, alpha_d, alpha_w, K, Krhs, Rw, handled));
     if (*handled) return PYN_OK;
   }

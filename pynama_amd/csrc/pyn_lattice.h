@@ -30,7 +30,7 @@ struct LatArgs {
   int std_lat;             // P[j] == j*nx*ny, all planes owned, standard z order: plane bases, z codes AND row offsets
                            // come from arithmetic (no index loads at all)
   int lean;                // the uploaded tables are the standard 2x2x2 Gauss tables: closed-form element routine (q1_laplace_lean)
-  int ablate;              // diagnostics (PYNAMA_LATTICE_ABLATE): 1 no element phase, 4 no plain-tile store path,
+  int ablate;              // diagnostics (PYNAMA_LATTICE_ABLATE): 1 no element phase, 4 no plain-tile store path, 16 boundary columns of the march through the CSR-slot decode,
                            // 6 round-robin instead of XCD-contiguous tile order
   TileArgs q;              // quadrature tables (w, hrs, hcoo, aff) -- only those fields are used
   double* A;
@@ -214,9 +214,10 @@ __device__ __forceinline__ void lat_emit_dinv(const LatArgs& T, int x0, int y0, 
 // write every row of the tile once (half a wave per row, UNROLL rows in flight): A gets the free columns,
 // Arhs the imposed ones (negated), imposed rows become identity rows (mat_generator.py:113-118).
 // ZERO: clear each accumulator after reading it (the z-marching kernels reuse the buffer for the next plane).
-template <int TX, int TY, int TZ, bool ZERO = false>
-__device__ __forceinline__ void lat_store(const LatArgs& T, int x0, int y0, double* acc, const int* rlo, const int* zrd,
-                                          const unsigned char* nbc, int t, int nt) {
+// The rows are map(0) .. map(n-1) (lat_store: all NR rows; the z-marching kernel's boundary columns: only the rows on a domain face).
+template <int TX, int TY, int TZ, bool ZERO, typename RowMap>
+__device__ __forceinline__ void lat_store_rows(const LatArgs& T, int x0, int y0, double* acc, const int* rlo, const int* zrd,
+                                               const unsigned char* nbc, int t, int nt, int n, RowMap map) {
   using LT = LatTile<TX, TY, TZ>;
   const int nx = T.nx, ny = T.ny;
   double* __restrict__ outA = T.A;
@@ -225,19 +226,19 @@ __device__ __forceinline__ void lat_store(const LatArgs& T, int x0, int y0, doub
   const int NH = nt >> 5;
   constexpr int UNROLL = 4;
   // branch-free per row: the LDS reads of the UNROLL rows are independent of each other, so they overlap
-  for (int s0 = half; s0 < LT::NR; s0 += NH * UNROLL) {
+  for (int s0 = half; s0 < n; s0 += NH * UNROLL) {
     int lo[UNROLL], ai[UNROLL], bi[UNROLL], bo[UNROLL];
     bool diag[UNROLL];
 #pragma unroll
     for (int u = 0; u < UNROLL; ++u) {
-      const int s = min(s0 + u * NH, LT::NR - 1);
+      const int s = map(min(s0 + u * NH, n - 1));
       const int rl = rlo[s];
       const int rx = s % TX, ry = (s / TX) % TY, rz = s / (TX * TY);
       const int x = x0 + rx, y = y0 + ry;
       const int zi = zrd[rz];
       const int cx = 3 - (x == 0) - (x == nx - 1), cy = 3 - (y == 0) - (y == ny - 1), cz = zi & 3;
       const int cc = cx * cy;
-      const bool act = (s0 + u * NH < LT::NR) && rl >= 0 && k < cc * cz;
+      const bool act = (s0 + u * NH < n) && rl >= 0 && k < cc * cz;
       const int kz = (k >= cc) + (k >= 2 * cc);
       const int r = k - kz * cc;
       const int ky = (r >= cx) + (r >= 2 * cx);
@@ -271,6 +272,12 @@ __device__ __forceinline__ void lat_store(const LatArgs& T, int x0, int y0, doub
   }
 }
 
+template <int TX, int TY, int TZ, bool ZERO = false>
+__device__ __forceinline__ void lat_store(const LatArgs& T, int x0, int y0, double* acc, const int* rlo, const int* zrd,
+                                          const unsigned char* nbc, int t, int nt) {
+  lat_store_rows<TX, TY, TZ, ZERO>(T, x0, y0, acc, rlo, zrd, nbc, t, nt, LatTile<TX, TY, TZ>::NR, [](int j) { return j; });
+}
+
 // Store phase of a "plain" tile -- no row on a domain face, the three z-neighbour planes in ascending id order,
 // no imposed node in the node box: CSR slot k of a row IS stencil position k, and the TX rows of an x-line are
 // one contiguous run of TX*27 doubles both in LDS and in the CSR value array.  Straight coalesced copy.
@@ -299,6 +306,72 @@ __device__ __forceinline__ void lat_store_plain(const LatArgs& T, double* acc, c
       }
     }
   }
+}
+
+// Store phase of one plane (TZ = 1) of a BOUNDARY column of the z-marching kernel whose z-neighbour planes are in standard order
+// (zrd == ZCODE_STD: every plane but the domain's first and last).  Most of its rows still have the full 27-point stencil: on an
+// x-line with interior y the rows x = 1 .. nx-2 are one contiguous run in LDS and in the CSR array with slot == stencil position,
+// i.e. the x-line copy of lat_store_plain plus the Dirichlet routing (two flag bytes per entry) -- no CSR-slot decode.  Only the
+// rows ON a domain face (x = 0, x = nx-1, y = 0, y = ny-1: one row per line or one line per plane) take the decode of lat_store_rows.
+template <int TX, int TY, bool ZERO>
+__device__ __forceinline__ void lat_store_lines(const LatArgs& T, int x0, int y0, double* acc, const int* rlo, const int* zrd,
+                                                const unsigned char* nbc, int anybc, int t, int nt) {
+  using LT = LatTile<TX, TY, 1>;
+  const int nx = T.nx, ny = T.ny;
+  double* __restrict__ outA = T.A;
+  double* __restrict__ outR = T.Arhs;
+  const int txv = min(TX, nx - x0), tyv = min(TY, ny - y0);                         // rows of the column inside the domain
+  const int r0 = x0 == 0 ? 1 : 0, r1 = (x0 + txv == nx) ? txv - 1 : txv;            // [r0, r1): rows with interior x
+  const int nrun = max(r1 - r0, 0) * 27;
+  const int w = t >> 6, lane = t & 63, nw = nt >> 6;
+  constexpr int PER = (TX * 27 + 63) / 64;
+  for (int ry = w; ry < tyv; ry += nw) {
+    const int y = y0 + ry;
+    if (y == 0 || y == ny - 1 || nrun == 0) continue;
+    const int base = rlo[ry * TX + r0];
+    const int a0 = (ry * TX + r0) * 27, b0 = (LT::BY + ry + 1) * LT::BX + r0 + 1;
+    // all LDS reads of the line first (independent of each other), then the routing, then the stores
+    double v[PER];
+    unsigned char fr[PER], fc[PER];
+#pragma unroll
+    for (int j = 0; j < PER; ++j) {
+      const int i = min(lane + 64 * j, nrun - 1);
+      const int r = i / 27, kk = i - r * 27;
+      const int dz = kk / 9, dy = (kk - dz * 9) / 3, dx = kk - dz * 9 - dy * 3;     // 0 .. 2 each
+      v[j] = acc[a0 + i];
+      fr[j] = anybc ? nbc[b0 + r] : 0;
+      fc[j] = anybc ? nbc[b0 + r + ((dz - 1) * LT::BY + dy - 1) * LT::BX + dx - 1] : 0;
+    }
+#pragma unroll
+    for (int j = 0; j < PER; ++j) {
+      const int i = lane + 64 * j;
+      if (i < nrun) {
+        const int kk = i % 27;
+        const double idv = kk == 13 ? 1.0 : 0.0;
+        if (ZERO) acc[a0 + i] = 0.0;
+        outA[base + i] = fr[j] ? idv : (fc[j] ? 0.0 : v[j]);
+        if (outR) outR[base + i] = fr[j] ? idv : (fc[j] ? -v[j] : 0.0);
+      }
+    }
+  }
+  // rows on a domain face: the x-end row of every interior-y line, then the whole y-face lines
+  const bool xlo = x0 == 0, xhi = x0 + txv == nx, ylo = y0 == 0, yhi = y0 + tyv == ny;
+  const int nyf = (ylo ? 1 : 0) + ((yhi && !(ylo && tyv == 1)) ? 1 : 0);               // y-face lines in this column
+  const int nxe = (xlo ? 1 : 0) + ((xhi && !(xlo && txv == 1)) ? 1 : 0);               // x-end rows per line
+  const int yin0 = ylo ? 1 : 0, nyin = tyv - nyf;                                      // interior-y lines [yin0, yin0 + nyin)
+  const int nspecial = nyf * txv + max(nyin, 0) * nxe;
+  if (nspecial > 0)
+    lat_store_rows<TX, TY, 1, ZERO>(T, x0, y0, acc, rlo, zrd, nbc, t, nt, nspecial, [=](int j) {
+      if (j < nyf * txv) {                       // y-face lines (at most two), row by row
+        const int f = j >= txv ? 1 : 0, rx = j - f * txv;
+        const int ry = (f == 0 && ylo) ? 0 : tyv - 1;
+        return ry * TX + rx;
+      }
+      const int q = j - nyf * txv;               // x-end rows (one or two per line) of the interior-y lines
+      const int ly = nxe == 2 ? q >> 1 : q, e = q - ly * nxe;
+      const int rx = (e == 0 && xlo) ? 0 : txv - 1;
+      return (yin0 + ly) * TX + rx;
+    });
 }
 
 template <int TX, int TY, int TZ>

@@ -903,6 +903,9 @@ def test_assemble_kle_lattice_kernel(lib, tile, kind):
         assert sp_rel_err(mat_to_scipy(ctx, K2, 3, 3), Kref) < FP_TOL
         assert sp_rel_err(mat_to_scipy(ctx, Krhs, 3, 3), Krref) < FP_TOL
         assert sp_rel_err(mat_to_scipy(ctx, Rw, 3, 3), Rwref) < FP_TOL
+        Rw2 = ctx.mat_create(3, 3)
+        ctx.assemble_kle(1e3, 1e2, -1, -1, Rw2, -1)          # Rw alone
+        assert sp_rel_err(mat_to_scipy(ctx, Rw2, 3, 3), Rwref) < FP_TOL
         # and the patch-plan kernels (explicit plan) give the same matrices
         ctx.patch_plan_set(*tile_plan(mesh, (3, 3, 3)), kind=1)
         K3, Rw3 = ctx.mat_create(3, 3), ctx.mat_create(3, 3)

@@ -28,8 +28,11 @@ A, Ar = ctx.mat_create(1, 1), ctx.mat_create(1, 1)
 
 
 def run(v, with_rhs=False):
-    for k in ("PYNAMA_NO_MARCH", "PYNAMA_MARCH_TILE", "PYNAMA_NO_LEAN", "PYNAMA_LATTICE_TILE"):
+    for k in ("PYNAMA_NO_MARCH", "PYNAMA_MARCH_TILE", "PYNAMA_NO_LEAN", "PYNAMA_LATTICE_TILE", "PYNAMA_LATTICE_ABLATE"):
         os.environ.pop(k, None)
+    if "a" in v and not v.startswith("l"):     # <march tile>a<ablate code>, e.g. 0a16 = default shape, boundary columns through the CSR-slot decode
+        v, ab = v.split("a")
+        os.environ["PYNAMA_LATTICE_ABLATE"] = ab
     if v == "t":          # 7x7x7 tile kernel with the table-driven Gauss loop (round 1)
         os.environ["PYNAMA_NO_MARCH"] = "1"
         os.environ["PYNAMA_NO_LEAN"] = "1"

@@ -84,7 +84,7 @@ def counters(db, out_json, needle=""):
         key = re.split(r"[<(]", re.sub(r"^void\s+", "", name).replace("(anonymous namespace)::", ""))[0].strip()
         res.setdefault(key, {"launches": n})[cn] = mean
     with open(out_json, "w") as f:
-        json.dump(res, f, indent=1)
+        json.dump({"source_hash": _source_hash(), **res}, f, indent=1)
 
 
 if __name__ == "__main__":
