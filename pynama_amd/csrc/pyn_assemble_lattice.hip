@@ -941,6 +941,95 @@ __global__ void __launch_bounds__(256) kle_elem_laplace_kernel(LatArgs L, double
   for (int i = 0; i < 28; ++i) Lel[(int64_t)i * ne + e] = Lo[i];
 }
 
+#ifndef KLE_RW_M_OUTER
+#define KLE_RW_M_OUTER 1
+#endif
+// Rw with the vorticity component m as the OUTER loop: 16 instead of 48 accumulators live across the Gauss loop (a wave's two columns x
+// eight rows for one m), the Jacobian rows are evaluated three times (8 x 3 x (24 + 6 + 6 + 16) = 1,250 instead of 860 FP64
+// instructions per wave) -- but the kernel fits 168 registers, i.e. three workgroups per CU like the K kernel instead of two.
+template <int TX, int TY, int TZ, int A0>
+__device__ __forceinline__ void kle_lat_rw_general_m(const KleLatArgs& T, const double (&C)[2][2][2][3], int lx, int ly, int lz, int z0,
+                                                     double* acc) {
+  constexpr int CX[8] = {0, 0, 1, 1, 0, 1, 1, 0};
+  constexpr int CY[8] = {0, 1, 1, 0, 0, 0, 1, 1};
+  constexpr int CZ[8] = {0, 0, 0, 0, 1, 1, 1, 1};
+  // centroid: cofactor rows of J'_0 (first-order Haar coefficients); Gr[m][a] = (sum_d s_d(a) A0[d][m]) / det'_0
+  double A0c[3][3], ri, caw;
+  {
+    double r0[3], r1[3], r2[3];
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+      r0[c] = C[0][0][1][c];
+      r1[c] = C[0][1][0][c];
+      r2[c] = C[1][0][0][c];
+    }
+    A0c[0][0] = r1[1] * r2[2] - r1[2] * r2[1];
+    A0c[0][1] = r1[2] * r2[0] - r1[0] * r2[2];
+    A0c[0][2] = r1[0] * r2[1] - r1[1] * r2[0];
+    A0c[1][0] = r2[1] * r0[2] - r2[2] * r0[1];
+    A0c[1][1] = r2[2] * r0[0] - r2[0] * r0[2];
+    A0c[1][2] = r2[0] * r0[1] - r2[1] * r0[0];
+    A0c[2][0] = r0[1] * r1[2] - r0[2] * r1[1];
+    A0c[2][1] = r0[2] * r1[0] - r0[0] * r1[2];
+    A0c[2][2] = r0[0] * r1[1] - r0[1] * r1[0];
+    const double det0 = r0[0] * A0c[0][0] + r0[1] * A0c[0][1] + r0[2] * A0c[0][2];
+    ri = q1_rcp(det0);
+    caw = T.wr[0] * det0 * (1.0 / 512.0) * T.alpha_w;
+  }
+  // LDS offsets of the element's eight node rows (-1: the row is not this tile's)
+  int rofs[8];
+#pragma unroll
+  for (int a = 0; a < 8; ++a) {
+    const int rx = lx - 1 + CX[a], ry = ly - 1 + CY[a], rz = lz - 1 + CZ[a];
+    rofs[a] = (rx < 0 || rx >= TX || ry < 0 || ry >= TY || rz < 0 || rz >= TZ || z0 + rz >= T.L.n_own) ? -1 : ((rz * TY + ry) * TX + rx) * 243;
+  }
+#pragma unroll
+  for (int m = 0; m < 3; ++m) {
+    double Tm[8][2];
+#pragma unroll
+    for (int a = 0; a < 8; ++a) Tm[a][0] = Tm[a][1] = 0.0;
+#pragma nounroll
+    for (int G = 0; G < 8; ++G) {
+      const Q1PointTab& tb = Q1_POINTS[G];
+      const double xi = tb.xi[0], eta = tb.xi[1], zeta = tb.xi[2];
+      double r0[3], r1[3], r2[3];
+#pragma unroll
+      for (int c = 0; c < 3; ++c) {
+        const double mm = fma(xi, C[1][1][1][c], C[1][1][0][c]);
+        r0[c] = fma(zeta, fma(eta, C[1][1][1][c], C[1][0][1][c]), fma(eta, C[0][1][1][c], C[0][0][1][c]));
+        r1[c] = fma(zeta, mm, fma(xi, C[0][1][1][c], C[0][1][0][c]));
+        r2[c] = fma(eta, mm, fma(xi, C[1][0][1][c], C[1][0][0][c]));
+      }
+      const int m1 = (m + 1) % 3, m2 = (m + 2) % 3;       // component m of the cross products r1 x r2, r2 x r0, r0 x r1
+      const double a0 = r1[m1] * r2[m2] - r1[m2] * r2[m1];
+      const double a1 = r2[m1] * r0[m2] - r2[m2] * r0[m1];
+      const double a2 = r0[m1] * r1[m2] - r0[m2] * r1[m1];
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        const int b = A0 + h;
+        const double gb = fma(a2, tb.h[2][b], fma(a1, tb.h[1][b], a0 * tb.h[0][b]));
+#pragma unroll
+        for (int a = 0; a < 8; ++a) Tm[a][h] = fma(tb.n[a], gb, Tm[a][h]);
+      }
+    }
+    const int P1 = (m + 1) % 3, P2 = (m + 2) % 3;
+#pragma unroll
+    for (int a = 0; a < 8; ++a) {
+      if (rofs[a] < 0) continue;
+      double* rowp = acc + rofs[a];
+      const double gr = ((2 * CX[a] - 1) * A0c[0][m] + (2 * CY[a] - 1) * A0c[1][m] + (2 * CZ[a] - 1) * A0c[2][m]) * ri;
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        const int b = A0 + h;
+        const int kk = (CZ[b] - CZ[a] + 1) * 9 + (CY[b] - CY[a] + 1) * 3 + (CX[b] - CX[a] + 1);
+        const double wv = Tm[a][h] - caw * gr * T.Hr[b];
+        atomicAdd(&rowp[(P2 * 27 + kk) * 3 + P1], wv);
+        atomicAdd(&rowp[(P1 * 27 + kk) * 3 + P2], -wv);
+      }
+    }
+  }
+}
+
 template <int TX, int TY, int TZ, bool RW, int A0>
 __device__ __forceinline__ void kle_lat_rows_general(const KleLatArgs& T, const double (&C)[2][2][2][3], const double (&Lv)[2][8], int lx,
                                                      int ly, int lz, int z0, double* acc) {
@@ -1048,7 +1137,7 @@ __device__ __forceinline__ void kle_lat_rows_general(const KleLatArgs& T, const 
 }
 
 template <int TX, int TY, int TZ, bool RW, bool GEN>
-__global__ void __launch_bounds__(256, GEN && RW ? 2 : 3) assemble_q1_hex_kle_lattice_kernel(KleLatArgs T) {
+__global__ void __launch_bounds__(256, GEN && RW && !KLE_RW_M_OUTER ? 2 : 3) assemble_q1_hex_kle_lattice_kernel(KleLatArgs T) {
   using LT = LatTile<TX, TY, TZ>;
   constexpr int ROW = 243, ACC = LT::NR * ROW;
   extern __shared__ __align__(16) double lds[];
@@ -1102,6 +1191,15 @@ __global__ void __launch_bounds__(256, GEN && RW ? 2 : 3) assemble_q1_hex_kle_la
           P[1][j][i][cc] = qz[(j * nx + i) * 3 + cc];
         }
     q1_haar_coeffs(P, C);
+    if (RW && KLE_RW_M_OUTER) {
+      switch (part) {
+        case 0: kle_lat_rw_general_m<TX, TY, TZ, 0>(T, C, lx, ly, lz, z0, acc); break;
+        case 1: kle_lat_rw_general_m<TX, TY, TZ, 2>(T, C, lx, ly, lz, z0, acc); break;
+        case 2: kle_lat_rw_general_m<TX, TY, TZ, 4>(T, C, lx, ly, lz, z0, acc); break;
+        default: kle_lat_rw_general_m<TX, TY, TZ, 6>(T, C, lx, ly, lz, z0, acc); break;
+      }
+      continue;
+    }
     switch (part) {
       case 0: kle_lat_rows_general<TX, TY, TZ, RW, 0>(T, C, Lv, lx, ly, lz, z0, acc); break;
       case 1: kle_lat_rows_general<TX, TY, TZ, RW, 2>(T, C, Lv, lx, ly, lz, z0, acc); break;
@@ -1458,6 +1556,7 @@ int pyn_assemble_kle_lattice(pyn_ctx* c, double alpha_d, double alpha_w, double*
     case 1: PYN_TRY((launch_kle_lattice<6, 2, 2, false>(c, T, K, Krhs, Rw))); break;
     case 2: PYN_TRY((launch_kle_lattice<3, 3, 2, false>(c, T, K, Krhs, Rw))); break;
     case 3: PYN_TRY((launch_kle_lattice<4, 3, 3, false>(c, T, K, Krhs, Rw))); break;
+    case 4: PYN_TRY((launch_kle_lattice<5, 2, 2, false>(c, T, K, Krhs, Rw))); break;   // 39 KB: four workgroups per CU, -3.5 % (flat 6x3x1 / 7x2x1 / 3x3x1 tiles: +0 .. +37 %)
     default: PYN_TRY((launch_kle_lattice<3, 3, 3, false>(c, T, K, Krhs, Rw))); break;
   }
   *handled = true;

@@ -848,7 +848,7 @@ def test_rccl_overlapped_halo_in_cg(lib):
 
 
 # ---- plan-free KLE kernels on lattices of parallelepipeds ------------------------------------------
-@pytest.mark.parametrize("tile", [0, 1, 2, 3])
+@pytest.mark.parametrize("tile", [0, 1, 2, 3, 4])
 @pytest.mark.parametrize("kind", ["uniform", "sheared", "partial_bc", "nobc", "interior_bc"])
 def test_assemble_kle_lattice_kernel(lib, tile, kind):
     """box meshes of parallelepipeds are assembled by the plan-free KLE kernels (K, Krhs, Rw): every tile shape,
@@ -917,16 +917,17 @@ def test_assemble_kle_lattice_kernel(lib, tile, kind):
         del os.environ["PYNAMA_KLE_LATTICE_TILE"]
 
 
+@pytest.mark.parametrize("jitter", [0.0, 0.2])
 @pytest.mark.parametrize("size,nz", [(2, 9), (3, 9), (4, 3)])
-def test_kle_lattice_kernel_on_rank_slabs(lib, size, nz):
+def test_kle_lattice_kernel_on_rank_slabs(lib, size, nz, jitter):
     from pynama_amd.common.comm import Comm
     from pynama_amd.domain.dmplex import DMPlexDom
     from pynama_amd.elements.spectral import Spectral
     nelem = [5, 4, nz]
-    glob = fo.box_mesh(nelem, [0, 0, 0], [1, 1, 1], 2)
+    glob = fo.box_mesh(nelem, [0, 0, 0], [1, 1, 1], 2, jitter=jitter)   # 0.2: general geometry (element pre-pass over the slab incl. ghost layers)
     ref = fo.assemble_kle_freeslip(glob, fo.Tables(2, 3))
     for r in range(size):
-        dom = DMPlexDom(boxMesh={'nelem': nelem, 'lower': [0, 0, 0], 'upper': [1, 1, 1]}, comm=Comm(r, size))
+        dom = DMPlexDom(boxMesh={'nelem': nelem, 'lower': [0, 0, 0], 'upper': [1, 1, 1]}, comm=Comm(r, size), jitter=jitter)
         dom.setFemIndexing(2)
         ctx = lib.Context(0)
         ctx.comm_init(r, size, None)

@@ -40,6 +40,8 @@ def timed(env, k, kr, rw):
 
 cases = [("full", {}), ("no element phase", {"PYNAMA_LATTICE_ABLATE": "1"}), ("all tiles through the CSR-slot store", {"PYNAMA_LATTICE_ABLATE": "4"}),
          ("Krhs written in full", {"PYNAMA_RHS_FULL_WRITE": "1"})]
+if os.environ.get("KLE_QUICK"):
+    cases = cases[:1]
 for tl in os.environ.get("KLE_TILES", "").split(","):
     if tl:
         cases.append((f"tile {tl}", {"PYNAMA_KLE_LATTICE_TILE": tl}))
