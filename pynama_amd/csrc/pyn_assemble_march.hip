@@ -30,6 +30,7 @@ struct MarchTile {
   static constexpr int EX = TX + 1, EY = TY + 1, NT = EX * EY, NR = TX * TY, ACC = NR * 27;
   using L1 = LatTile<TX, TY, 1>;
   static constexpr size_t BYTES = 2 * (size_t)ACC * sizeof(double) + (L1::META_INTS + 2) * sizeof(int);   // + anyflag[2]
+  static_assert(NT % 64 == 0, "one element per lane: (TX + 1)(TY + 1) must fill whole waves (the store phases stride by waves)");
 };
 
 // corner coordinates of the 2 x 2 nodes (j, i) above lattice node n00 of z-plane pl
