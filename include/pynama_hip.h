@@ -253,7 +253,7 @@ typedef struct pyn_solve_info {
   int reason;
   double rnorm;       /* last residual norm in the solver's norm type */
   double rnorm0;
-  double true_resid;  /* ||b - A x||_2 / ||b||_2 recomputed at exit */
+  double true_resid;  /* ||b - A x||_2 / ||b||_2 recomputed at exit; -1 (not computed) when opts.fixed_iters > 0 */
   double solve_ms;    /* device time of the iteration loop (HIP events) */
   double spmv_ms;     /* mean device time of one SpMV launch (profile != 0), else 0 */
   int spmv_launches;  /* launches averaged in spmv_ms */

@@ -343,6 +343,7 @@ def test_cg_zero_rhs_and_maxit(lib, variant):
     x3 = ctx.vec_get(vx, 1)
     info = ctx.solve(A, vb, vx, fixed_iters=3, cg_variant=variant)
     assert info.iters == 3 and info.reason == 4
+    assert info.true_resid == -1.0                          # fixed-iteration runs do not pay the exit product (pynama_hip.h)
     assert rel_err(ctx.vec_get(vx, 1), x3) < 1e-12          # same 3 iterates either way
     x_o, _, _ = fo.pcg(mat_to_scipy(ctx, A, 1, 1), b, rtol=1e-30, maxit=3)
     assert rel_err(x3, x_o) < 1e-10
