@@ -266,7 +266,7 @@ typedef struct pyn_solve_info {
  * (src/solver/ksp_solver.py:9-19, call site base_problem.py:481). */
 int pyn_solve(pyn_ctx* ctx, int mat_id, int b_vec, int x_vec, const pyn_solve_opts* opts,
               pyn_solve_info* info);
-/* Direct solve of a SMALL system: dense LU with partial pivoting, the factors cached in the matrix until its values change.
+/* Direct solve of a SMALL system: blocked dense LU with partial pivoting, the factors cached in the matrix until its values change.
  * Stands for the reference's hard-wired `-ksp_type preonly -pc_type lu` (src/solver/ksp_solver.py:13-16, makefile:7: PETSc
  * factors at KSPSetUp, every later call is two triangular solves) at the sizes the reference's own tests use it
  * (src/tests/test_solver.py).  One rank, rows <= pyn_direct_max_rows(); info->iters = 1 and info->reason =

@@ -4,7 +4,7 @@
 // factors K once at KSPSetUp and every solveKLE is two triangular solves.  A sparse direct solver is outside this build's hot
 // path; what the reference's own tests and cases exercise with that default are systems of 10^2..10^3 unknowns (src/tests/
 // test_solver.py: 882, 882 and 1,029 DOFs), and for those a dense factorisation IS a direct solve: block CSR -> dense n x n,
-// right-looking LU with partial pivoting (one pivot search, one row swap, one rank-1 update launch per column), factors cached
+// blocked right-looking LU with partial pivoting (panels of 64 columns: panel factorisation, row interchanges, triangular solve, tile update), factors cached
 // per matrix version, forward / backward substitution in blocks of 64 unknowns (one launch per block).  n <= PYN_DIRECT_MAX_N (8,192: 512 MB of factors); larger
 // systems take the Krylov substitute of KspSolver (pynama_amd/solver/ksp_solver.py).  One rank only.
 #include <algorithm>
@@ -28,6 +28,13 @@ __global__ void dense_from_bcsr_kernel(const int32_t* __restrict__ rowptr, const
     }
   }
 }
+
+// ---- blocked right-looking LU, panels of LU_NB columns: (1) inside a panel the elimination goes column by column with partial
+// pivoting (pivot search in one workgroup, whole-row interchange, multipliers, rank-1 update of the panel's remaining columns: four
+// small launches per column -- a one-workgroup panel kernel was tried and is slower: one CU streams the panel 64 times), (2) U12 =
+// L11^-1 A12 (one thread per column, L11 through scalar loads), (3) A22 -= L21 U12 (64 x 64 tiles, 4 x 4 per thread, K = LU_NB
+// through LDS).  The trailing matrix is touched once per panel instead of once per column.
+constexpr int LU_NB = 64;
 
 // pivot of column k: row of the largest |D[i][k]|, i >= k (one workgroup)
 __global__ void __launch_bounds__(256) lu_pivot_kernel(const double* __restrict__ D, int64_t n, int k, int* __restrict__ piv, int* __restrict__ flag) {
@@ -75,12 +82,73 @@ __global__ void lu_scale_kernel(double* __restrict__ D, int64_t n, int k) {
   for (int64_t i = k + 1 + (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) D[i * n + k] *= inv;
 }
 
-// trailing update D[i][j] -= l_ik D[k][j],  i, j > k  (16 x 16 tiles; a 64-lane wave covers 4 rows x 16 columns)
-__global__ void __launch_bounds__(256) lu_update_kernel(double* __restrict__ D, int64_t n, int k) {
+// rank-1 update inside the panel: D[i][j] -= l_ik D[k][j],  i > k,  k < j < kend  (16 x 16 tiles)
+__global__ void __launch_bounds__(256) lu_update_kernel(double* __restrict__ D, int64_t n, int k, int kend) {
   const int64_t j = k + 1 + (int64_t)blockIdx.x * 16 + (threadIdx.x & 15);
   const int64_t i = k + 1 + (int64_t)blockIdx.y * 16 + (threadIdx.x >> 4);
-  if (i >= n || j >= n) return;
+  if (i >= n || j >= kend) return;
   D[i * n + j] = fma(-D[i * n + k], D[(int64_t)k * n + j], D[i * n + j]);
+}
+
+// U12 = L11^-1 A12: one thread per column right of the panel, its nb entries in registers; L11 (unit lower, final after the panel
+// kernel, disjoint from the columns written here) is the same for every thread: uniform addresses, i.e. scalar loads
+__global__ void __launch_bounds__(256) lu_trsm_kernel(double* __restrict__ D, const double* __restrict__ L11, int64_t n, int kb, int nb) {
+  const int64_t c = kb + nb + (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (c >= n) return;
+  double u[LU_NB];
+#pragma unroll
+  for (int j = 0; j < LU_NB; ++j) u[j] = j < nb ? D[(int64_t)(kb + j) * n + c] : 0.0;
+#pragma unroll
+  for (int i = 1; i < LU_NB; ++i) {
+    if (i < nb) {
+      const double* __restrict__ Li = L11 + (int64_t)i * n;
+      double a = u[i];
+#pragma unroll
+      for (int j = 0; j < i; ++j) a = fma(-Li[j], u[j], a);
+      u[i] = a;
+    }
+  }
+#pragma unroll
+  for (int j = 1; j < LU_NB; ++j)
+    if (j < nb) D[(int64_t)(kb + j) * n + c] = u[j];
+}
+
+// A22 -= L21 U12: 64 x 64 tile per workgroup, 4 x 4 per thread
+__global__ void __launch_bounds__(256) lu_gemm_kernel(double* __restrict__ D, int64_t n, int kb, int nb) {
+  __shared__ double As[64][LU_NB + 1];   // L21 tile [row][k]
+  __shared__ double Bs[LU_NB][64];       // U12 tile [k][col]
+  const int64_t i0 = kb + nb + (int64_t)blockIdx.y * 64, c0 = kb + nb + (int64_t)blockIdx.x * 64;
+  const int t = threadIdx.x;
+  for (int e = t; e < 64 * LU_NB; e += 256) {
+    const int r = e / LU_NB, k = e % LU_NB;
+    As[r][k] = (i0 + r < n && k < nb) ? D[(i0 + r) * n + kb + k] : 0.0;
+  }
+  for (int e = t; e < LU_NB * 64; e += 256) {
+    const int k = e / 64, cc = e % 64;
+    Bs[k][cc] = (c0 + cc < n && k < nb) ? D[(int64_t)(kb + k) * n + c0 + cc] : 0.0;
+  }
+  __syncthreads();
+  const int tx = t & 15, ty = t >> 4;
+  double acc[4][4] = {};
+#pragma unroll 8
+  for (int k = 0; k < LU_NB; ++k) {
+    double a[4], b[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) a[r] = As[ty * 4 + r][k];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) b[q] = Bs[k][tx + 16 * q];
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) acc[r][q] = fma(a[r], b[q], acc[r][q]);
+  }
+#pragma unroll
+  for (int r = 0; r < 4; ++r)
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int64_t i = i0 + ty * 4 + r, c = c0 + tx + 16 * q;
+      if (i < n && c < n) D[i * n + c] -= acc[r][q];
+    }
 }
 
 // the interchanges of the factorisation as one gather: (P b)[i] = b[perm[i]]  (once per factorisation, one thread)
@@ -203,13 +271,20 @@ static int direct_factor(pyn_ctx* c, DMat& A) {
   int* flag = A.lu_piv + n;
   PYN_HIP(hipMemsetAsync(flag, 0, sizeof(int), s));
   dense_from_bcsr_kernel<<<(int)std::min<int64_t>(c->n_owned, 4096), 256, 0, s>>>(c->d_rowptr, c->d_colidx, A.val, c->n_owned, A.br, A.lu, n);
-  for (int k = 0; k < (int)n; ++k) {
-    lu_pivot_kernel<<<1, 256, 0, s>>>(A.lu, n, k, A.lu_piv, flag);
-    lu_swap_kernel<<<(int)((n + 255) / 256), 256, 0, s>>>(A.lu, n, k, A.lu_piv);
-    const int m = (int)(n - k - 1);
-    if (m > 0) {
-      lu_scale_kernel<<<(m + 255) / 256, 256, 0, s>>>(A.lu, n, k);
-      lu_update_kernel<<<dim3((m + 15) / 16, (m + 15) / 16), 256, 0, s>>>(A.lu, n, k);
+  for (int kb = 0; kb < (int)n; kb += LU_NB) {
+    const int nb = (int)std::min<int64_t>(LU_NB, n - kb), kend = kb + nb;
+    for (int k = kb; k < kend; ++k) {
+      lu_pivot_kernel<<<1, 256, 0, s>>>(A.lu, n, k, A.lu_piv, flag);
+      lu_swap_kernel<<<(int)((n + 255) / 256), 256, 0, s>>>(A.lu, n, k, A.lu_piv);
+      const int m = (int)(n - k - 1), w = kend - k - 1;
+      if (m > 0) lu_scale_kernel<<<(m + 255) / 256, 256, 0, s>>>(A.lu, n, k);
+      if (m > 0 && w > 0) lu_update_kernel<<<dim3((w + 15) / 16, (m + 15) / 16), 256, 0, s>>>(A.lu, n, k, kend);
+    }
+    const int64_t m2 = n - kend;
+    if (m2 > 0) {
+      lu_trsm_kernel<<<(int)((m2 + 255) / 256), 256, 0, s>>>(A.lu, A.lu + (int64_t)kb * n + kb, n, kb, nb);
+      const int g = (int)((m2 + 63) / 64);
+      lu_gemm_kernel<<<dim3(g, g), 256, 0, s>>>(A.lu, n, kb, nb);
     }
   }
   lu_perm_kernel<<<1, 1, 0, s>>>(A.lu_piv, (int)n, A.lu_piv + n + 1);

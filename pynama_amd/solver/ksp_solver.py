@@ -12,7 +12,7 @@ with the matrix-free form of the operator when the matrix carries one (``Mat.K``
 assembled matrix then only supplies the Jacobi diagonal and the exit check; the library verifies that both agree.
 
 The reference's hard-wired default is ``preonly`` + ``lu`` (:13-16).  Systems of up to ``-pynama_direct_max_rows`` rows
-(default 4096; one rank) ARE solved directly: ``pyn_solve_direct`` factors the matrix densely with partial pivoting once
+(default 8192 = the library's limit; one rank) ARE solved directly: ``pyn_solve_direct`` factors the matrix densely with partial pivoting once
 per matrix version and every call is two triangular solves -- the sizes at which the reference's own tests use the default
 (src/tests/test_solver.py: 882 .. 1,029 unknowns).  There is no sparse direct solver on the device path: above that size
 (or on several ranks) the combination is served by a Krylov solve driven to round-off --
@@ -45,7 +45,7 @@ class KspSolver(object):
         self.gmres_orthog = 1            # KSPGMRES default: classical Gram-Schmidt, refine_never
         self.norm_type = "preconditioned"
         self.mat_free = False
-        self.direct_max_rows = 4096      # preonly/lu: dense LU up to this many rows, the Krylov substitute above
+        self.direct_max_rows = 8192      # preonly/lu: dense LU up to this many rows (the library's limit), the Krylov substitute above
         self.info = None
         self._symmetric = None
 
