@@ -320,6 +320,95 @@ __global__ void __launch_bounds__(256) sellp_spmv_kernel(const int64_t* __restri
   }
 }
 
+// The same product straight from the CSR value array (no SELL image): one wave per 64 consecutive rows.  Their CSR entries are ONE
+// contiguous run (<= 64 W doubles): it is read with fully coalesced loads (lane l takes the entries 64 j + l), parked in LDS, and
+// every lane then walks its own row there (row offsets differ by the row length: odd for the 27-point stencil, i.e. free of bank
+// conflicts).  The gathers of x depend only on the column pattern, not on the values: they are issued together with the value loads.
+// Traffic = 8 B per stored entry (no slice padding) + 4 B pattern id + x, y per row.
+constexpr int CSRL_WAVES = 4;   // waves per workgroup (LDS: W x 512 B per wave): two workgroups = eight waves per CU measured best
+template <int W, bool DOT>
+__global__ void __launch_bounds__(64 * CSRL_WAVES) csrl_spmv_kernel(const int32_t* __restrict__ rowptr, const int32_t* __restrict__ pid,
+                                                                    const int32_t* __restrict__ tab, int npat, const double* __restrict__ val,
+                                                                    const double* __restrict__ x, double* __restrict__ y, int64_t n_rows,
+                                                                    int64_t n_slices, const int* __restrict__ flag, double* __restrict__ part,
+                                                                    int64_t s_begin, int part_off, int64_t hole_begin, int64_t hole_len) {
+  extern __shared__ double csrl_lds[];   // [CSRL_WAVES][64 W] values | [(npat + 1)][PAT_W] pattern table
+  __shared__ double smd[CSRL_WAVES];
+  if (flag && flag[0]) return;
+  int32_t* ltab = reinterpret_cast<int32_t*>(csrl_lds + CSRL_WAVES * 64 * W);
+  for (int i = threadIdx.x; i < (npat + 1) * PAT_W; i += 64 * CSRL_WAVES) ltab[i] = i < npat * PAT_W ? tab[i] : 0;
+  __syncthreads();
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  double* __restrict__ buf = csrl_lds + wv * 64 * W;
+  const int64_t w0 = (int64_t)blockIdx.x * CSRL_WAVES + wv;
+  const int64_t nw = (int64_t)gridDim.x * CSRL_WAVES;
+  double dot = 0.0;
+  // row offsets one slice ahead: the value loads of a slice then start without a dependent load in front of them
+  int nrp0 = 0, nrp1 = 0;
+  {
+    const int64_t sq = s_begin + w0;
+    if (sq < n_slices) {
+      const int64_t r = (sq >= hole_begin ? sq + hole_len : sq) * SH + lane;
+      nrp0 = rowptr[r < n_rows ? r : n_rows];
+      nrp1 = rowptr[r < n_rows ? r + 1 : n_rows];
+    }
+  }
+  for (int64_t sq = s_begin + w0; sq < n_slices; sq += nw) {   // n_slices: logical end (hole removed)
+    const int64_t s = sq >= hole_begin ? sq + hole_len : sq;
+    const int64_t row = s * SH + lane;
+    const bool live = row < n_rows;
+    const int rp0 = nrp0, rp1 = nrp1;
+    if (sq + nw < n_slices) {
+      const int64_t r = ((sq + nw) >= hole_begin ? sq + nw + hole_len : sq + nw) * SH + lane;
+      nrp0 = rowptr[r < n_rows ? r : n_rows];
+      nrp1 = rowptr[r < n_rows ? r + 1 : n_rows];
+    }
+    const int base = __builtin_amdgcn_readfirstlane(rp0);
+    const int total = __builtin_amdgcn_readlane(rp1, 63) - base;
+    const int off = rp0 - base, len = rp1 - rp0;
+    const double* __restrict__ v = val + base;
+    // the run of the 64 rows, coalesced; zero beyond its end
+    double vr[W];
+#pragma unroll
+    for (int j = 0; j < W; ++j) vr[j] = (64 * j + lane < total) ? v[64 * j + lane] : 0.0;
+    // the row's x entries (pattern table: column = row + t[k])
+    const int32_t* __restrict__ t = ltab + (live ? pid[row] : npat) * PAT_W;
+    const int64_t rb = live ? row : 0;
+    double xg[W];
+#pragma unroll
+    for (int k = 0; k < W; ++k) xg[k] = x[rb + (k < len ? t[k] : 0)];
+#pragma unroll
+    for (int j = 0; j < W; ++j) buf[64 * j + lane] = vr[j];
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    double a0 = 0.0, a1 = 0.0;
+#pragma unroll
+    for (int k = 0; k + 1 < W; k += 2) {
+      a0 = fma(k < len ? buf[off + k] : 0.0, xg[k], a0);
+      a1 = fma(k + 1 < len ? buf[off + k + 1] : 0.0, xg[k + 1], a1);
+    }
+    if (W & 1) a0 = fma(W - 1 < len ? buf[off + W - 1] : 0.0, xg[W - 1], a0);
+    const double acc = a0 + a1;
+    if (live) {
+      y[row] = acc;
+      if (DOT) dot += acc * x[row];
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();   // every lane has read its row before the next run overwrites the buffer
+  }
+  if (DOT) {
+    dot = wsum64(dot);
+    if (lane == 0) smd[wv] = dot;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      double sm = 0.0;
+      for (int i = 0; i < CSRL_WAVES; ++i) sm += smd[i];
+      part[part_off + blockIdx.x] = sm;
+    }
+  }
+}
+
 // Block matrices: lane = scalar row (i,p); columns come from the NODE-level dictionary
 // (col = (i + off[k / BC]) * BC + k % BC) or from the explicit expanded column array.
 template <int BC, bool PAT, bool DOT>
@@ -442,6 +531,12 @@ __global__ void slice_ghost_flag_kernel(const int32_t* __restrict__ rowptr, cons
   }
 }
 
+// Scalar matrices whose rows follow the column-pattern dictionary (rows of at most PAT_W entries) are multiplied straight from their CSR
+// values (csrl_spmv_kernel): no SELL image, no refresh after an assembly.  PYNAMA_SELL_IMAGE=1 keeps the image-based kernel.
+static bool csr_product(const pyn_ctx* c, const DMat& A, const SellShape* S) {
+  return A.br == 1 && A.bc == 1 && c->sell_npat > 0 && S && S->maxw <= PAT_W && !getenv("PYNAMA_SELL_IMAGE");
+}
+
 int pyn_sell_ensure(pyn_ctx* c, DMat& A) {
   PYN_CHECK(pyn_sell_supported(A), "no SELL kernel for block shape %dx%d", A.br, A.bc);
   hipStream_t s = c->stream;
@@ -504,6 +599,14 @@ int pyn_sell_ensure(pyn_ctx* c, DMat& A) {
     c->sell_shapes.push_back(q);
     S = &c->sell_shapes.back();
     fresh = true;
+  }
+  if (csr_product(c, A, S)) {   // nothing to refresh: the product reads A.val
+    if (A.sell_val) {
+      (void)hipFree(A.sell_val);
+      A.sell_val = nullptr;
+    }
+    A.sell_valid = true;
+    return PYN_OK;
   }
   if (!A.sell_val) PYN_HIP(hipMalloc((void**)&A.sell_val, S->total * sizeof(double)));
   if (!A.sell_valid || fresh) {
@@ -588,6 +691,37 @@ int pyn_sell_spmv_range2(pyn_ctx* c, const DMat& A, const double* x, double* y, 
   }
   const int grid = (int)std::max<int64_t>(1, std::min<int64_t>((s1 - s0 + 3) / 4, max_grid));
   PYN_CHECK(poff + grid <= PYN_MAX_PARTIALS, "partial buffer overflow");
+  if (csr_product(c, A, S)) {   // straight from the CSR values
+    const int W = S->maxw <= 27 ? 27 : 32;
+    const size_t lds = (size_t)CSRL_WAVES * 64 * W * sizeof(double) + (size_t)(c->sell_npat + 1) * PAT_W * sizeof(int32_t);
+    // persistent waves: exactly the workgroups that are resident together (LDS: 160 KB per CU; 160-190 VGPRs: three / two waves per
+    // SIMD), so that every wave walks the same number of slices -- a grid of 1.6 x that capacity runs 20 % longer
+    const int per_cu = std::max(1, std::min((int)(163840 / (lds + 64)), 8 / CSRL_WAVES));   // eight waves per CU (ten: +3 %, twelve: +12 %)
+    const char* gcu = getenv("PYNAMA_CSR_SPMV_WGS_PER_CU");
+    const int resident = 256 * (gcu ? atoi(gcu) : per_cu);
+    const int gridc = (int)std::max<int64_t>(1, std::min<int64_t>(std::min<int64_t>((s1 - s0 + CSRL_WAVES - 1) / CSRL_WAVES, max_grid), resident));
+#define CSRL_LAUNCH(WW, DD)                                                                                                             \
+  do {                                                                                                                                  \
+    static bool attr = false;                                                                                                           \
+    if (!attr) {                                                                                                                        \
+      PYN_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(csrl_spmv_kernel<WW, DD>), hipFuncAttributeMaxDynamicSharedMemorySize, \
+                                  (int)(CSRL_WAVES * 64 * WW * sizeof(double) + (PAT_MAX + 1) * PAT_W * sizeof(int32_t))));             \
+      attr = true;                                                                                                                      \
+    }                                                                                                                                   \
+    csrl_spmv_kernel<WW, DD><<<gridc, 64 * CSRL_WAVES, lds, st>>>(c->d_rowptr, c->sell_pid, c->sell_tab, c->sell_npat, A.val, x, y,     \
+                                                                  c->n_owned, s1, DD ? c->d_flag : nullptr, DD ? c->d_part : nullptr,  \
+                                                                  s0, poff, hb, hl);                                                    \
+  } while (0)
+    PYN_CHECK(poff + gridc <= PYN_MAX_PARTIALS, "partial buffer overflow");
+    if (W == 27 && dot) CSRL_LAUNCH(27, true);
+    else if (W == 27) CSRL_LAUNCH(27, false);
+    else if (dot) CSRL_LAUNCH(32, true);
+    else CSRL_LAUNCH(32, false);
+#undef CSRL_LAUNCH
+    PYN_HIP(hipGetLastError());
+    if (grid_out) *grid_out = gridc;
+    return PYN_OK;
+  }
   if (A.br == 1 && A.bc == 1) {  // scalar fast paths
     if (c->sell_npat > 0) {
       const size_t lds = (size_t)(c->sell_npat + 1) * PAT_W * sizeof(int32_t);

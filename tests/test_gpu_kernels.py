@@ -1362,3 +1362,37 @@ def test_imposed_column_matrices_rewritten_only_where_needed(lib, form):
     finally:
         del os.environ["PYNAMA_RHS_FULL_WRITE"]
     ctx.close()
+
+
+@pytest.mark.parametrize("nelem", [[9, 8, 7], [3, 2, 2], [30, 5]])
+def test_csr_product_equals_sell_image_product(lib, nelem):
+    """scalar matrices that follow the column-pattern dictionary are multiplied straight from their CSR values (csrl_spmv_kernel:
+    64-row runs transposed through LDS, no SELL image, nothing to refresh after an assembly); PYNAMA_SELL_IMAGE=1 keeps the
+    image-based kernel.  Both equal scipy's product -- partial last slice, rows of every length (faces, edges, corners), CG on top."""
+    mesh = fo.box_mesh(nelem, [0.0] * len(nelem), [1.0, 0.9, 1.2][:len(nelem)], 2, jitter=0.2)
+    rng = np.random.default_rng(3)
+    xin = rng.standard_normal(mesh.n_node)
+    out = {}
+    for mode in ("csr", "image"):
+        if mode == "image":
+            os.environ["PYNAMA_SELL_IMAGE"] = "1"
+        try:
+            ctx = make_ctx(lib, mesh, 2, bc_ndof=1, bc_nodes=mesh.boundary)
+            A = ctx.mat_create(1, 1)
+            ctx.assemble_scalar(lib.FORM_LAPLACE, A, -1)
+            S = mat_to_scipy(ctx, A, 1, 1)
+            vx, vy, vb = ctx.vec_create(1), ctx.vec_create(1), ctx.vec_create(1)
+            ctx.vec_set(vx, xin)
+            b = S @ xin
+            ctx.vec_set(vb, b)
+            info = ctx.solve(A, vb, vy, rtol=1e-12, maxit=2000, norm_type=lib.NORM_UNPRECONDITIONED)   # the product inside CG
+            assert info.reason > 0 and info.true_resid < 1e-11
+            sol = ctx.vec_get(vy, 1).copy()
+            ctx.spmv(A, vx, vy)                                                                         # host-facing product
+            out[mode] = (ctx.vec_get(vy, 1).copy(), sol, info.iters)
+            assert np.abs(out[mode][0] - b).max() <= 1e-13 * np.abs(b).max()
+            ctx.close()
+        finally:
+            os.environ.pop("PYNAMA_SELL_IMAGE", None)
+    assert np.abs(out["csr"][1] - out["image"][1]).max() <= 1e-9 * np.abs(out["image"][1]).max()
+    assert abs(out["csr"][2] - out["image"][2]) <= 1
