@@ -80,6 +80,7 @@ struct DMat {
   double* val = nullptr;  // [nnzb*br*bc], layout in pynama_hip.h
   double* sell_val = nullptr;  // SELL-64 image of `val` (scalar matrices, solver side)
   bool sell_valid = false;
+  bool csr_product = false;    // scalar dictionary-mode matrix: the product reads `val` directly (csrl_spmv_kernel), there is no image (decided in pyn_sell_ensure)
   double* dinv = nullptr;      // 1 / diagonal per scalar row (Jacobi), written by the lattice assemblies in their store
   bool dinv_valid = false;     // phase, else extracted once per matrix version (pyn_dinv_ensure)
   double* lu = nullptr;        // dense LU factors of small systems (pyn_direct.hip), [n][n] row-major, multipliers in place

@@ -600,7 +600,8 @@ int pyn_sell_ensure(pyn_ctx* c, DMat& A) {
     S = &c->sell_shapes.back();
     fresh = true;
   }
-  if (csr_product(c, A, S)) {   // nothing to refresh: the product reads A.val
+  A.csr_product = csr_product(c, A, S);
+  if (A.csr_product) {   // nothing to refresh: the product reads A.val
     if (A.sell_val) {
       (void)hipFree(A.sell_val);
       A.sell_val = nullptr;
@@ -691,7 +692,7 @@ int pyn_sell_spmv_range2(pyn_ctx* c, const DMat& A, const double* x, double* y, 
   }
   const int grid = (int)std::max<int64_t>(1, std::min<int64_t>((s1 - s0 + 3) / 4, max_grid));
   PYN_CHECK(poff + grid <= PYN_MAX_PARTIALS, "partial buffer overflow");
-  if (csr_product(c, A, S)) {   // straight from the CSR values
+  if (A.csr_product) {   // straight from the CSR values (decided once per pyn_sell_ensure, not per launch)
     const int W = S->maxw <= 27 ? 27 : 32;
     const size_t lds = (size_t)CSRL_WAVES * 64 * W * sizeof(double) + (size_t)(c->sell_npat + 1) * PAT_W * sizeof(int32_t);
     // persistent waves: exactly the workgroups that are resident together (LDS: 160 KB per CU; 160-190 VGPRs: three / two waves per
