@@ -607,6 +607,7 @@ extern "C" int pyn_mat_create(pyn_ctx* c, int br, int bc, int* mat_id) {
   size_t n = (size_t)c->nnzb * br * bc;
   PYN_HIP(hipMalloc((void**)&m.val, n * sizeof(double)));
   PYN_HIP(hipMemsetAsync(m.val, 0, n * sizeof(double), c->stream));
+  if (getenv("PYNAMA_DEBUG_ALLOC")) fprintf(stderr, "[pynama] matrix %d: %zu bytes at %p\n", (int)c->mats.size(), n * sizeof(double), (void*)m.val);
   m.rhs_clean = PYN_RHS_ANY;
   m.live = true;
   c->mats.push_back(m);

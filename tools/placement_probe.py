@@ -23,6 +23,12 @@ ctx.csr_symbolic()
 b = np.random.default_rng(0).standard_normal(dom.nOwned)
 b[bm != 0] = 0
 mats, pads = [], []
+if os.environ.get("PRE_GB"):        # PRE_GB=<GiB>: a dummy device allocation of that size is made (and kept) before the first matrix
+    import ctypes
+    hip = ctypes.CDLL("libamdhip64.so")
+    dummy = ctypes.c_void_p()
+    rc = hip.hipMalloc(ctypes.byref(dummy), ctypes.c_size_t(int(float(os.environ["PRE_GB"]) * 2 ** 30)))
+    print("dummy allocation rc", rc, hex(dummy.value or 0), flush=True)
 if os.environ.get("WARM"):          # WARM=<seconds of CG before the first measured matrix>, on a matrix that is destroyed again
     import time
     A = ctx.mat_create(1, 1)
