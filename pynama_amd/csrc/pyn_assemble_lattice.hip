@@ -1184,6 +1184,61 @@ __device__ __forceinline__ void kle_lat_rows_general(const KleLatArgs& T, const 
   }
 }
 
+// loads of one element of the general-geometry KLE kernels: the eight corners and, for K, this wave's two rows {2 part, 2 part + 1} of
+// the element Laplacian integrated by kle_elem_laplace_kernel (element id = x + (nx-1)(y + (ny-1) layer)); raw loads, no arithmetic
+template <bool RW, int WHAT = 3>   // WHAT: 1 the Laplacian rows, 2 the corners, 3 both
+__device__ __forceinline__ void kle_gen_loads(const KleLatArgs& T, int part, int n00, int gx, int gy, int gl, double (&P)[2][2][2][3],
+                                              double (&Lv)[2][8]) {
+  const LatArgs& L = T.L;
+  const int nx = L.nx, ny = L.ny;
+  const double* q0 = L.xyz + (int64_t)(lat_plane(L, gl) + n00) * 3;
+  const double* qz = L.xyz + (int64_t)(lat_plane(L, gl + 1) + n00) * 3;
+  if (!RW && (WHAT & 1)) {
+    const double* Le = T.Lel + ((int64_t)gl * (ny - 1) + gy) * (nx - 1) + gx;
+#pragma unroll
+    for (int h = 0; h < 2; ++h)
+#pragma unroll
+      for (int bb = 0; bb < 8; ++bb) {
+        const int a = 2 * part + h;
+        const int lo = min(a, bb), hi = max(a, bb);
+        const int off = lo * 7 - (lo * (lo - 1)) / 2 + (hi - lo - 1);     // q1_off(lo, hi)
+        Lv[h][bb] = a == bb ? 0.0 : Le[(int64_t)off * T.ne];
+      }
+  }
+  if (WHAT & 2) {
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int cc = 0; cc < 3; ++cc) {
+          P[0][j][i][cc] = q0[(j * nx + i) * 3 + cc];
+          P[1][j][i][cc] = qz[(j * nx + i) * 3 + cc];
+        }
+  }
+}
+
+// wave `part` adds the node rows (K) / node columns (Rw) {2 part, 2 part + 1} of its element
+template <int TX, int TY, int TZ, bool RW>
+__device__ __forceinline__ void kle_gen_dispatch(const KleLatArgs& T, int part, const double (&C)[2][2][2][3], const double (&Lv)[2][8], int lx,
+                                                 int ly, int lz, int z0, double* acc) {
+  if (RW && KLE_RW_M_OUTER) {
+    switch (part) {
+      case 0: kle_lat_rw_general_m<TX, TY, TZ, 0>(T, C, lx, ly, lz, z0, acc); break;
+      case 1: kle_lat_rw_general_m<TX, TY, TZ, 2>(T, C, lx, ly, lz, z0, acc); break;
+      case 2: kle_lat_rw_general_m<TX, TY, TZ, 4>(T, C, lx, ly, lz, z0, acc); break;
+      default: kle_lat_rw_general_m<TX, TY, TZ, 6>(T, C, lx, ly, lz, z0, acc); break;
+    }
+    return;
+  }
+  switch (part) {
+    case 0: kle_lat_rows_general<TX, TY, TZ, RW, 0>(T, C, Lv, lx, ly, lz, z0, acc); break;
+    case 1: kle_lat_rows_general<TX, TY, TZ, RW, 2>(T, C, Lv, lx, ly, lz, z0, acc); break;
+    case 2: kle_lat_rows_general<TX, TY, TZ, RW, 4>(T, C, Lv, lx, ly, lz, z0, acc); break;
+    default: kle_lat_rows_general<TX, TY, TZ, RW, 6>(T, C, Lv, lx, ly, lz, z0, acc); break;
+  }
+}
+
 template <int TX, int TY, int TZ, bool RW, bool GEN>
 __global__ void __launch_bounds__(256, GEN && RW && !KLE_RW_M_OUTER ? 2 : 3) assemble_q1_hex_kle_lattice_kernel(KleLatArgs T) {
   using LT = LatTile<TX, TY, TZ>;
@@ -1201,12 +1256,33 @@ __global__ void __launch_bounds__(256, GEN && RW && !KLE_RW_M_OUTER ? 2 : 3) ass
   const int nx = L.nx, ny = L.ny;
   LatMeta<TX, TY, TZ, 256> meta;
   lat_meta_load<TX, TY, TZ, 256, 3>(L, x0, y0, z0, tid, meta);
+  // the loads of a lane's FIRST element (for 3 x 3 x 3 tiles: its only one) are requested before the 52 KB of accumulators are cleared:
+  // their latency overlaps the clearing and its barrier instead of following it
+  // (not for K with general geometry: that kernel sits at its register limit for three workgroups per CU; with the loads hoisted it
+  // spills and runs 14 % longer)
+  constexpr bool EARLY = !(GEN && !RW);
+  double P[2][2][2][3], Lv[2][8], C4[4][3];
+  bool pre_ok = false;
+  if (EARLY && L.ablate != 1) {
+    const int t = lane;
+    const int lx = t % LT::EX, ly = (t / LT::EX) % LT::EY, lz = t / (LT::EX * LT::EY);
+    const int gx = x0 - 1 + lx, gy = y0 - 1 + ly, gl = L.p_own0 + z0 - 1 + lz;
+    pre_ok = t < LT::NE && gx >= 0 && gx < nx - 1 && gy >= 0 && gy < ny - 1 && gl >= 0 && gl < L.npl - 1;
+    if (pre_ok) {
+      const int n00 = gy * nx + gx;
+      if (GEN) {
+        kle_gen_loads<RW>(T, part, n00, gx, gy, gl, P, Lv);
+      } else {
+        lat_affine_corners(L, n00, gl, C4);
+      }
+    }
+  }
   for (int i = tid; i < ACC; i += 256) acc[i] = 0.0;
   __syncthreads();
 
   const double* __restrict__ S = L.q.aff + 248;
   // ---- general geometry: every wave sees the same elements (lane = element)
-  for (int t = lane; GEN && t < LT::NE && L.ablate != 1; t += 64) {
+  for (int t = lane; GEN && !RW && t < LT::NE && L.ablate != 1; t += 64) {   // K: loads where they are needed (see EARLY)
     const int lx = t % LT::EX, ly = (t / LT::EX) % LT::EY, lz = t / (LT::EX * LT::EY);
     const int gx = x0 - 1 + lx, gy = y0 - 1 + ly, gl = L.p_own0 + z0 - 1 + lz;
     if (gx < 0 || gx >= nx - 1 || gy < 0 || gy >= ny - 1 || gl < 0 || gl >= L.npl - 1) continue;
@@ -1255,21 +1331,34 @@ __global__ void __launch_bounds__(256, GEN && RW && !KLE_RW_M_OUTER ? 2 : 3) ass
       default: kle_lat_rows_general<TX, TY, TZ, RW, 6>(T, C, Lv, lx, ly, lz, z0, acc); break;
     }
   }
+  for (int t = lane; GEN && RW && t < LT::NE && L.ablate != 1; t += 64) {
+    const int lx = t % LT::EX, ly = (t / LT::EX) % LT::EY, lz = t / (LT::EX * LT::EY);
+    const int gx = x0 - 1 + lx, gy = y0 - 1 + ly, gl = L.p_own0 + z0 - 1 + lz;
+    if (gx < 0 || gx >= nx - 1 || gy < 0 || gy >= ny - 1 || gl < 0 || gl >= L.npl - 1) continue;
+    const int n00 = gy * nx + gx;
+    if (!EARLY) {   // K: loads where they are needed, in locals of their own (hoisted state costs this kernel its third workgroup per CU)
+      double Pl[2][2][2][3], Lvl[2][8], C[2][2][2][3];
+      kle_gen_loads<RW>(T, part, n00, gx, gy, gl, Pl, Lvl);
+      q1_haar_coeffs(Pl, C);
+      kle_gen_dispatch<TX, TY, TZ, RW>(T, part, C, Lvl, lx, ly, lz, z0, acc);
+    } else {
+      double C[2][2][2][3];
+      if (t != lane) kle_gen_loads<RW>(T, part, n00, gx, gy, gl, P, Lv);   // (later elements of the lane: tiles with more than 64 elements)
+      q1_haar_coeffs(P, C);
+      kle_gen_dispatch<TX, TY, TZ, RW>(T, part, C, Lv, lx, ly, lz, z0, acc);
+    }
+  }
   for (int t = lane; !GEN && t < LT::NE && L.ablate != 1; t += 64) {
     const int lx = t % LT::EX, ly = (t / LT::EX) % LT::EY, lz = t / (LT::EX * LT::EY);
     const int gx = x0 - 1 + lx, gy = y0 - 1 + ly, gl = L.p_own0 + z0 - 1 + lz;
     if (gx < 0 || gx >= nx - 1 || gy < 0 || gy >= ny - 1 || gl < 0 || gl >= L.npl - 1) continue;
     const int n00 = gy * nx + gx;
-    const double* q0 = L.xyz + (int64_t)(lat_plane(L, gl) + n00) * 3;
-    const double* qz = L.xyz + (int64_t)(lat_plane(L, gl + 1) + n00) * 3;
+    if (t != lane) lat_affine_corners(L, n00, gl, C4);
     double E[3][3];
 #pragma unroll
-    for (int x = 0; x < 3; ++x) {
-      const double o = q0[x];
-      E[0][x] = q0[3 + x] - o;
-      E[1][x] = q0[3 * nx + x] - o;
-      E[2][x] = qz[x] - o;
-    }
+    for (int d = 0; d < 3; ++d)
+#pragma unroll
+      for (int x = 0; x < 3; ++x) E[d][x] = C4[d + 1][x] - C4[0][x];
     double J[3][3];
 #pragma unroll
     for (int d = 0; d < 3; ++d)
