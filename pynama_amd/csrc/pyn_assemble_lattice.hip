@@ -1258,11 +1258,18 @@ __global__ void __launch_bounds__(256, GEN && RW && !KLE_RW_M_OUTER ? 2 : 3) ass
   lat_meta_load<TX, TY, TZ, 256, 3>(L, x0, y0, z0, tid, meta);
   // the loads of a lane's FIRST element (for 3 x 3 x 3 tiles: its only one) are requested before the 52 KB of accumulators are cleared:
   // their latency overlaps the clearing and its barrier instead of following it
-  // (not for K with general geometry: that kernel sits at its register limit for three workgroups per CU; with the loads hoisted it
-  // spills and runs 14 % longer)
+  // (K with general geometry keeps its own loop below: routed through the shared helpers its code lands on 168 VGPRs + spills and
+  // runs 14 % longer; written out in place it needs 108)
   constexpr bool EARLY = !(GEN && !RW);
   double P[2][2][2][3], Lv[2][8], C4[4][3];
   bool pre_ok = false;
+  if (!EARLY && L.ablate != 1) {   // K, general geometry: this wave's 14 Laplacian entries and the eight corners
+    const int t = lane;
+    const int lx = t % LT::EX, ly = (t / LT::EX) % LT::EY, lz = t / (LT::EX * LT::EY);
+    const int gx = x0 - 1 + lx, gy = y0 - 1 + ly, gl = L.p_own0 + z0 - 1 + lz;
+    if (t < LT::NE && gx >= 0 && gx < nx - 1 && gy >= 0 && gy < ny - 1 && gl >= 0 && gl < L.npl - 1)
+      kle_gen_loads<RW, 3>(T, part, gy * nx + gx, gx, gy, gl, P, Lv);
+  }
   if (EARLY && L.ablate != 1) {
     const int t = lane;
     const int lx = t % LT::EX, ly = (t / LT::EX) % LT::EY, lz = t / (LT::EX * LT::EY);
@@ -1282,7 +1289,7 @@ __global__ void __launch_bounds__(256, GEN && RW && !KLE_RW_M_OUTER ? 2 : 3) ass
 
   const double* __restrict__ S = L.q.aff + 248;
   // ---- general geometry: every wave sees the same elements (lane = element)
-  for (int t = lane; GEN && !RW && t < LT::NE && L.ablate != 1; t += 64) {   // K: loads where they are needed (see EARLY)
+  for (int t = lane; GEN && !RW && t < LT::NE && L.ablate != 1; t += 64) {   // K (see EARLY)
     const int lx = t % LT::EX, ly = (t / LT::EX) % LT::EY, lz = t / (LT::EX * LT::EY);
     const int gx = x0 - 1 + lx, gy = y0 - 1 + ly, gl = L.p_own0 + z0 - 1 + lz;
     if (gx < 0 || gx >= nx - 1 || gy < 0 || gy >= ny - 1 || gl < 0 || gl >= L.npl - 1) continue;
@@ -1291,8 +1298,7 @@ __global__ void __launch_bounds__(256, GEN && RW && !KLE_RW_M_OUTER ? 2 : 3) ass
     const double* qz = L.xyz + (int64_t)(lat_plane(L, gl + 1) + n00) * 3;
     // K: the element's Laplacian entries were integrated once by kle_elem_laplace_kernel (element id = x + (nx-1)(y + (ny-1) layer));
     // this wave's two rows {2 part, 2 part + 1}, requested together with the corner coordinates (one memory latency, not two)
-    double Lv[2][8];
-    if (!RW) {
+    if (!RW && t != lane) {   // (the lane's first element: requested before the accumulators were cleared)
       const double* Le = T.Lel + ((int64_t)gl * (ny - 1) + gy) * (nx - 1) + gx;
 #pragma unroll
       for (int h = 0; h < 2; ++h)
@@ -1304,16 +1310,18 @@ __global__ void __launch_bounds__(256, GEN && RW && !KLE_RW_M_OUTER ? 2 : 3) ass
           Lv[h][bb] = a == bb ? 0.0 : Le[(int64_t)off * T.ne];
         }
     }
-    double P[2][2][2][3], C[2][2][2][3];
+    double C[2][2][2][3];
+    if (t != lane) {
 #pragma unroll
-    for (int j = 0; j < 2; ++j)
+      for (int j = 0; j < 2; ++j)
 #pragma unroll
-      for (int i = 0; i < 2; ++i)
+        for (int i = 0; i < 2; ++i)
 #pragma unroll
-        for (int cc = 0; cc < 3; ++cc) {
-          P[0][j][i][cc] = q0[(j * nx + i) * 3 + cc];
-          P[1][j][i][cc] = qz[(j * nx + i) * 3 + cc];
-        }
+          for (int cc = 0; cc < 3; ++cc) {
+            P[0][j][i][cc] = q0[(j * nx + i) * 3 + cc];
+            P[1][j][i][cc] = qz[(j * nx + i) * 3 + cc];
+          }
+    }
     q1_haar_coeffs(P, C);
     if (RW && KLE_RW_M_OUTER) {
       switch (part) {
