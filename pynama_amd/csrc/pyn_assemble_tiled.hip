@@ -422,6 +422,14 @@ __global__ void __launch_bounds__(TILE_THREADS, 3) assemble_p1_tet_tiled_kernel(
   int* rmeta = reinterpret_cast<int*>(acc + (size_t)T.maxrows * ml);
   unsigned* cflag = reinterpret_cast<unsigned*>(rmeta + 2 * T.maxrows);
   const int tid = threadIdx.x;
+  // element id -> node ids -> coordinates is a chain of three dependent loads: the first two hops run ONE element ahead (the first
+  // element's before the accumulators are cleared), so that an iteration starts with its node ids in registers
+  int e_nx = 0;
+  int4 cn_nx = make_int4(0, 0, 0, 0);
+  if (tid < ne) {
+    e_nx = T.p_elem[(int64_t)e_lo + tid];
+    cn_nx = reinterpret_cast<const int4*>(T.conn)[e_nx];
+  }
   for (int i = tid; i < nrows * ml; i += TILE_THREADS) acc[i] = 0.0;
   for (int sl = tid; sl < nrows; sl += TILE_THREADS) {
     cflag[sl] = 0u;
@@ -434,8 +442,11 @@ __global__ void __launch_bounds__(TILE_THREADS, 3) assemble_p1_tet_tiled_kernel(
   const double* __restrict__ hr = T.hrs;   // [3][4] reference gradients (constant over the element)
   for (int t = tid; t < ne; t += TILE_THREADS) {
     const int64_t pe = (int64_t)e_lo + t;
-    const int e = T.p_elem[pe];
-    const int4 cn = reinterpret_cast<const int4*>(T.conn)[e];
+    const int4 cn = cn_nx;
+    if (t + TILE_THREADS < ne) {
+      e_nx = T.p_elem[pe + TILE_THREADS];
+      cn_nx = reinterpret_cast<const int4*>(T.conn)[e_nx];
+    }
     const int nd[4] = {cn.x, cn.y, cn.z, cn.w};
     double X[4][3];
 #pragma unroll
