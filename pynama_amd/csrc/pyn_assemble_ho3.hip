@@ -1,0 +1,823 @@
+// Second-order elements (ngl = 3: 9-node quadrilaterals, 27-node hexahedra) on structured meshes: atomics-free assembly of the KLE
+// matrices -- the element order every case of the reference runs (src/cases/*.yaml: `ngl: 3`; Spectral picks Gauss(3)^dim and
+// Gauss(2)^dim there, src/elements/spectral.py:41-43).
+//
+// Reference: Spectral.getElemKLEMatrices (src/elements/spectral.py:89-157) per cell inside FreeSlip.buildKLEMats
+// (src/cases/base_problem.py:499-552), Mat.setIndices2One (src/matrices/mat_generator.py:113-118).
+//
+// Why not the LDS tiles of the Q1 kernels: a vertex row of the 3-D K has 125 neighbours x 9 values = 9 KB, a tile of rows does
+// not fit the LDS.  Instead a workgroup owns a RUN of consecutive node rows of one x-line -- one contiguous piece of every
+// block-CSR value array -- keeps exactly that piece in LDS, and enumerates the (row, element, column node) triples that feed it:
+// 729 (3-D) / 81 (2-D) per element, each computed by ONE lane of ONE workgroup, so nothing is integrated twice.  Rows of a line
+// alternate between two classes (even / odd x), lines come in 2^(dim-1) classes (parity of y, z): one launch per line class, its
+// LDS sized for that class.  `ds_add_f64` sums the <= 8 element contributions of an entry; the piece leaves as one coalesced
+// copy, with the Dirichlet routing K / Krhs / unit diagonal applied on the way out in runs that touch an imposed DOF.
+//
+// Element matrices: on a parallelogram / parallelepiped J is constant, so
+//   sum_g w_g detJ (J^-1 Hrs_g)^T (J^-1 Hrs_g) = detJ J^-1 [ sum_g w_g Hrs_g Hrs_g^T ] J^-T     (an identity, any rule)
+// and every block is a contraction of the per-element J^-1 (pre-pass, 80 B per element) with reference matrices computed ONCE
+// from the uploaded tables (pyn_ho3_tables):  with Y_pq = sum_rs Ji_pr Ji_qs Tr_rs[a][b],  Q = Ji^T Ji,
+//   K [(a,p),(b,q)] = detJ ( alpha_d Y_pq - alpha_w Y_qp ) + d_pq detJ ( sum_rs Q_rs Tf_rs[a][b] + alpha_w tr Y )
+//   Rw[(a,p),(b,k)] = detJ sum_{(p,k,d,s) in curl_w} s Ji_d. Uf_.[a][b] + alpha_w detJ sum_{(k,p,d,s) in curl_v} s Ji_d. Ur_.[b][a]
+// (spectral.py:124-156 written out; checked against the oracle's quadrature loop).  Meshes with a non-affine element keep the
+// generic workgroup-per-element kernel.
+#include <hipcub/hipcub.hpp>
+
+#include <algorithm>
+
+#include "pyn_internal.h"
+
+namespace {
+
+// lattice offset (x, y[, z]) in {0, 1, 2} of local node a: the reference's vertex / edge / face / interior order
+// (spectral.py:346-431, fixture tests/golden/g2_tables.npz `order_*`); 2-D carries the x ~ -r, y ~ -s flip of SURVEY.md A.2
+constexpr int LOC2[9][2] = {{0, 0}, {2, 0}, {2, 2}, {0, 2}, {1, 0}, {2, 1}, {1, 2}, {0, 1}, {1, 1}};
+constexpr int LOC3[27][3] = {{0, 0, 0}, {0, 2, 0}, {2, 2, 0}, {2, 0, 0}, {0, 0, 2}, {2, 0, 2}, {2, 2, 2}, {0, 2, 2}, {0, 1, 0},
+                             {1, 2, 0}, {2, 1, 0}, {1, 0, 0}, {1, 0, 2}, {2, 1, 2}, {1, 2, 2}, {0, 1, 2}, {2, 0, 1}, {0, 0, 1},
+                             {0, 2, 1}, {2, 2, 1}, {1, 1, 0}, {1, 1, 2}, {1, 0, 1}, {1, 2, 1}, {2, 1, 1}, {0, 1, 1}, {1, 1, 1}};
+
+inline int tens_of(int dim, int a) {
+  return dim == 2 ? LOC2[a][1] * 3 + LOC2[a][0] : (LOC3[a][2] * 3 + LOC3[a][1]) * 3 + LOC3[a][0];
+}
+
+enum { M_K = 0, M_RW = 1, M_LAP = 2 };
+
+struct Ho3Args {
+  int EX, EY, EZ, NX, NY, npl, p_own0, n_own;
+  const int32_t* P;
+  const int32_t* rowptr;
+  const uint8_t* nbits;   // per local node: bit p = DOF p imposed; null = nothing imposed
+  const double* geom;     // [n_elem][GS]
+  const double* tabs;
+  double alpha_d, alpha_w;
+  double* A;
+  double* Arhs;
+  int rhs_clean;          // Arhs holds zeros wherever this Dirichlet set leaves zeros: runs without an imposed DOF skip it
+  int par_y, par_z;       // class of the x-lines of this launch (parity of the local y / z index)
+  int nruns, nly;         // runs per x-line, lines of this class per plane (3-D)
+  int so0;                // first owned plane (3-D) / line (2-D), as an owned index, whose local index has the parity of the class
+  int img_len;            // doubles of LDS behind the kernel
+};
+
+__device__ __forceinline__ void axis_range(int c, int N, int& lo, int& n) {
+  const int h = (c & 1) ? 1 : 2;
+  lo = max(0, c - h);
+  n = min(N - 1, c + h) - lo + 1;
+}
+
+// exact k / n for 0 <= k < 2048, n in {3, 5, 9, 15, 25}
+__device__ __forceinline__ int small_div(int k, int n) { return (k * (65536 / n + 1)) >> 16; }
+
+// corner cn of an element (first 2^dim local nodes) as lattice bits x | y << 1 | z << 2 -- LOC2 / LOC3 halved, spelled out for device code
+constexpr int CB2[4] = {0, 1, 3, 2};
+constexpr int CB3[8] = {0, 2, 3, 1, 4, 5, 7, 6};
+constexpr bool corner_bits_match() {
+  for (int cn = 0; cn < 4; ++cn)
+    if (CB2[cn] != ((LOC2[cn][0] >> 1) | ((LOC2[cn][1] >> 1) << 1))) return false;
+  for (int cn = 0; cn < 8; ++cn)
+    if (CB3[cn] != ((LOC3[cn][0] >> 1) | ((LOC3[cn][1] >> 1) << 1) | ((LOC3[cn][2] >> 1) << 2))) return false;
+  return true;
+}
+static_assert(corner_bits_match(), "corner tables out of step with the local node order");
+
+template <int DIM>
+__global__ void __launch_bounds__(256) ho3_geom_kernel(const int32_t* __restrict__ conn, const double* __restrict__ xyz, int64_t n_elem,
+                                                       const double* __restrict__ hcoo, double* __restrict__ geom, int* __restrict__ not_affine) {
+  constexpr int NN = DIM == 3 ? 27 : 9, NC = 1 << DIM, GS = DIM == 3 ? 10 : 6;
+  const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= n_elem) return;
+  double X[NC][DIM];
+#pragma unroll
+  for (int cn = 0; cn < NC; ++cn) {
+    const double* p = xyz + (int64_t)conn[e * NN + cn] * DIM;
+#pragma unroll
+    for (int x = 0; x < DIM; ++x) X[cn][x] = p[x];
+  }
+  // J = HrsCoo . X at the first point of the full rule (spectral.py:120); constant on a parallelepiped
+  double J[DIM * DIM], Ji[DIM * DIM];
+#pragma unroll
+  for (int r = 0; r < DIM; ++r)
+#pragma unroll
+    for (int x = 0; x < DIM; ++x) {
+      double s = 0.0;
+#pragma unroll
+      for (int cn = 0; cn < NC; ++cn) s = fma(hcoo[r * NC + cn], X[cn][x], s);
+      J[r * DIM + x] = s;
+    }
+  double det;
+  if (DIM == 2) {
+    det = J[0] * J[3] - J[1] * J[2];
+    const double rr = 1.0 / det;
+    Ji[0] = J[3] * rr;
+    Ji[1] = -J[1] * rr;
+    Ji[2] = -J[2] * rr;
+    Ji[3] = J[0] * rr;
+  } else {
+    const double c00 = J[4] * J[8] - J[5] * J[7], c01 = J[5] * J[6] - J[3] * J[8], c02 = J[3] * J[7] - J[4] * J[6];
+    det = J[0] * c00 + J[1] * c01 + J[2] * c02;
+    const double rr = 1.0 / det;
+    Ji[0] = c00 * rr;
+    Ji[1] = (J[2] * J[7] - J[1] * J[8]) * rr;
+    Ji[2] = (J[1] * J[5] - J[2] * J[4]) * rr;
+    Ji[3] = c01 * rr;
+    Ji[4] = (J[0] * J[8] - J[2] * J[6]) * rr;
+    Ji[5] = (J[2] * J[3] - J[0] * J[5]) * rr;
+    Ji[6] = c02 * rr;
+    Ji[7] = (J[1] * J[6] - J[0] * J[7]) * rr;
+    Ji[8] = (J[0] * J[4] - J[1] * J[3]) * rr;
+  }
+  double* g = geom + e * GS;
+#pragma unroll
+  for (int i = 0; i < DIM * DIM; ++i) g[i] = Ji[i];
+  g[DIM * DIM] = det;
+  if (DIM == 2) g[5] = 0.0;
+  if (not_affine) {
+    // corner cn sits at the lattice offsets LOC[cn] / 2: a parallelepiped is X_o + sum_d bit_d (X_d - X_o)
+    constexpr int cb2[4] = {0, 1, 3, 2}, cb3[8] = {0, 2, 3, 1, 4, 5, 7, 6};   // = CB2 / CB3
+    int o = 0, ax[DIM];
+    int bits[NC];
+#pragma unroll
+    for (int cn = 0; cn < NC; ++cn) bits[cn] = DIM == 2 ? cb2[cn & 3] : cb3[cn];
+#pragma unroll
+    for (int cn = 0; cn < NC; ++cn) {
+      if (bits[cn] == 0) o = cn;
+#pragma unroll
+      for (int d = 0; d < DIM; ++d)
+        if (bits[cn] == (1 << d)) ax[d] = cn;
+    }
+    double na = 0.0, h2 = 0.0;
+#pragma unroll
+    for (int cn = 0; cn < NC; ++cn)
+#pragma unroll
+      for (int x = 0; x < DIM; ++x) {
+        double pr = X[o][x];
+#pragma unroll
+        for (int d = 0; d < DIM; ++d)
+          if ((bits[cn] >> d) & 1) pr += X[ax[d]][x] - X[o][x];
+        const double df = X[cn][x] - pr;
+        na = fma(df, df, na);
+        if (bits[cn] == NC - 1) h2 = fma(X[cn][x] - X[o][x], X[cn][x] - X[o][x], h2);
+      }
+    if (!(na <= 1e-25 * h2) || !(det > 0.0)) *not_affine = 1;   // round-off of the coordinates only (as element_is_affine, pyn_q1_hex.h)
+  }
+}
+
+__global__ void ho3_pack_bits_kernel(const uint8_t* __restrict__ mask, int64_t n_node, int ndof, uint8_t* __restrict__ bits) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n_node) return;
+  int m = 0;
+  for (int p = 0; p < ndof; ++p) m |= (mask[i * ndof + p] ? 1 : 0) << p;
+  bits[i] = (uint8_t)m;
+}
+
+// one block of the element matrix of element `g` (J^-1, detJ) for the local node pair (a, b) in tensor order
+template <int DIM, int MAT>
+__device__ __forceinline__ void ho3_block(const double* __restrict__ g, const double* __restrict__ tabs, int a, int b, double alpha_d,
+                                          double alpha_w, double (&v)[3][3]) {
+  constexpr int NN = DIM == 3 ? 27 : 9, N2 = NN * NN, DD = DIM * DIM;
+  double Ji[DIM][DIM];
+#pragma unroll
+  for (int x = 0; x < DIM; ++x)
+#pragma unroll
+    for (int r = 0; r < DIM; ++r) Ji[x][r] = g[x * DIM + r];
+  const double det = g[DD];
+#pragma unroll
+  for (int p = 0; p < 3; ++p)
+#pragma unroll
+    for (int q = 0; q < 3; ++q) v[p][q] = 0.0;
+  const int ab = a * NN + b;
+  if (MAT == M_K || MAT == M_LAP) {
+    double tf[DIM][DIM];
+#pragma unroll
+    for (int r = 0; r < DIM; ++r)
+#pragma unroll
+      for (int s = 0; s < DIM; ++s) tf[r][s] = tabs[(r * DIM + s) * N2 + ab];
+    double lap = 0.0;   // sum_rs Q_rs Tf_rs, Q = Ji^T Ji
+#pragma unroll
+    for (int x = 0; x < DIM; ++x)
+#pragma unroll
+      for (int r = 0; r < DIM; ++r) {
+        double t = 0.0;
+#pragma unroll
+        for (int s = 0; s < DIM; ++s) t = fma(tf[r][s], Ji[x][s], t);
+        lap = fma(Ji[x][r], t, lap);
+      }
+    if (MAT == M_LAP) {
+      v[0][0] = det * lap;
+      return;
+    }
+    double tr[DIM][DIM];
+#pragma unroll
+    for (int r = 0; r < DIM; ++r)
+#pragma unroll
+      for (int s = 0; s < DIM; ++s) tr[r][s] = tabs[(DD + r * DIM + s) * N2 + ab];
+    double X[DIM][DIM], Y[DIM][DIM];
+#pragma unroll
+    for (int p = 0; p < DIM; ++p)
+#pragma unroll
+      for (int s = 0; s < DIM; ++s) {
+        double t = 0.0;
+#pragma unroll
+        for (int r = 0; r < DIM; ++r) t = fma(Ji[p][r], tr[r][s], t);
+        X[p][s] = t;
+      }
+    double trY = 0.0;
+#pragma unroll
+    for (int p = 0; p < DIM; ++p)
+#pragma unroll
+      for (int q = 0; q < DIM; ++q) {
+        double t = 0.0;
+#pragma unroll
+        for (int s = 0; s < DIM; ++s) t = fma(X[p][s], Ji[q][s], t);
+        Y[p][q] = t;
+        if (p == q) trY += t;
+      }
+    const double dg = det * fma(alpha_w, trY, lap);
+#pragma unroll
+    for (int p = 0; p < DIM; ++p)
+#pragma unroll
+      for (int q = 0; q < DIM; ++q) v[p][q] = det * (alpha_d * Y[p][q] - alpha_w * Y[q][p]) + (p == q ? dg : 0.0);
+  } else {
+    // Rw: gU[d] = sum_x Ji[d][x] Uf_x[a][b] (H_a grad_d N_b, full rule), gR[d] = sum_x Ji[d][x] Ur_x[b][a] (grad_d N_a H_b, reduced rule)
+    double gU[DIM], gR[DIM];
+    const int ba = b * NN + a;
+    double uf[DIM], ur[DIM];
+#pragma unroll
+    for (int x = 0; x < DIM; ++x) {
+      uf[x] = tabs[(2 * DD + x) * N2 + ab];
+      ur[x] = tabs[(2 * DD + DIM + x) * N2 + ba];
+    }
+#pragma unroll
+    for (int d = 0; d < DIM; ++d) {
+      double s0 = 0.0, s1 = 0.0;
+#pragma unroll
+      for (int x = 0; x < DIM; ++x) {
+        s0 = fma(Ji[d][x], uf[x], s0);
+        s1 = fma(Ji[d][x], ur[x], s1);
+      }
+      gU[d] = det * s0;
+      gR[d] = alpha_w * det * s1;
+    }
+    if (DIM == 2) {
+      // curl_w = [(0,0,1,+), (1,0,0,-)], curl_v = [(0,1,0,+), (0,0,1,-)]   (indWCurl / indCurl, spectral.py:26-27)
+      v[0][0] = gU[1] - gR[1];
+      v[1][0] = -gU[0] + gR[0];
+    } else {
+      // (curl w)_r = s d_d w_comp and (curl v)_r = s d_d v_comp as (r, comp, d, s): indWCurl = indCurl (spectral.py:29-32) with the
+      // alternating sign of :128-129, 147-148
+      constexpr int CURL3[6][4] = {{0, 2, 1, 1}, {0, 1, 2, -1}, {1, 0, 2, 1}, {1, 2, 0, -1}, {2, 1, 0, 1}, {2, 0, 1, -1}};
+#pragma unroll
+      for (int i = 0; i < 6; ++i) {
+        const int r = CURL3[i][0], cp = CURL3[i][1], d = CURL3[i][2];
+        const double s = (double)CURL3[i][3];
+        const double u = d == 0 ? gU[0] : (d == 1 ? gU[1] : gU[DIM - 1]);
+        const double w = d == 0 ? gR[0] : (d == 1 ? gR[1] : gR[DIM - 1]);
+        // full: row component r, column component cp; reduced: row component cp, column component r
+#pragma unroll
+        for (int p = 0; p < 3; ++p)
+#pragma unroll
+          for (int q = 0; q < 3; ++q) {
+            if (p == r && q == cp) v[p][q] += s * u;
+            if (p == cp && q == r) v[p][q] += s * w;
+          }
+      }
+    }
+  }
+}
+
+template <int DIM, int MAT, int R>
+__global__ void __launch_bounds__(256) assemble_ho3_lattice_kernel(Ho3Args T) {
+  constexpr int NN = DIM == 3 ? 27 : 9, GS = DIM == 3 ? 10 : 6;
+  constexpr int BR = MAT == M_LAP ? 1 : DIM;
+  constexpr int BC = MAT == M_K ? DIM : (MAT == M_RW ? (DIM == 3 ? 3 : 1) : 1);
+  constexpr int BB = BR * BC;
+  constexpr int BXW = R + 4, BYW = 5, BZW = DIM == 3 ? 5 : 1;
+  extern __shared__ double img[];
+  __shared__ int rowoff[R + 1];
+  __shared__ int srank[5], splane[5];   // slow axis: sorted position of neighbour plane j, and its inverse
+  __shared__ unsigned char nb[BXW * BYW * BZW];
+  const int tid = threadIdx.x;
+  int bid = blockIdx.x;
+  const int run = bid % T.nruns;
+  bid /= T.nruns;
+  const int NX = T.NX, x0 = run * R;
+  const int nrows = min(R, NX - x0);
+  int cy, cz = 0, so;   // local y / z index of the line, owned index along the slow axis
+  if (DIM == 3) {
+    const int iy = bid % T.nly;
+    so = T.so0 + 2 * (bid / T.nly);
+    cy = 2 * iy + T.par_y;
+    cz = T.p_own0 + so;
+  } else {
+    so = T.so0 + 2 * bid;
+    cy = T.p_own0 + so;
+  }
+  const int NYL = DIM == 3 ? T.NY : T.npl;   // extent of the y axis
+  int ylo, n_y, zlo = 0, n_z = 1;
+  axis_range(cy, NYL, ylo, n_y);
+  if (DIM == 3) axis_range(cz, T.npl, zlo, n_z);
+  const int slo = DIM == 3 ? zlo : ylo, n_s = DIM == 3 ? n_z : n_y;
+  const int64_t row0 = DIM == 3 ? ((int64_t)so * T.NY + cy) * NX + x0 : (int64_t)so * NX + x0;
+  const int rp0 = T.rowptr[row0];
+  if (tid <= nrows) rowoff[tid] = T.rowptr[row0 + tid] - rp0;
+  if (tid < n_s) {
+    const int pj = T.P[slo + tid];
+    int rk = 0;
+    for (int j = 0; j < n_s; ++j) rk += T.P[slo + j] < pj;
+    srank[tid] = rk;
+    splane[rk] = slo + tid;
+  }
+  // Dirichlet bits of the node box around the run
+  int any = 0;
+  if (T.nbits) {
+    for (int i = tid; i < BXW * BYW * BZW; i += 256) {
+      const int bx = i % BXW, by = (i / BXW) % BYW, bz = i / (BXW * BYW);
+      const int x = x0 - 2 + bx, y = cy - 2 + by, z = cz - 2 + bz;
+      int m = 0;
+      if (x >= 0 && x < NX && y >= 0 && y < NYL && (DIM == 2 || (z >= 0 && z < T.npl))) {
+        const int64_t id = DIM == 3 ? (int64_t)T.P[z] + (int64_t)y * NX + x : (int64_t)T.P[y] + x;
+        m = T.nbits[id];
+      }
+      nb[i] = (unsigned char)m;
+      any |= m;
+    }
+  }
+  for (int i = tid; i < T.img_len; i += 256) img[i] = 0.0;
+  const int routed = __syncthreads_or(any);
+
+  // ---- the (row, element, column node) triples of the run
+  const int ny_e = (cy & 1) ? 1 : 2, nz_e = DIM == 3 ? ((cz & 1) ? 1 : 2) : 1;
+  const int nyz = ny_e * nz_e, sh = nyz == 4 ? 2 : (nyz == 2 ? 1 : 0);
+  const int nu = ((nrows + 1) >> 1) * 3 * nyz * NN;
+  const int EYL = T.EY;
+  for (int u = tid; u < nu; u += 256) {
+    const int t0 = u / NN, b = u - t0 * NN;
+    const int yz = t0 & (nyz - 1), t1 = t0 >> sh;
+    const int pr = t1 / 3, xs = t1 - pr * 3;
+    const int cx = x0 + 2 * pr + (xs == 2);
+    const int ex = (x0 >> 1) + pr - (xs == 0);
+    if (cx >= NX || ex < 0 || ex >= T.EX) continue;
+    const int la_x = xs == 0 ? 2 : (xs == 1 ? 0 : 1);
+    const int ys = yz & (ny_e - 1), zs = ny_e == 2 ? yz >> 1 : yz;
+    int ey, la_y, ez = 0, la_z = 0;
+    if (cy & 1) {
+      ey = cy >> 1;
+      la_y = 1;
+    } else {
+      ey = (cy >> 1) - 1 + ys;
+      la_y = ys ? 0 : 2;
+    }
+    if (ey < 0 || ey >= EYL) continue;
+    if (DIM == 3) {
+      if (cz & 1) {
+        ez = cz >> 1;
+        la_z = 1;
+      } else {
+        ez = (cz >> 1) - 1 + zs;
+        la_z = zs ? 0 : 2;
+      }
+      if (ez < 0 || ez >= T.EZ) continue;
+    }
+    const int64_t e = ex + (int64_t)T.EX * (ey + (int64_t)EYL * ez);
+    const int a = (la_z * 3 + la_y) * 3 + la_x;
+    const int lbx = b % 3, lby = (b / 3) % 3, lbz = b / 9;
+    int xlo, n_x;
+    axis_range(cx, NX, xlo, n_x);
+    const int kx = 2 * ex + lbx - xlo, ky = 2 * ey + lby - ylo;
+    int k;
+    if (DIM == 3)
+      k = (srank[2 * ez + lbz - zlo] * n_y + ky) * n_x + kx;
+    else
+      k = srank[ky] * n_x + kx;
+    const int r = cx - x0;
+    const int base = rowoff[r] * BB, len = rowoff[r + 1] - rowoff[r];
+    double v[3][3];
+    ho3_block<DIM, MAT>(T.geom + e * GS, T.tabs, a, b, T.alpha_d, T.alpha_w, v);
+#pragma unroll
+    for (int p = 0; p < BR; ++p)
+#pragma unroll
+      for (int q = 0; q < BC; ++q) atomicAdd(&img[base + (p * len + k) * BC + q], v[p][q]);
+  }
+  __syncthreads();
+
+  // ---- the piece of the value array(s) this run owns
+  const int64_t gbase = (int64_t)rp0 * BB;
+  double* __restrict__ outA = T.A;
+  double* __restrict__ outR = T.Arhs;
+  if (!routed) {
+    const int total = rowoff[nrows] * BB;
+    const bool zr = outR && !T.rhs_clean;
+    for (int i = tid; i < total; i += 256) {
+      outA[gbase + i] = img[i];
+      if (zr) outR[gbase + i] = 0.0;
+    }
+    return;
+  }
+  for (int r = 0; r < nrows; ++r) {
+    const int cx = x0 + r;
+    int xlo, n_x;
+    axis_range(cx, NX, xlo, n_x);
+    const int base = rowoff[r] * BB, len = rowoff[r + 1] - rowoff[r], L1 = len * BC;
+    const int rowbits = nb[((BZW >> 1) * BYW + 2) * BXW + r + 2];
+    const int nxy = n_x * n_y;
+    for (int j = tid; j < len * BB; j += 256) {
+      const int p = BR == 1 ? 0 : (j >= L1) + (BR == 3 ? (j >= 2 * L1) : 0);
+      const int rem = j - p * L1;
+      const int k = rem / BC, q = rem - k * BC;
+      int dx, dy, dz = 0;
+      if (DIM == 3) {
+        const int kz = small_div(k, nxy), r2 = k - kz * nxy;
+        const int ky = small_div(r2, n_x);
+        dx = xlo + (r2 - ky * n_x) - cx;
+        dy = ylo + ky - cy;
+        dz = splane[kz] - cz;
+      } else {
+        const int ks = small_div(k, n_x);
+        dx = xlo + (k - ks * n_x) - cx;
+        dy = splane[ks] - cy;
+      }
+      const double v = img[base + j];
+      double va, vr;
+      if ((rowbits >> p) & 1) {   // imposed row: unit diagonal in K and Krhs (mat_generator.py:113-118), nothing in Rw
+        va = vr = (MAT != M_RW && dx == 0 && dy == 0 && dz == 0 && q == p) ? 1.0 : 0.0;
+      } else if (MAT != M_RW && ((nb[((dz + (BZW >> 1)) * BYW + dy + 2) * BXW + r + 2 + dx] >> q) & 1)) {
+        va = 0.0;                  // imposed column of a free row: -K_e[free, bc] goes to Krhs (base_problem.py:531-533)
+        vr = -v;
+      } else {
+        va = v;
+        vr = 0.0;
+      }
+      outA[gbase + base + j] = va;
+      if (MAT != M_RW && outR) outR[gbase + base + j] = vr;
+    }
+  }
+}
+
+// ---- symbolic phase in closed form: row lengths -> scan -> sorted columns
+__device__ __forceinline__ void ho3_row_coords(const Ho3Args& T, int dim, int64_t i, int& cx, int& cy, int& cz) {
+  cx = (int)(i % T.NX);
+  if (dim == 3) {
+    cy = (int)((i / T.NX) % T.NY);
+    cz = T.p_own0 + (int)(i / ((int64_t)T.NX * T.NY));
+  } else {
+    cy = T.p_own0 + (int)(i / T.NX);
+    cz = 0;
+  }
+}
+
+__global__ void ho3_rowlen_kernel(Ho3Args T, int dim, int64_t n_rows, int32_t* __restrict__ len) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i > n_rows) return;
+  if (i == n_rows) {
+    len[i] = 0;
+    return;
+  }
+  int cx, cy, cz, lo, n_x, n_y, n_z = 1;
+  ho3_row_coords(T, dim, i, cx, cy, cz);
+  axis_range(cx, T.NX, lo, n_x);
+  axis_range(cy, dim == 3 ? T.NY : T.npl, lo, n_y);
+  if (dim == 3) axis_range(cz, T.npl, lo, n_z);
+  len[i] = n_x * n_y * n_z;
+}
+
+__global__ void ho3_columns_kernel(Ho3Args T, int dim, int64_t n_rows, const int32_t* __restrict__ rowptr, int32_t* __restrict__ colidx) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n_rows) return;
+  int cx, cy, cz, xlo, ylo, zlo = 0, n_x, n_y, n_z = 1;
+  ho3_row_coords(T, dim, i, cx, cy, cz);
+  axis_range(cx, T.NX, xlo, n_x);
+  axis_range(cy, dim == 3 ? T.NY : T.npl, ylo, n_y);
+  if (dim == 3) axis_range(cz, T.npl, zlo, n_z);
+  const int slo = dim == 3 ? zlo : ylo, n_s = dim == 3 ? n_z : n_y;
+  int k = rowptr[i];
+  // planes (x-lines in 2-D) in ascending order of their first node id: selection over <= 5 candidates
+  int32_t prev = -1;
+  for (int t = 0; t < n_s; ++t) {
+    int32_t best = INT32_MAX;
+    for (int j = 0; j < n_s; ++j) {
+      const int32_t pj = T.P[slo + j];
+      if (pj > prev && pj < best) best = pj;
+    }
+    prev = best;
+    if (dim == 3) {
+      for (int y = ylo; y < ylo + n_y; ++y)
+        for (int x = xlo; x < xlo + n_x; ++x) colidx[k++] = best + y * T.NX + x;
+    } else {
+      for (int x = xlo; x < xlo + n_x; ++x) colidx[k++] = best + x;
+    }
+  }
+}
+
+void fill_lattice_args(const pyn_ctx* c, Ho3Args& T) {
+  const Ho3Lattice& L = c->ho3;
+  T.EX = L.EX;
+  T.EY = L.EY;
+  T.EZ = L.EZ;
+  T.NX = L.NX;
+  T.NY = L.NY;
+  T.npl = L.npl;
+  T.p_own0 = L.p_own0;
+  T.n_own = L.n_own;
+  T.P = L.d_P;
+  T.rowptr = c->d_rowptr;
+  T.nbits = nullptr;
+  T.geom = L.d_geom;
+  T.tabs = c->d_ho3_tabs;
+  T.alpha_d = T.alpha_w = 0.0;
+  T.A = T.Arhs = nullptr;
+  T.rhs_clean = 0;
+  T.par_y = T.par_z = 0;
+  T.nruns = T.nly = 0;
+  T.so0 = 0;
+  T.img_len = 0;
+}
+
+template <int DIM, int MAT, int R>
+int launch_ho3(pyn_ctx* c, Ho3Args T) {
+  constexpr int BR = MAT == M_LAP ? 1 : DIM;
+  constexpr int BC = MAT == M_K ? DIM : (MAT == M_RW ? (DIM == 3 ? 3 : 1) : 1);
+  const Ho3Lattice& L = c->ho3;
+  T.nruns = (L.NX + R - 1) / R;
+  static bool attr_done = false;
+  if (!attr_done) {
+    PYN_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(assemble_ho3_lattice_kernel<DIM, MAT, R>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));
+    attr_done = true;
+  }
+  for (int pz = 0; pz < (DIM == 3 ? 2 : 1); ++pz)
+    for (int py = 0; py < 2; ++py) {
+      T.par_y = py;
+      T.par_z = pz;
+      const int ps = DIM == 3 ? pz : py;                        // parity along the slow axis
+      T.so0 = ((L.p_own0 & 1) == ps) ? 0 : 1;
+      const int nslow = T.so0 < L.n_own ? (L.n_own - T.so0 + 1) / 2 : 0;
+      T.nly = DIM == 3 ? (py == 0 ? L.EY + 1 : L.EY) : 1;
+      const int64_t grid = (int64_t)T.nruns * T.nly * nslow;
+      if (grid == 0) continue;
+      PYN_CHECK(grid < (int64_t)INT32_MAX, "ngl = 3 lattice assembly: %lld workgroups", (long long)grid);
+      const int n_y = py ? 3 : 5, n_z = DIM == 3 ? (pz ? 3 : 5) : 1;
+      T.img_len = (R / 2) * (5 + 3) * n_y * n_z * BR * BC;
+      const size_t lds = (size_t)T.img_len * sizeof(double);
+      PYN_CHECK(lds <= 96 * 1024, "ngl = 3 lattice assembly: %zu B of LDS per run", lds);
+      assemble_ho3_lattice_kernel<DIM, MAT, R><<<(int)grid, 256, lds, c->stream>>>(T);
+    }
+  PYN_HIP(hipGetLastError());
+  return PYN_OK;
+}
+
+template <int DIM, int MAT>
+int launch_ho3_r(pyn_ctx* c, const Ho3Args& T) {
+  const char* e = getenv("PYNAMA_HO3_RUN");
+  const int r = e ? atoi(e) : 0;
+  if (DIM == 3) {
+    if (r == 2) return launch_ho3<DIM, MAT, 2>(c, T);
+    if (r == 8) return launch_ho3<DIM, MAT, 8>(c, T);
+    return launch_ho3<DIM, MAT, 4>(c, T);
+  }
+  if (r == 16) return launch_ho3<DIM, MAT, 16>(c, T);
+  if (r == 64) return launch_ho3<DIM, MAT, 64>(c, T);
+  return launch_ho3<DIM, MAT, 32>(c, T);
+}
+
+}  // namespace
+
+void pyn_ho3_release(pyn_ctx* c) {
+  Ho3Lattice& L = c->ho3;
+  (void)hipFree(L.d_P);
+  (void)hipFree(L.d_geom);
+  (void)hipFree(L.d_nbits);
+  L = Ho3Lattice();
+}
+
+// Is the connectivity that of a structured ngl = 3 mesh (the reference's box mesh, src/domain/dmplex.py:8-21, 42-61, or a rank's
+// slab of one)?  Host, once per pyn_mesh_set; every entry of `conn` is checked against the closed form the kernels use.
+int pyn_ho3_detect(pyn_ctx* c, const int32_t* conn) {
+  pyn_ho3_release(c);
+  const int dim = c->dim, nn = c->nn;
+  if (!((dim == 2 && nn == 9) || (dim == 3 && nn == 27)) || c->n_elem < 1 || getenv("PYNAMA_NO_HO3")) return PYN_OK;
+  int a_of[27];
+  for (int a = 0; a < nn; ++a) a_of[tens_of(dim, a)] = a;
+  const int a0 = a_of[0];
+  const int64_t ne = c->n_elem;
+  int64_t EX = 1;
+  while (EX < ne && conn[EX * nn + a0] == conn[a0] + 2 * EX) ++EX;
+  if (ne % EX) return PYN_OK;
+  const int64_t NX = 2 * EX + 1;
+  int64_t EY, EZ = 0, NY = 0, PS, EL;   // EL: element layers along the slow axis
+  if (dim == 3) {
+    EY = 1;
+    while (EY * EX < ne && conn[EY * EX * nn + a0] == conn[a0] + 2 * EY * NX) ++EY;
+    if ((ne / EX) % EY) return PYN_OK;
+    EZ = ne / (EX * EY);
+    NY = 2 * EY + 1;
+    PS = NX * NY;
+    EL = EZ;
+  } else {
+    EY = ne / EX;
+    PS = NX;
+    EL = EY;
+  }
+  const int64_t npl = 2 * EL + 1;
+  if (PS * npl != c->n_node || PS > INT32_MAX / 4) return PYN_OK;
+  std::vector<int32_t> P((size_t)npl, -1);
+  const int64_t per_layer = ne / EL;
+  for (int64_t l = 0; l < EL; ++l)
+    for (int j = 0; j < 3; ++j) {
+      const int t = dim == 3 ? j * 9 : j * 3;
+      const int32_t base = conn[l * per_layer * nn + a_of[t]];
+      if (P[2 * l + j] >= 0 && P[2 * l + j] != base) return PYN_OK;
+      P[2 * l + j] = base;
+    }
+  for (int64_t e = 0; e < ne; ++e) {
+    const int64_t ex = e % EX, ey = dim == 3 ? (e / EX) % EY : 0, el = e / per_layer;
+    const int32_t* q = conn + e * nn;
+    for (int a = 0; a < nn; ++a) {
+      int64_t id;
+      if (dim == 3)
+        id = (int64_t)P[2 * el + LOC3[a][2]] + (2 * ey + LOC3[a][1]) * NX + 2 * ex + LOC3[a][0];
+      else
+        id = (int64_t)P[2 * el + LOC2[a][1]] + 2 * ex + LOC2[a][0];
+      if (q[a] != id) return PYN_OK;
+    }
+  }
+  std::vector<int32_t> sorted(P);
+  std::sort(sorted.begin(), sorted.end());
+  for (int64_t j = 0; j < npl; ++j)
+    if (sorted[j] != j * PS) return PYN_OK;
+  if (c->n_owned % PS) return PYN_OK;
+  const int n_own = (int)(c->n_owned / PS);
+  int p0 = -1;
+  for (int64_t j = 0; j < npl; ++j)
+    if (P[j] == 0) p0 = (int)j;
+  if (p0 < 0 || p0 + n_own > npl || n_own < 1) return PYN_OK;
+  for (int j = 0; j < n_own; ++j)
+    if (P[p0 + j] != (int64_t)j * PS) return PYN_OK;
+  Ho3Lattice& L = c->ho3;
+  PYN_HIP(hipMalloc((void**)&L.d_P, npl * sizeof(int32_t)));
+  PYN_HIP(hipMemcpy(L.d_P, P.data(), npl * sizeof(int32_t), hipMemcpyHostToDevice));
+  L.P = P;
+  L.dim = dim;
+  L.EX = (int)EX;
+  L.EY = (int)EY;
+  L.EZ = (int)EZ;
+  L.NX = (int)NX;
+  L.NY = (int)NY;
+  L.npl = (int)npl;
+  L.p_own0 = p0;
+  L.n_own = n_own;
+  L.valid = true;
+  return PYN_OK;
+}
+
+// Reference matrices of the ngl = 3 element from one uploaded rule (pyn_elem_tables_set), in tensor order
+int pyn_ho3_tables(pyn_ctx* c, int which, int ngp, const double* w, const double* H, const double* Hrs) {
+  const int dim = c->dim, nn = c->nn;
+  if (which != PYN_Q_FULL && which != PYN_Q_RED) return PYN_OK;
+  if (!((dim == 2 && nn == 9) || (dim == 3 && nn == 27))) return PYN_OK;
+  const int dd = dim * dim, n2 = nn * nn;
+  const size_t total = (size_t)(2 * dd + 2 * dim) * n2;
+  if (c->ho3_tabs_nn != nn) {
+    (void)hipFree(c->d_ho3_tabs);
+    c->d_ho3_tabs = nullptr;
+    c->ho3_tabs_ok[0] = c->ho3_tabs_ok[1] = false;
+    PYN_HIP(hipMalloc((void**)&c->d_ho3_tabs, total * sizeof(double)));
+    c->ho3_tabs_nn = nn;
+  }
+  std::vector<double> T((size_t)dd * n2), U((size_t)dim * n2);
+  for (int a = 0; a < nn; ++a)
+    for (int b = 0; b < nn; ++b) {
+      const int ta = tens_of(dim, a), tb = tens_of(dim, b);
+      for (int r = 0; r < dim; ++r) {
+        for (int s = 0; s < dim; ++s) {
+          double acc = 0.0;
+          for (int g = 0; g < ngp; ++g) acc += w[g] * Hrs[((size_t)g * dim + r) * nn + a] * Hrs[((size_t)g * dim + s) * nn + b];
+          T[(size_t)(r * dim + s) * n2 + ta * nn + tb] = acc;
+        }
+        double acc = 0.0;
+        for (int g = 0; g < ngp; ++g) acc += w[g] * H[(size_t)g * nn + a] * Hrs[((size_t)g * dim + r) * nn + b];
+        U[(size_t)r * n2 + ta * nn + tb] = acc;
+      }
+    }
+  const size_t offT = which == PYN_Q_FULL ? 0 : (size_t)dd * n2;
+  const size_t offU = (size_t)2 * dd * n2 + (which == PYN_Q_FULL ? 0 : (size_t)dim * n2);
+  PYN_HIP(hipMemcpyAsync(c->d_ho3_tabs + offT, T.data(), T.size() * sizeof(double), hipMemcpyHostToDevice, c->stream));
+  PYN_HIP(hipMemcpyAsync(c->d_ho3_tabs + offU, U.data(), U.size() * sizeof(double), hipMemcpyHostToDevice, c->stream));
+  PYN_HIP(hipStreamSynchronize(c->stream));
+  c->ho3_tabs_ok[which] = true;
+  return PYN_OK;
+}
+
+int pyn_ho3_symbolic(pyn_ctx* c, bool* done) {
+  *done = false;
+  const Ho3Lattice& L = c->ho3;
+  if (!L.valid || getenv("PYNAMA_NO_HO3_SYMBOLIC")) return PYN_OK;
+  hipStream_t s = c->stream;
+  Ho3Args T;
+  fill_lattice_args(c, T);
+  const int64_t n = c->n_owned;
+  DevTmp tlen, tmp;
+  PYN_HIP(tlen.alloc((n + 1) * sizeof(int32_t)));
+  (void)hipFree(c->d_rowptr);
+  (void)hipFree(c->d_colidx);
+  c->d_rowptr = nullptr;
+  c->d_colidx = nullptr;
+  c->nnzb = 0;
+  PYN_HIP(hipMalloc((void**)&c->d_rowptr, (n + 1) * sizeof(int32_t)));
+  const int grid = (int)((n + 1 + 255) / 256);
+  ho3_rowlen_kernel<<<grid, 256, 0, s>>>(T, L.dim, n, tlen.as<int32_t>());
+  // the total must fit the int32 CSR before the scan wraps: the interior count bounds it
+  const double est = (double)c->n_elem * (L.dim == 3 ? 512.0 : 64.0);
+  PYN_CHECK(est < 2.0e9, "pattern has about %.3g entries (int32 CSR limit)", est);
+  size_t tb = 0;
+  PYN_HIP(hipcub::DeviceScan::ExclusiveSum(nullptr, tb, tlen.as<int32_t>(), c->d_rowptr, (int)(n + 1), s));
+  PYN_HIP(tmp.alloc(tb));
+  PYN_HIP(hipcub::DeviceScan::ExclusiveSum(tmp.p, tb, tlen.as<int32_t>(), c->d_rowptr, (int)(n + 1), s));
+  int32_t nnz = 0;
+  PYN_HIP(hipMemcpyAsync(&nnz, c->d_rowptr + n, sizeof(int32_t), hipMemcpyDeviceToHost, s));
+  PYN_HIP(hipStreamSynchronize(s));
+  PYN_CHECK(nnz > 0, "empty pattern");
+  PYN_HIP(hipMalloc((void**)&c->d_colidx, (size_t)nnz * sizeof(int32_t)));
+  ho3_columns_kernel<<<(int)((n + 255) / 256), 256, 0, s>>>(T, L.dim, n, c->d_rowptr, c->d_colidx);
+  PYN_HIP(hipGetLastError());
+  c->nnzb = nnz;
+  *done = true;
+  return PYN_OK;
+}
+
+// K (+ Krhs), Rw of pyn_assemble_kle and the scalar Laplacian of pyn_assemble_scalar on a structured ngl = 3 mesh of
+// parallelograms / parallelepipeds.  *handled stays false when the mesh or the tables do not fit (the caller falls back).
+int pyn_assemble_ho3_lattice(pyn_ctx* c, int form, double alpha_d, double alpha_w, double* K, double* Krhs, double* Rw, bool* handled) {
+  *handled = false;
+  Ho3Lattice& L = c->ho3;
+  if (!L.valid || c->ho3_tabs_nn != c->nn || !c->ho3_tabs_ok[0] || c->quad[0].ngp < 1) return PYN_OK;
+  if (form == PYN_FORM_KLE && !c->ho3_tabs_ok[1]) return PYN_OK;
+  if (form != PYN_FORM_KLE && form != PYN_FORM_LAPLACE) return PYN_OK;
+  hipStream_t s = c->stream;
+  const int gs = L.dim == 3 ? 10 : 6;
+  if (!L.d_geom) PYN_HIP(hipMalloc((void**)&L.d_geom, (size_t)c->n_elem * gs * sizeof(double)));
+  const int ge = (int)((c->n_elem + 255) / 256);
+  DevTmp flag;
+  int* d_flag = nullptr;
+  if (L.affine < 0) {   // once per mesh
+    PYN_HIP(flag.alloc(sizeof(int)));
+    PYN_HIP(hipMemsetAsync(flag.p, 0, sizeof(int), s));
+    d_flag = flag.as<int>();
+  }
+  // J^-1, detJ of every element (part of the numeric phase: runs inside the timed region of every assembly)
+  if (L.dim == 3)
+    ho3_geom_kernel<3><<<ge, 256, 0, s>>>(c->d_conn, c->d_xyz, c->n_elem, c->quad[0].HrsCoo, L.d_geom, d_flag);
+  else
+    ho3_geom_kernel<2><<<ge, 256, 0, s>>>(c->d_conn, c->d_xyz, c->n_elem, c->quad[0].HrsCoo, L.d_geom, d_flag);
+  PYN_HIP(hipGetLastError());
+  if (d_flag) {
+    int h = 1;
+    PYN_HIP(hipMemcpyAsync(&h, d_flag, sizeof(int), hipMemcpyDeviceToHost, s));
+    PYN_HIP(hipStreamSynchronize(s));
+    L.affine = h ? 0 : 1;
+  }
+  if (!L.affine || getenv("PYNAMA_NO_HO3_LATTICE")) return PYN_OK;
+  Ho3Args T;
+  fill_lattice_args(c, T);
+  if (c->d_bcmask) {
+    if (L.nbits_stamp != c->bc_stamp) {
+      if (!L.d_nbits) PYN_HIP(hipMalloc((void**)&L.d_nbits, (size_t)c->n_node));
+      ho3_pack_bits_kernel<<<(int)((c->n_node + 255) / 256), 256, 0, s>>>(c->d_bcmask, c->n_node, c->bc_ndof, L.d_nbits);
+      L.nbits_stamp = c->bc_stamp;
+    }
+    T.nbits = L.d_nbits;
+  }
+  T.alpha_d = alpha_d;
+  T.alpha_w = alpha_w;
+  if (form == PYN_FORM_LAPLACE) {
+    PYN_CHECK(K, "scalar assembly without a target");
+    T.A = K;
+    T.Arhs = Krhs;
+    T.rhs_clean = c->asm_rhs_clean ? 1 : 0;
+    if (L.dim == 3)
+      PYN_TRY((launch_ho3_r<3, M_LAP>(c, T)));
+    else
+      PYN_TRY((launch_ho3_r<2, M_LAP>(c, T)));
+    *handled = true;
+    return PYN_OK;
+  }
+  if (K) {
+    T.A = K;
+    T.Arhs = Krhs;
+    T.rhs_clean = c->asm_rhs_clean ? 1 : 0;
+    if (L.dim == 3)
+      PYN_TRY((launch_ho3_r<3, M_K>(c, T)));
+    else
+      PYN_TRY((launch_ho3_r<2, M_K>(c, T)));
+  }
+  if (Rw) {
+    T.A = Rw;
+    T.Arhs = nullptr;
+    T.rhs_clean = 0;
+    if (L.dim == 3)
+      PYN_TRY((launch_ho3_r<3, M_RW>(c, T)));
+    else
+      PYN_TRY((launch_ho3_r<2, M_RW>(c, T)));
+  }
+  *handled = true;
+  return PYN_OK;
+}

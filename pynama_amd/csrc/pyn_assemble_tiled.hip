@@ -1301,6 +1301,12 @@ static int ensure_default_plan(pyn_ctx* c, int kind) {
 
 int pyn_assemble_q1_tiled(pyn_ctx* c, int form, double alpha_d, double alpha_w, double* K, double* Krhs, double* Rw, double* Rd, bool* handled) {
   *handled = false;
+  if (c->ho3.valid && !Rd && ((form == PYN_FORM_LAPLACE && K && !Rw) || (form == PYN_FORM_KLE && (K || (Rw && !Krhs))))) {
+    // second-order (ngl = 3) structured meshes: row-run kernels without atomics (pyn_assemble_ho3.hip)
+    PYN_TRY(pyn_assemble_ho3_lattice(c, form, alpha_d, alpha_w, K, Krhs, Rw, handled));
+    if (*handled) return PYN_OK;
+    PYN_CHECK(!getenv("PYNAMA_HO3_REQUIRE"), "PYNAMA_HO3_REQUIRE: the ngl = 3 lattice kernels declined this assembly (non-affine cell or tables missing)");
+  }
   if (form == PYN_FORM_LAPLACE && K && !Rw && !Rd && c->lat.valid && !c->plan[0].user) {
     PYN_TRY(pyn_assemble_lattice(c, K, Krhs, handled));
     if (*handled) return PYN_OK;

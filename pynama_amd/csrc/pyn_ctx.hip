@@ -140,6 +140,8 @@ extern "C" int pyn_ctx_destroy(pyn_ctx* c) {
   (void)hipFree(c->d_aff);
   (void)hipFree(c->lat.d_P);
   (void)hipFree(c->lat.d_zord);
+  pyn_ho3_release(c);
+  (void)hipFree(c->d_ho3_tabs);
   (void)hipFree(c->d_bcmask);
   (void)hipFree(c->d_rowptr);
   (void)hipFree(c->d_colidx);
@@ -470,6 +472,7 @@ extern "C" int pyn_mesh_set(pyn_ctx* c, int dim, int nn, int64_t n_elem, int64_t
     c->mf_set[k] = false;
   }
   PYN_TRY(pyn_lattice_detect(c, conn));
+  PYN_TRY(pyn_ho3_detect(c, conn));
   // graph + matrices depend on the mesh
   (void)hipFree(c->d_rowptr);
   (void)hipFree(c->d_colidx);
@@ -481,6 +484,13 @@ extern "C" int pyn_mesh_set(pyn_ctx* c, int dim, int nn, int64_t n_elem, int64_t
 
 extern "C" int pyn_mesh_topology(pyn_ctx* c, int* kind, int* nx, int* ny, int* nz) {
   PYN_CHECK(c && c->n_elem > 0, "pyn_mesh_set first");
+  if (c->ho3.valid) {   // second-order lattice: nodes per x-line, x-lines per plane, planes (2-D: ny = x-lines, nz = 1)
+    if (kind) *kind = 2;
+    if (nx) *nx = c->ho3.NX;
+    if (ny) *ny = c->ho3.dim == 3 ? c->ho3.NY : c->ho3.npl;
+    if (nz) *nz = c->ho3.dim == 3 ? c->ho3.npl : 1;
+    return PYN_OK;
+  }
   if (kind) *kind = c->lat.valid ? 1 : 0;
   if (nx) *nx = c->lat.nx;
   if (ny) *ny = c->lat.ny;
@@ -502,6 +512,7 @@ extern "C" int pyn_elem_tables_set(pyn_ctx* c, int which, int ngp, const double*
   PYN_TRY(dev_upload(&q.HrsCoo, HrsCoo, (size_t)ngp * c->dim * c->nc, c->stream));
   q.wsum = 0.0;
   for (int g = 0; g < ngp; ++g) q.wsum += w[g];
+  PYN_TRY(pyn_ho3_tables(c, which, ngp, w, H, Hrs));   // ngl = 3: reference matrices of the closed-form blocks
   q.const_grad = c->nc == c->nn;
   for (int g = 0; g < ngp && q.const_grad; ++g)
     for (int t = 0; t < c->dim * c->nn; ++t)

@@ -127,6 +127,24 @@ struct Lattice {
   int32_t* d_zord = nullptr;   // [npl]: count | (dz+1) codes of the z-neighbour planes sorted by node id
 };
 
+// Structured topology of a SECOND-ORDER mesh (ngl = 3: 9-node quadrilaterals / 27-node hexahedra in the reference's local order,
+// src/elements/spectral.py:346-431), the order all of the reference's cases run (src/cases/*.yaml: `ngl: 3`).  Nodes sit on the GLL
+// lattice of 2 E + 1 points per axis; the slowest axis (y in 2-D, z in 3-D) is cut into "planes" (x-lines in 2-D) whose first node
+// ids are P[j], so that a rank's slab with its ghost planes fits the same arithmetic: id = P[c_slow] + c_y NX + c_x (3-D).
+struct Ho3Lattice {
+  bool valid = false;
+  int dim = 0;
+  int EX = 0, EY = 0, EZ = 0;   // local elements per axis (2-D: EY = local element rows, EZ = 0)
+  int NX = 0, NY = 0;           // nodes per x-line; x-lines per plane (3-D)
+  int npl = 0, p_own0 = 0, n_own = 0;   // planes of the local mesh, owned ones = [p_own0, p_own0 + n_own) with ids 0 .. n_owned-1
+  int32_t* d_P = nullptr;       // [npl]
+  std::vector<int32_t> P;
+  int affine = -1;              // every element a parallelogram / parallelepiped? (-1: not checked yet)
+  double* d_geom = nullptr;     // [n_elem][6 | 10]: J^-1 (row = physical axis) and det J, rewritten by every assembly
+  uint8_t* d_nbits = nullptr;   // per local node: bit p = DOF p imposed (packed copy of d_bcmask)
+  int64_t nbits_stamp = -1;     // pyn_ctx::bc_stamp the packed copy belongs to
+};
+
 struct SellShape {
   int br = 0, bc = 0, maxw = 0;
   int64_t ns = 0, total = 0;
@@ -200,6 +218,12 @@ struct pyn_ctx {
   PatchPlan plan[2];
   bool plan_unfit[2] = {false, false};  // the automatic plan did not fit this graph (reset by pyn_csr_symbolic)
   Lattice lat;  // structured topology, if the mesh has one (plan-free assembly kernel)
+  Ho3Lattice ho3;   // ... of a second-order (ngl = 3) mesh (pyn_assemble_ho3.hip)
+  // reference matrices of the ngl = 3 element in tensor (lattice) order, from the uploaded tables (pyn_elem_tables_set):
+  // Tf / Tr[r][s][a][b] = sum_g w Hrs_r[a] Hrs_s[b] (full / reduced rule), Uf / Ur[r][a][b] = sum_g w H[a] Hrs_r[b]
+  double* d_ho3_tabs = nullptr;
+  bool ho3_tabs_ok[2] = {false, false};
+  int ho3_tabs_nn = 0;
 
   // SELL-64 structures, one per block shape, + the node-level column-pattern dictionary (pyn_sell.hip)
   std::vector<SellShape> sell_shapes;
@@ -271,3 +295,9 @@ int pyn_assemble_kle_lattice(pyn_ctx* c, double alpha_d, double alpha_w, double*
 bool pyn_q1_mixed_tables_standard(const double* w, const double* H, const double* Hrs);
 bool pyn_q1_gauss_tables_standard(const double* w, const double* H, const double* Hrs, const double* HrsCoo);   // pyn_assemble_march.hip
 int pyn_assemble_lattice_march(pyn_ctx* c, void* lat_args, int tile);   // general geometry, z-marching (pyn_assemble_march.hip)
+// second-order (ngl = 3) lattices (pyn_assemble_ho3.hip)
+int pyn_ho3_detect(pyn_ctx* c, const int32_t* conn_host);
+void pyn_ho3_release(pyn_ctx* c);
+int pyn_ho3_tables(pyn_ctx* c, int which, int ngp, const double* w, const double* H, const double* Hrs);
+int pyn_ho3_symbolic(pyn_ctx* c, bool* done);
+int pyn_assemble_ho3_lattice(pyn_ctx* c, int form, double alpha_d, double alpha_w, double* K, double* Krhs, double* Rw, bool* handled);

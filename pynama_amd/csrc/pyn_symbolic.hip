@@ -56,6 +56,7 @@ extern "C" int pyn_csr_symbolic(pyn_ctx* c) {
   PYN_HIP(hipEventRecord(c->ev0, s));
   bool arithmetic = false;   // structured topology: the graph in closed form, no sort
   PYN_TRY(pyn_lattice_symbolic(c, &arithmetic));
+  if (!arithmetic) PYN_TRY(pyn_ho3_symbolic(c, &arithmetic));
   if (arithmetic) {
     PYN_HIP(hipEventRecord(c->ev1, s));
     PYN_HIP(hipStreamSynchronize(s));

@@ -1,0 +1,308 @@
+"""GPU parity of the second-order (ngl = 3) structured path -- the element order of every case of the reference
+(src/cases/*.yaml: `ngl: 3`; rules of src/elements/spectral.py:41-43): closed-form graph, row-run assembly kernels
+(pynama_amd/csrc/pyn_assemble_ho3.hip) for K, Krhs, Rw and the scalar Laplacian, against the CPU oracle
+(oracle/fem_oracle.py), the generic atomics kernel (variant 0) and the reference's own element fixtures (tests/golden/g3_elem.npz).
+Everything goes through the C ABI (pynama_amd._lib.Context == include/pynama_hip.h)."""
+import os
+
+import numpy as np
+import pytest
+
+from oracle import fem_oracle as fo
+from tests.util import mat_to_scipy, rel_err, sp_rel_err
+
+pytestmark = pytest.mark.gpu
+
+FP_TOL = 2e-13      # relative; summation order differs from numpy (closed-form blocks, LDS adds)
+
+
+@pytest.fixture(scope="module")
+def lib():
+    from pynama_amd import _lib
+    assert _lib.device_count() > 0, "GPU tests need an MI355X"
+    return _lib
+
+
+def make_ctx(lib, mesh, mask=None, ndof=None):
+    from pynama_amd.elements.spectral import Spectral
+    ctx = lib.Context(0)
+    ctx.mesh_set(mesh.dim, mesh.conn, mesh.xyz)
+    for t in Spectral(3, mesh.dim).deviceTables():
+        ctx.tables_set(*t)
+    if mask is not None:
+        ctx.bc_set(ndof, mask)
+    ctx.csr_symbolic()
+    return ctx
+
+
+def oracle_kle(mesh, mask):
+    """assemble_kle_freeslip with a per-DOF mask [n_node, dim] (the oracle's own routine takes node sets)"""
+    import scipy.sparse as sp
+    dim = mesh.dim
+    tb = fo.Tables(3, dim)
+    dw = tb.dim_w
+    Ke, Rwe, _ = fo.elem_kle_matrices(tb, mesh.corners())
+    n = mesh.n_node
+    vdof, wdof = fo.dof_indices(mesh.conn, dim), fo.dof_indices(mesh.conn, dw)
+    is_bc = np.asarray(mask, bool).reshape(-1)
+    rfree, cbc = ~is_bc[vdof], is_bc[vdof]
+    R = np.broadcast_to(vdof[:, :, None], Ke.shape)
+    C = np.broadcast_to(vdof[:, None, :], Ke.shape)
+    mff = rfree[:, :, None] & rfree[:, None, :]
+    mfb = rfree[:, :, None] & cbc[:, None, :]
+    K = fo._scatter((n * dim, n * dim), R[mff], C[mff], Ke[mff])
+    Krhs = fo._scatter((n * dim, n * dim), R[mfb], C[mfb], -Ke[mfb])
+    bc_idx = np.nonzero(is_bc)[0]
+    ident = sp.coo_matrix((np.ones(len(bc_idx)), (bc_idx, bc_idx)), shape=K.shape).tocsr()
+    Rr = np.broadcast_to(vdof[:, :, None], Rwe.shape)
+    Rc = np.broadcast_to(wdof[:, None, :], Rwe.shape)
+    mrow = np.broadcast_to(rfree[:, :, None], Rwe.shape)
+    return {"K": (K + ident).tocsr(), "Krhs": (Krhs + ident).tocsr(), "Rw": fo._scatter((n * dim, n * dw), Rr[mrow], Rc[mrow], Rwe[mrow])}
+
+
+def boundary_mask(mesh):
+    m = np.zeros((mesh.n_node, mesh.dim), np.uint8)
+    m[mesh.boundary] = 1
+    return m
+
+
+@pytest.mark.parametrize("nelem", [[3, 4], [19, 5], [1, 1], [2, 3, 2], [5, 1, 2], [1, 1, 1]])
+def test_topology_and_closed_form_graph(lib, nelem):
+    dim = len(nelem)
+    mesh = fo.box_mesh(nelem, [0.0] * dim, [1.0] * dim, 3)
+    ctx = make_ctx(lib, mesh)
+    lat = [2 * n + 1 for n in nelem]
+    assert ctx.mesh_topology() == ("lattice-ngl3", lat[0], lat[1], lat[2] if dim == 3 else 1)
+    rp, ci = ctx.csr_get()
+    rp_o, ci_o = fo.node_graph(mesh)
+    assert np.array_equal(rp, rp_o) and np.array_equal(ci, ci_o)          # bit exact, integer work
+    os.environ["PYNAMA_NO_HO3_SYMBOLIC"] = "1"                            # ... and equal to the sort-based graph
+    try:
+        ctx.csr_symbolic()
+    finally:
+        del os.environ["PYNAMA_NO_HO3_SYMBOLIC"]
+    rp_s, ci_s = ctx.csr_get()
+    assert np.array_equal(rp, rp_s) and np.array_equal(ci, ci_s)
+    ctx.close()
+
+
+@pytest.mark.parametrize("nelem,upper", [([3, 4], [1.0, 0.8]), ([19, 5], [2.0, 0.5]), ([40, 33], [1.0, 1.0]), ([1, 1], [1.0, 1.0]),
+                                         ([2, 3, 2], [1.0, 0.8, 1.2]), ([5, 3, 2], [1.0, 1.0, 1.0]), ([1, 1, 1], [1.0, 1.0, 1.0]),
+                                         ([6, 5, 4], [1.0, 0.8, 1.2])])
+def test_kle_vs_oracle_and_generic(lib, nelem, upper):
+    """K, Krhs, Rw of FreeSlip.buildKLEMats (External Boundary imposed): row-run kernels == oracle == generic atomics kernel"""
+    dim = len(nelem)
+    dw = 1 if dim == 2 else 3
+    mesh = fo.box_mesh(nelem, [0.0] * dim, upper, 3)
+    ctx = make_ctx(lib, mesh, boundary_mask(mesh), dim)
+    K, Krhs, Rw = ctx.mat_create(dim, dim), ctx.mat_create(dim, dim), ctx.mat_create(dim, dw)
+    ctx.assemble_kle(1e3, 1e2, K, Krhs, Rw, -1, variant=1)
+    ref = fo.assemble_kle_freeslip(mesh, fo.Tables(3, dim))
+    got = {"K": mat_to_scipy(ctx, K, dim, dim), "Krhs": mat_to_scipy(ctx, Krhs, dim, dim), "Rw": mat_to_scipy(ctx, Rw, dim, dw)}
+    for k in ("K", "Krhs", "Rw"):
+        assert sp_rel_err(got[k], ref[k]) < FP_TOL, k
+    K0, Kr0, Rw0 = ctx.mat_create(dim, dim), ctx.mat_create(dim, dim), ctx.mat_create(dim, dw)
+    ctx.assemble_kle(1e3, 1e2, K0, Kr0, Rw0, -1, variant=0)
+    for a, b, br, bc in ((K, K0, dim, dim), (Krhs, Kr0, dim, dim), (Rw, Rw0, dim, dw)):
+        assert rel_err(ctx.mat_values(a, br, bc), ctx.mat_values(b, br, bc)) < FP_TOL       # entry by entry, storage order
+    ctx.close()
+
+
+@pytest.mark.parametrize("nelem,run", [([19, 5], 16), ([70, 3], 64), ([5, 3, 2], 2), ([9, 2, 2], 8)])
+def test_run_lengths(lib, nelem, run):
+    """every run length of the row-run kernel gives the oracle's matrices (partial last runs included)"""
+    dim = len(nelem)
+    dw = 1 if dim == 2 else 3
+    mesh = fo.box_mesh(nelem, [0.0] * dim, [1.0] * dim, 3)
+    ctx = make_ctx(lib, mesh, boundary_mask(mesh), dim)
+    K, Krhs, Rw = ctx.mat_create(dim, dim), ctx.mat_create(dim, dim), ctx.mat_create(dim, dw)
+    os.environ["PYNAMA_HO3_RUN"] = str(run)
+    try:
+        ctx.assemble_kle(1e3, 1e2, K, Krhs, Rw, -1)
+    finally:
+        del os.environ["PYNAMA_HO3_RUN"]
+    ref = fo.assemble_kle_freeslip(mesh, fo.Tables(3, dim))
+    assert sp_rel_err(mat_to_scipy(ctx, K, dim, dim), ref["K"]) < FP_TOL
+    assert sp_rel_err(mat_to_scipy(ctx, Krhs, dim, dim), ref["Krhs"]) < FP_TOL
+    assert sp_rel_err(mat_to_scipy(ctx, Rw, dim, dw), ref["Rw"]) < FP_TOL
+    ctx.close()
+
+
+@pytest.mark.parametrize("nelem", [[9, 7], [4, 3, 3]])
+@pytest.mark.parametrize("kind", ["none", "per_dof_random", "interior_nodes"])
+def test_dirichlet_routing(lib, nelem, kind):
+    """no mask, a random PER-DOF mask (imposed DOFs anywhere, also inside), imposed interior nodes: K / Krhs / unit diagonal"""
+    dim = len(nelem)
+    dw = 1 if dim == 2 else 3
+    mesh = fo.box_mesh(nelem, [0.0] * dim, [1.0, 0.9, 1.1][:dim], 3)
+    rng = np.random.default_rng(7)
+    if kind == "none":
+        mask = None
+    elif kind == "per_dof_random":
+        mask = (rng.uniform(size=(mesh.n_node, dim)) < 0.15).astype(np.uint8)
+    else:
+        mask = np.zeros((mesh.n_node, dim), np.uint8)
+        mask[rng.choice(mesh.n_node, mesh.n_node // 10, replace=False)] = 1
+    ctx = make_ctx(lib, mesh, mask, dim)
+    K, Krhs, Rw = ctx.mat_create(dim, dim), ctx.mat_create(dim, dim), ctx.mat_create(dim, dw)
+    ctx.assemble_kle(1e3, 1e2, K, Krhs, Rw, -1)
+    ref = oracle_kle(mesh, mask if mask is not None else np.zeros((mesh.n_node, dim), np.uint8))
+    assert sp_rel_err(mat_to_scipy(ctx, K, dim, dim), ref["K"]) < FP_TOL
+    assert sp_rel_err(mat_to_scipy(ctx, Krhs, dim, dim), ref["Krhs"]) < FP_TOL
+    assert sp_rel_err(mat_to_scipy(ctx, Rw, dim, dw), ref["Rw"]) < FP_TOL
+    ctx.close()
+
+
+@pytest.mark.parametrize("dim", [2, 3])
+def test_sheared_mesh_and_nonaffine_fallback(lib, dim):
+    """an affine image of the box keeps every cell a parallelogram / parallelepiped (row-run kernels, full J^-1); moving ONE
+    vertex makes its cells non-affine and the whole assembly falls back to the generic quadrature kernel -- both equal the oracle"""
+    nelem = [5, 4] if dim == 2 else [3, 2, 3]
+    dw = 1 if dim == 2 else 3
+    mesh = fo.box_mesh(nelem, [0.0] * dim, [1.0] * dim, 3)
+    A = np.eye(dim) + 0.25 * np.random.default_rng(3).standard_normal((dim, dim))
+    assert np.linalg.det(A) > 0
+    mesh.xyz = mesh.xyz @ A.T + 0.3
+    for bend in (False, True):
+        if bend:
+            corner_nodes = np.unique(mesh.conn[:, :2 ** dim])
+            inner = np.setdiff1d(corner_nodes, mesh.boundary)
+            mesh.xyz[inner[len(inner) // 2]] += 0.02
+        ctx = make_ctx(lib, mesh, boundary_mask(mesh), dim)
+        K, Krhs, Rw = ctx.mat_create(dim, dim), ctx.mat_create(dim, dim), ctx.mat_create(dim, dw)
+        ctx.assemble_kle(1e3, 1e2, K, Krhs, Rw, -1)
+        ref = fo.assemble_kle_freeslip(mesh, fo.Tables(3, dim))
+        assert sp_rel_err(mat_to_scipy(ctx, K, dim, dim), ref["K"]) < FP_TOL, bend
+        assert sp_rel_err(mat_to_scipy(ctx, Krhs, dim, dim), ref["Krhs"]) < FP_TOL, bend
+        assert sp_rel_err(mat_to_scipy(ctx, Rw, dim, dw), ref["Rw"]) < FP_TOL, bend
+        ctx.close()
+
+
+@pytest.mark.parametrize("dim", [2, 3])
+def test_single_cell_mesh_reproduces_reference_element(lib, golden, dim):
+    """the row-run kernels on a ONE-cell mesh against the reference's own K_e / Rw_e (tests/golden/g3_elem.npz, written by
+    src/elements/spectral.py:89-157): the affine fixtures"""
+    g = golden["g3_elem"]
+    dw = 1 if dim == 2 else 3
+    mesh = fo.box_mesh([1] * dim, [0.0] * dim, [1.0] * dim, 3)
+    for case in ("unit", "reftest", "brick128", "stretched"):
+        key = f"d{dim}_n3_{case}"
+        coords = g[key + "_coords"].reshape(2 ** dim, dim)
+        mesh.xyz[mesh.conn[0, :2 ** dim]] = coords           # geometry is multilinear from the corners (spectral.py:44, 120)
+        ctx = make_ctx(lib, mesh)
+        assert ctx.mesh_topology()[0] == "lattice-ngl3"
+        K, Rw = ctx.mat_create(dim, dim), ctx.mat_create(dim, dw)
+        ctx.assemble_kle(1e3, 1e2, K, -1, Rw, -1)
+        # one cell: the global matrices ARE the element matrices, permuted to node order
+        perm = np.argsort(mesh.conn[0])
+        pk = (perm[:, None] * dim + np.arange(dim)).ravel()
+        pw = (perm[:, None] * dw + np.arange(dw)).ravel()
+        assert rel_err(mat_to_scipy(ctx, K, dim, dim).toarray(), g[key + "_K"][np.ix_(pk, pk)]) < FP_TOL, case
+        assert rel_err(mat_to_scipy(ctx, Rw, dim, dw).toarray(), g[key + "_Rw"][np.ix_(pk, pw)]) < FP_TOL, case
+        ctx.close()
+
+
+@pytest.mark.parametrize("nelem", [[11, 6], [4, 3, 2]])
+def test_scalar_laplacian(lib, nelem):
+    dim = len(nelem)
+    mesh = fo.box_mesh(nelem, [0.0] * dim, [1.0, 0.7, 1.3][:dim], 3)
+    mask = np.zeros(mesh.n_node, np.uint8)
+    mask[mesh.boundary] = 1
+    ctx = make_ctx(lib, mesh, mask, 1)
+    A, Ar = ctx.mat_create(1, 1), ctx.mat_create(1, 1)
+    ctx.assemble_scalar(lib.FORM_LAPLACE, A, Ar)
+    ref = fo.assemble_scalar(mesh, fo.Tables(3, dim), "laplace", dirichlet=mesh.boundary)
+    assert sp_rel_err(mat_to_scipy(ctx, A, 1, 1), ref["A"]) < FP_TOL
+    assert sp_rel_err(mat_to_scipy(ctx, Ar, 1, 1), ref["Arhs"]) < FP_TOL
+    ctx.close()
+
+
+def test_imposed_column_matrix_across_dirichlet_sets(lib):
+    """Krhs is rewritten where a NEW Dirichlet set needs it (and cleared where the old one left values)"""
+    nelem = [6, 5]
+    mesh = fo.box_mesh(nelem, [0.0, 0.0], [1.0, 1.0], 3)
+    ctx = make_ctx(lib, mesh, boundary_mask(mesh), 2)
+    K, Krhs = ctx.mat_create(2, 2), ctx.mat_create(2, 2)
+    ctx.assemble_kle(1e3, 1e2, K, Krhs, -1, -1)
+    ctx.assemble_kle(1e3, 1e2, K, Krhs, -1, -1)                    # second call: Krhs known clean for this set
+    ref = fo.assemble_kle_freeslip(mesh, fo.Tables(3, 2))
+    assert sp_rel_err(mat_to_scipy(ctx, Krhs, 2, 2), ref["Krhs"]) < FP_TOL
+    mask = np.zeros((mesh.n_node, 2), np.uint8)
+    mask[np.random.default_rng(5).choice(mesh.n_node, 12, replace=False)] = 1
+    ctx.bc_set(2, mask)
+    ctx.assemble_kle(1e3, 1e2, K, Krhs, -1, -1)
+    ref2 = oracle_kle(mesh, mask)
+    assert sp_rel_err(mat_to_scipy(ctx, K, 2, 2), ref2["K"]) < FP_TOL
+    assert sp_rel_err(mat_to_scipy(ctx, Krhs, 2, 2), ref2["Krhs"]) < FP_TOL
+    ctx.close()
+
+
+@pytest.mark.parametrize("nelem,size", [([5, 8], 2), ([4, 9], 3), ([3, 2, 6], 2), ([2, 2, 7], 3)])
+def test_rank_slabs(lib, nelem, size):
+    """a rank's slab (owned planes first, ghost planes with the LAST ids): closed-form graph, K, Krhs, Rw and the product equal the
+    owned rows of the serial oracle"""
+    from pynama_amd.common.comm import Comm
+    from pynama_amd.domain.dmplex import DMPlexDom
+    from pynama_amd.elements.spectral import Spectral
+    dim = len(nelem)
+    dw = 1 if dim == 2 else 3
+    lo, up = [0.0] * dim, [1.0, 0.8, 1.2][:dim]
+    glob = fo.box_mesh(nelem, lo, up, 3)
+    ref = fo.assemble_kle_freeslip(glob, fo.Tables(3, dim))
+    rp_g, ci_g = fo.node_graph(glob)
+    xg = np.random.default_rng(11).standard_normal(glob.n_node * dim)
+    yg = ref["K"] @ xg
+    for r in range(size):
+        dom = DMPlexDom(boxMesh={'nelem': nelem, 'lower': lo, 'upper': up}, comm=Comm(r, size))
+        dom.setFemIndexing(3)
+        ctx = lib.Context(0)
+        ctx.comm_init(r, size, None)                      # detached
+        ctx.halo_set(*dom._halo_plan())
+        ctx.mesh_set(dim, dom.conn, dom.xyz)
+        for t in Spectral(3, dim).deviceTables():
+            ctx.tables_set(*t)
+        ctx.bc_set(dim, np.repeat(dom.boundaryMaskLocal()[:, None], dim, axis=1))
+        ctx.csr_symbolic()
+        assert ctx.mesh_topology()[0] == "lattice-ngl3"
+        rp, ci = ctx.csr_get()
+        l2g = dom._local2global(np.arange(dom.nLocal))
+        assert np.array_equal(np.diff(rp), np.diff(rp_g)[dom.rStart:dom.rEnd])
+        for i in range(0, dom.nOwned, max(1, dom.nOwned // 50)):
+            gi = dom.rStart + i
+            assert np.array_equal(np.sort(l2g[ci[rp[i]:rp[i + 1]]]), ci_g[rp_g[gi]:rp_g[gi + 1]])
+            assert np.all(np.diff(ci[rp[i]:rp[i + 1]]) > 0)
+        K, Krhs, Rw = ctx.mat_create(dim, dim), ctx.mat_create(dim, dim), ctx.mat_create(dim, dw)
+        ctx.assemble_kle(1e3, 1e2, K, Krhs, Rw, -1)
+        rows = (np.arange(dom.rStart, dom.rEnd)[:, None] * dim + np.arange(dim)).ravel()
+        cv = (l2g[:, None] * dim + np.arange(dim)).ravel()
+        cw = (l2g[:, None] * dw + np.arange(dw)).ravel()
+        assert sp_rel_err(mat_to_scipy(ctx, K, dim, dim), ref["K"][rows][:, cv]) < FP_TOL
+        assert sp_rel_err(mat_to_scipy(ctx, Krhs, dim, dim), ref["Krhs"][rows][:, cv]) < FP_TOL
+        assert sp_rel_err(mat_to_scipy(ctx, Rw, dim, dw), ref["Rw"][rows][:, cw]) < FP_TOL
+        vx, vy = ctx.vec_create(dim), ctx.vec_create(dim)
+        ctx.vec_set_local(vx, xg[cv])
+        ctx.spmv(K, vx, vy)
+        assert rel_err(ctx.vec_get(vy, dim), yg[rows]) < 1e-13
+        ctx.close()
+
+
+@pytest.mark.parametrize("dim", [2, 3])
+def test_uniform_flow_solve(lib, dim):
+    """the reference's analytic assertion (src/tests/test_solver.py:20-27, 52-62: uniform flow is reproduced exactly) on matrices of
+    the row-run kernels, at the C ABI: 10 x 10 (2-D) / 3 x 3 x 3 (3-D) cells, ngl 3"""
+    nelem = [10, 10] if dim == 2 else [3, 3, 3]
+    dw = 1 if dim == 2 else 3
+    mesh = fo.box_mesh(nelem, [0.0] * dim, [1.0] * dim, 3)
+    ctx = make_ctx(lib, mesh, boundary_mask(mesh), dim)
+    K, Krhs, Rw = ctx.mat_create(dim, dim), ctx.mat_create(dim, dim), ctx.mat_create(dim, dw)
+    ctx.assemble_kle(1e3, 1e2, K, Krhs, Rw, -1)
+    cte = np.array([1.0, 4.0, -2.0][:dim])
+    vel = np.zeros((mesh.n_node, dim))
+    vel[mesh.boundary] = cte
+    vv, vr, vx = ctx.vec_create(dim), ctx.vec_create(dim), ctx.vec_create(dim)
+    ctx.vec_set(vv, vel.ravel())
+    ctx.spmv(Krhs, vv, vr)                                  # rhs = Rw * 0 + Krhs * vel (base_problem.py:481)
+    info = ctx.solve(K, vr, vx, rtol=1e-14, atol=1e-300, dtol=1e8, norm_type=lib.NORM_UNPRECONDITIONED, maxit=200000)
+    err = np.linalg.norm(ctx.vec_get(vx, dim) - np.tile(cte, mesh.n_node))
+    assert err < (1e-12 if dim == 2 else 2e-13), (err, info.iters, info.reason)
+    ctx.close()
