@@ -79,8 +79,10 @@ struct DMat {
   int br = 0, bc = 0;
   double* val = nullptr;  // [nnzb*br*bc], layout in pynama_hip.h
   double* sell_val = nullptr;  // SELL-64 image of `val` (scalar matrices, solver side)
-  bool sell_valid = false;
+  bool sell_valid = false;     // the image holds the current values
+  bool prod_ready = false;     // pyn_sell_ensure has chosen the product kernel for the current values (image / CSR values)
   bool csr_product = false;    // scalar dictionary-mode matrix: the product reads `val` directly (csrl_spmv_kernel), there is no image (decided in pyn_sell_ensure)
+  bool bcsr_product = false;   // block matrix / long scalar rows: the product reads the block-CSR values directly (bcsr_spmv_kernel), no image either
   double* dinv = nullptr;      // 1 / diagonal per scalar row (Jacobi), written by the lattice assemblies in their store
   bool dinv_valid = false;     // phase, else extracted once per matrix version (pyn_dinv_ensure)
   double* lu = nullptr;        // dense LU factors of small systems (pyn_direct.hip), [n][n] row-major, multipliers in place
@@ -93,7 +95,7 @@ struct DMat {
   int64_t rhs_clean = -2;      // PYN_RHS_UNKNOWN
   bool live = false;
   void touch() {               // the values are about to change
-    sell_valid = dinv_valid = lu_valid = false;
+    sell_valid = prod_ready = dinv_valid = lu_valid = false;
     rhs_clean = -2;
   }
   void release_lu() {
@@ -269,7 +271,7 @@ int pyn_reduce_host(pyn_ctx* c, int nslots, int nblocks, int op, double* out);  
 int pyn_spmv_raw(pyn_ctx* c, const DMat& A, const double* x, double* y);        // no halo exchange
 int pyn_extract_diag_inv(pyn_ctx* c, const DMat& A, double* dinv, bool invert);
 int pyn_dinv_ensure(pyn_ctx* c, DMat& A);   // A.dinv valid for the current values (one diag_kernel per matrix version at most)
-int pyn_sell_ensure(pyn_ctx* c, DMat& A);
+int pyn_sell_ensure(pyn_ctx* c, DMat& A, bool solver = true);   // solver: the product will be repeated (Krylov loop), not a one-off pyn_spmv
 bool pyn_sell_supported(const DMat& A);
 int pyn_sell_spmv(pyn_ctx* c, const DMat& A, const double* x, double* y, bool dot, int* grid_out);
 void pyn_sell_drop_structure(pyn_ctx* c);

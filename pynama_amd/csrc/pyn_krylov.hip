@@ -669,7 +669,7 @@ extern "C" int pyn_spmv(pyn_ctx* c, int mat_id, int xv, int yv) {
   PYN_HIP(hipEventRecord(c->ev0, c->stream));
   PYN_TRY(pyn_halo_exchange(c, c->vecs[xv].d, A.bc));
   if (pyn_sell_supported(A) && !getenv("PYNAMA_NO_SELL")) {  // multiply through the SELL-64 image
-    PYN_TRY(pyn_sell_ensure(c, A));
+    PYN_TRY(pyn_sell_ensure(c, A, false));
     PYN_HIP(hipEventRecord(c->ev0, c->stream));  // time the product, not the (one-off) conversion
     PYN_TRY(pyn_sell_spmv(c, A, c->vecs[xv].d, c->vecs[yv].d, false, nullptr));
   } else {
@@ -1395,7 +1395,7 @@ extern "C" int pyn_solve(pyn_ctx* c, int mat_id, int bv, int xv, const pyn_solve
   PYN_TRY(pyn_ensure_work(c, (size_t)n * sizeof(double)));
   double* w = c->d_work;
   PYN_TRY(pyn_halo_exchange(c, x, A.bc));
-  if (A.sell_valid && pyn_sell_supported(A) && !getenv("PYNAMA_NO_SELL"))
+  if (A.prod_ready && pyn_sell_supported(A) && !getenv("PYNAMA_NO_SELL"))
     PYN_TRY(pyn_sell_spmv(c, A, x, w, false, nullptr));   // the image the iteration just used (2.6x the CSR product)
   else
     PYN_TRY(pyn_spmv_raw(c, A, x, w));

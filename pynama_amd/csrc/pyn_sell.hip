@@ -465,6 +465,104 @@ __global__ void __launch_bounds__(256) sellb_spmv_kernel(const int64_t* __restri
   }
 }
 
+// Block matrices (and scalar matrices with long rows) straight from the block-CSR values: G lanes per NODE row, 64 / G node rows per
+// wave.  The br scalar rows of a node are one contiguous piece (rowptr[i] br + p len_i) bc of the value array: lane g of the group takes
+// the entries r = g, g + G, ... of EVERY scalar row p (br coalesced loads per step), the x entry (col[r / BC] BC + r % BC) is gathered
+// once per step and serves the br rows, a shuffle tree ends the row.  No image of the matrix, nothing to refresh after an assembly
+// (the SELL image of a 128^3 3x3-block matrix cost 2.5 ms and 8.3 GB of traffic per assembly, and 8 % of padding in every product).
+// Traffic = the block-CSR bytes: 8 B per value + 4 B per BLOCK of column index + x, y.
+template <int BR, int BC, int U, bool DOT>
+__global__ void __launch_bounds__(256) bcsr_spmv_kernel(const int32_t* __restrict__ rowptr, const int32_t* __restrict__ colidx,
+                                                        const double* __restrict__ val, const double* __restrict__ x, double* __restrict__ y,
+                                                        int lg, int64_t n0, int64_t n1, int64_t hole_begin, int64_t hole_len,
+                                                        const int* __restrict__ flag, double* __restrict__ part, int part_off) {
+  __shared__ double smd[4];
+  if (flag && flag[0]) return;
+  // U entries per lane and trip: U column loads, U x gathers and U BR value loads in flight
+  const int G = 1 << lg, npw = 64 >> lg;
+  const int lane = threadIdx.x & 63, g = lane & (G - 1), sub = lane >> lg;
+  const int64_t w0 = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6), nw = (int64_t)gridDim.x * 4;
+  double dot = 0.0;
+  // row offsets one step ahead: a node's loads start without a dependent load in front of them
+  int nlo = 0, nhi = 0;
+  {
+    const int64_t tl = n0 + w0 * npw + sub;
+    if (tl < n1) {
+      const int64_t i = tl >= hole_begin ? tl + hole_len : tl;
+      nlo = rowptr[i];
+      nhi = rowptr[i + 1];
+    }
+  }
+  for (int64_t tb = n0 + w0 * npw; tb < n1; tb += nw * npw) {   // n1: logical end (hole removed)
+    const int64_t tl = tb + sub;
+    const bool live = tl < n1;
+    const int64_t i = tl >= hole_begin ? tl + hole_len : tl;
+    const int lo = nlo, len = nhi - nlo;
+    {
+      const int64_t t2 = tl + nw * npw;
+      nlo = nhi = 0;
+      if (t2 < n1) {
+        const int64_t i2 = t2 >= hole_begin ? t2 + hole_len : t2;
+        nlo = rowptr[i2];
+        nhi = rowptr[i2 + 1];
+      }
+    }
+    const int L1 = len * BC;
+    const double* __restrict__ v = val + (int64_t)lo * (BR * BC);
+    const int32_t* __restrict__ ci = colidx + lo;
+    double acc[BR];
+#pragma unroll
+    for (int p = 0; p < BR; ++p) acc[p] = 0.0;
+    int cn[U];   // column nodes of the next trip
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int r = g + u * G;
+      cn[u] = r < L1 ? ci[r / BC] : 0;
+    }
+    for (int r0 = g; r0 < L1; r0 += U * G) {
+      double a[U][BR], xv[U];
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const int r = r0 + u * G;
+        const bool in = r < L1;
+#pragma unroll
+        for (int p = 0; p < BR; ++p) a[u][p] = in ? v[p * L1 + r] : 0.0;
+      }
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const int r = r0 + u * G;
+        const int q = r % BC;
+        xv[u] = r < L1 ? x[(int64_t)cn[u] * BC + q] : 0.0;
+      }
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const int r = r0 + (U + u) * G;
+        cn[u] = r < L1 ? ci[r / BC] : 0;
+      }
+#pragma unroll
+      for (int u = 0; u < U; ++u)
+#pragma unroll
+        for (int p = 0; p < BR; ++p) acc[p] = fma(a[u][p], xv[u], acc[p]);
+    }
+#pragma unroll
+    for (int p = 0; p < BR; ++p)
+      for (int o = G >> 1; o > 0; o >>= 1) acc[p] += __shfl_xor(acc[p], o, 64);
+    if (live && g == 0) {
+#pragma unroll
+      for (int p = 0; p < BR; ++p) {
+        y[i * BR + p] = acc[p];
+        if (DOT) dot = fma(acc[p], x[i * BC + p], dot);
+      }
+    }
+  }
+  if (DOT) {
+    dot = wsum64(dot);
+    if (lane == 0) smd[threadIdx.x >> 6] = dot;
+    __syncthreads();
+    if (threadIdx.x == 0) part[part_off + blockIdx.x] = smd[0] + smd[1] + smd[2] + smd[3];
+  }
+}
+
 }  // namespace
 
 static int build_pattern_dictionary(pyn_ctx* c, int maxw) {
@@ -537,7 +635,24 @@ static bool csr_product(const pyn_ctx* c, const DMat& A, const SellShape* S) {
   return A.br == 1 && A.bc == 1 && c->sell_npat > 0 && S && S->maxw <= PAT_W && !getenv("PYNAMA_SELL_IMAGE");
 }
 
-int pyn_sell_ensure(pyn_ctx* c, DMat& A) {
+// Block matrices, and scalar matrices whose rows are too long for the dictionary (second-order elements: up to 125 entries), are
+// multiplied straight from the block-CSR values as well (bcsr_spmv_kernel).  PYNAMA_BLOCK_SELL=1 keeps the SELL image (A/B, tests).
+static bool bcsr_shape(int br, int bc) {
+  return (br == bc && (br == 1 || br == 2 || br == 3)) || (bc == 1 && (br == 2 || br == 3)) || (br == 1 && (bc == 2 || bc == 3)) ||
+         (br == 3 && bc == 2) || (br == 2 && bc == 3) || (br == 6 && bc == 3) || (br == 3 && bc == 6);
+}
+// 1: every product of A reads the CSR values (long rows: the SELL image would carry 20 % of padding and cost a refresh per assembly);
+// 2: only one-off products do (pyn_spmv of a matrix without a current image: Krhs v, Rw w, the operators -- a refresh costs three
+// products), solvers build the image, whose lane-per-row kernel is 20-25 % faster on the short rows of first-order elements; 0: never
+static int bcsr_mode(const pyn_ctx* c, const DMat& A) {
+  if (getenv("PYNAMA_BLOCK_SELL") || !bcsr_shape(A.br, A.bc)) return 0;
+  const char* e = getenv("PYNAMA_BCSR_MIN_AVG");
+  const double min_avg = e ? atof(e) : 128.0;
+  const double avg = (double)c->nnzb * A.bc / (double)std::max<int64_t>(1, c->n_owned);   // entries per scalar row
+  return avg >= min_avg ? 1 : 2;
+}
+
+int pyn_sell_ensure(pyn_ctx* c, DMat& A, bool solver) {
   PYN_CHECK(pyn_sell_supported(A), "no SELL kernel for block shape %dx%d", A.br, A.bc);
   hipStream_t s = c->stream;
   const int64_t n = c->n_owned * A.br;  // scalar rows
@@ -575,7 +690,7 @@ int pyn_sell_ensure(pyn_ctx* c, DMat& A) {
     PYN_HIP(hipMalloc((void**)&q.ptr, (ns + 1) * sizeof(int64_t)));
     PYN_HIP(hipMemcpyAsync(q.ptr, ptr.data(), (ns + 1) * sizeof(int64_t), hipMemcpyHostToDevice, s));
     PYN_HIP(hipStreamSynchronize(s));
-    if (c->sell_npat == 0) PYN_HIP(hipMalloc((void**)&q.col, q.total * sizeof(int32_t)));  // explicit columns needed
+    // explicit columns (no dictionary): allocated with the first IMAGE of this shape -- matrices multiplied from their CSR values never need them
     if (c->n_ghost > 0) {
       // interior slices (no ghost columns) can be multiplied while the halo exchange is in flight: usable when
       // they form ONE contiguous range (z-slabs: everything between the first and the last node plane)
@@ -601,17 +716,31 @@ int pyn_sell_ensure(pyn_ctx* c, DMat& A) {
     fresh = true;
   }
   A.csr_product = csr_product(c, A, S);
-  if (A.csr_product) {   // nothing to refresh: the product reads A.val
+  A.bcsr_product = false;
+  int bm = 0;
+  if (!A.csr_product) {
+    bm = bcsr_mode(c, A);
+    if (A.br == 1 && A.bc == 1 && !(S->maxw > PAT_W && !getenv("PYNAMA_SELL_IMAGE"))) bm = 0;   // scalar rows inside the dictionary's width keep their kernels
+    A.bcsr_product = bm == 1 || (bm == 2 && !solver && !(A.sell_val && A.sell_valid));
+  }
+  if (A.csr_product || bm == 1) {   // never an image: the products read A.val
     if (A.sell_val) {
       (void)hipFree(A.sell_val);
       A.sell_val = nullptr;
     }
-    A.sell_valid = true;
+    A.sell_valid = false;
+  }
+  if (A.csr_product || A.bcsr_product) {
+    A.prod_ready = true;
     return PYN_OK;
   }
-  if (!A.sell_val) PYN_HIP(hipMalloc((void**)&A.sell_val, S->total * sizeof(double)));
-  if (!A.sell_valid || fresh) {
-    const bool cols = fresh && S->col;
+  if (!A.sell_val) {
+    PYN_HIP(hipMalloc((void**)&A.sell_val, S->total * sizeof(double)));
+    A.sell_valid = false;
+  }
+  const bool cols = c->sell_npat == 0 && !S->col;   // this image also writes the shape's explicit column array
+  if (cols) PYN_HIP(hipMalloc((void**)&S->col, S->total * sizeof(int32_t)));
+  if (!A.sell_valid || fresh || cols) {
     if (A.br == 1 && A.bc == 1 && (size_t)SH * S->maxw * 12 <= 64 * 1024) {
       const size_t lds = (size_t)SH * S->maxw * (cols ? 12 : 8);
       const int grid = (int)std::min<int64_t>(ns, 256 * 32);
@@ -638,6 +767,7 @@ int pyn_sell_ensure(pyn_ctx* c, DMat& A) {
     PYN_HIP(hipGetLastError());
     A.sell_valid = true;
   }
+  A.prod_ready = true;
   return PYN_OK;
 }
 
@@ -681,7 +811,7 @@ int pyn_sell_spmv_range(pyn_ctx* c, const DMat& A, const double* x, double* y, b
 int pyn_sell_spmv_range2(pyn_ctx* c, const DMat& A, const double* x, double* y, bool dot, int64_t a0, int64_t a1, int64_t b0,
                          int64_t b1, int poff, int max_grid, hipStream_t st, int* grid_out) {
   const SellShape* S = pyn_sell_shape(c, A);
-  PYN_CHECK(S && A.sell_valid, "pyn_sell_ensure first");
+  PYN_CHECK(S && A.prod_ready, "pyn_sell_ensure first");
   PYN_CHECK(!dot || A.br == A.bc, "fused dot needs a square block shape");
   PYN_CHECK(a0 >= 0 && a0 <= a1 && a1 <= b0 && b0 <= b1 && b1 <= S->ns, "bad slice ranges");
   const int64_t hb = a1, hl = b0 - a1;        // hole in logical coordinates
@@ -692,6 +822,81 @@ int pyn_sell_spmv_range2(pyn_ctx* c, const DMat& A, const double* x, double* y, 
   }
   const int grid = (int)std::max<int64_t>(1, std::min<int64_t>((s1 - s0 + 3) / 4, max_grid));
   PYN_CHECK(poff + grid <= PYN_MAX_PARTIALS, "partial buffer overflow");
+  if (A.bcsr_product) {   // block-CSR values, G lanes per node row; slice boundaries become node boundaries (floor: a node that straddles
+                          // an interior and a boundary slice has no ghost column, either side may take it)
+    auto node_of = [&](int64_t sl) { return std::min<int64_t>(c->n_owned, sl * SH / A.br); };
+    const int64_t na0 = node_of(a0), na1 = node_of(a1), nb0 = node_of(b0), nb1 = node_of(b1);
+    const int64_t nhb = na1, nhl = nb0 - na1, n0 = na0, n1 = nb1 - nhl;
+    if (n0 >= n1) {
+      if (grid_out) *grid_out = 0;
+      return PYN_OK;
+    }
+    const char* ge = getenv("PYNAMA_BCSR_LANES");
+    int lg;
+    if (ge) {
+      const int gg = atoi(ge);
+      lg = gg >= 64 ? 6 : gg >= 32 ? 5 : gg >= 16 ? 4 : 3;
+    } else {
+      const double avg = (double)c->nnzb * A.bc / (double)std::max<int64_t>(1, c->n_owned);   // entries per scalar row
+      lg = avg >= 160.0 ? 6 : avg >= 56.0 ? 5 : avg >= 20.0 ? 4 : 3;
+    }
+    const char* ue = getenv("PYNAMA_BCSR_UNROLL");
+    const int un = ue ? atoi(ue) : 4;
+    const int npw = 64 >> lg;
+    const char* wcu = getenv("PYNAMA_BCSR_WGS_PER_CU");
+    const int64_t want = (n1 - n0 + 4 * npw - 1) / (4 * npw);
+    int gridb = 1;
+  // persistent waves: exactly the workgroups that are resident together (a grid of 1.6 x that capacity runs a second, half-empty round)
+#define BCSR_LAUNCH_U(RR, CC, UU, DD)                                                                                                      \
+  do {                                                                                                                                     \
+    static int per_cu = 0;                                                                                                                 \
+    if (!per_cu) {                                                                                                                         \
+      PYN_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, bcsr_spmv_kernel<RR, CC, UU, DD>, 256, 0));                            \
+      per_cu = std::max(1, std::min(per_cu, 8));                                                                                           \
+    }                                                                                                                                      \
+    gridb = (int)std::max<int64_t>(1, std::min<int64_t>(std::min<int64_t>(want, max_grid), 256 * (wcu ? atoi(wcu) : per_cu)));             \
+    PYN_CHECK(poff + gridb <= PYN_MAX_PARTIALS, "partial buffer overflow");                                                                \
+    bcsr_spmv_kernel<RR, CC, UU, DD><<<gridb, 256, 0, st>>>(c->d_rowptr, c->d_colidx, A.val, x, y, lg, n0, n1, nhb, nhl,                   \
+                                                            DD ? c->d_flag : nullptr, DD ? c->d_part : nullptr, poff);                    \
+  } while (0)
+#define BCSR_LAUNCH(RR, CC, DD)                 \
+  do {                                          \
+    if (un == 2)                                \
+      BCSR_LAUNCH_U(RR, CC, 2, DD);             \
+    else if (un == 3)                           \
+      BCSR_LAUNCH_U(RR, CC, 3, DD);             \
+    else                                        \
+      BCSR_LAUNCH_U(RR, CC, 4, DD);             \
+  } while (0)
+#define BCSR_SQUARE(NN)          \
+  do {                           \
+    if (dot)                     \
+      BCSR_LAUNCH(NN, NN, true); \
+    else                         \
+      BCSR_LAUNCH(NN, NN, false); \
+  } while (0)
+    const int shape = A.br * 8 + A.bc;
+    switch (shape) {
+      case 1 * 8 + 1: BCSR_SQUARE(1); break;
+      case 2 * 8 + 2: BCSR_SQUARE(2); break;
+      case 3 * 8 + 3: BCSR_SQUARE(3); break;
+      case 2 * 8 + 1: BCSR_LAUNCH(2, 1, false); break;
+      case 3 * 8 + 1: BCSR_LAUNCH(3, 1, false); break;
+      case 1 * 8 + 2: BCSR_LAUNCH(1, 2, false); break;
+      case 1 * 8 + 3: BCSR_LAUNCH(1, 3, false); break;
+      case 3 * 8 + 2: BCSR_LAUNCH(3, 2, false); break;
+      case 2 * 8 + 3: BCSR_LAUNCH(2, 3, false); break;
+      case 6 * 8 + 3: BCSR_LAUNCH(6, 3, false); break;
+      case 3 * 8 + 6: BCSR_LAUNCH(3, 6, false); break;
+      default: PYN_CHECK(false, "no block-CSR product for block shape %dx%d", A.br, A.bc);
+    }
+#undef BCSR_LAUNCH_U
+#undef BCSR_SQUARE
+#undef BCSR_LAUNCH
+    PYN_HIP(hipGetLastError());
+    if (grid_out) *grid_out = gridb;
+    return PYN_OK;
+  }
   if (A.csr_product) {   // straight from the CSR values (decided once per pyn_sell_ensure, not per launch)
     const int W = S->maxw <= 27 ? 27 : 32;
     const size_t lds = (size_t)CSRL_WAVES * 64 * W * sizeof(double) + (size_t)(c->sell_npat + 1) * PAT_W * sizeof(int32_t);

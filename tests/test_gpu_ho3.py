@@ -302,7 +302,60 @@ def test_uniform_flow_solve(lib, dim):
     vv, vr, vx = ctx.vec_create(dim), ctx.vec_create(dim), ctx.vec_create(dim)
     ctx.vec_set(vv, vel.ravel())
     ctx.spmv(Krhs, vv, vr)                                  # rhs = Rw * 0 + Krhs * vel (base_problem.py:481)
+    info = ctx.solve_direct(K, vr, vx)                      # the reference's default: -ksp_type preonly -pc_type lu (ksp_solver.py:13-16)
+    err = np.linalg.norm(ctx.vec_get(vx, dim) - np.tile(cte, mesh.n_node))
+    assert err < (1e-12 if dim == 2 else 2e-13), (err, info.true_resid)
     info = ctx.solve(K, vr, vx, rtol=1e-14, atol=1e-300, dtol=1e8, norm_type=lib.NORM_UNPRECONDITIONED, maxit=200000)
     err = np.linalg.norm(ctx.vec_get(vx, dim) - np.tile(cte, mesh.n_node))
-    assert err < (1e-12 if dim == 2 else 2e-13), (err, info.iters, info.reason)
+    assert err < 5e-12, (err, info.iters, info.reason)      # Jacobi-PCG to round-off on the same system
+    ctx.close()
+
+
+@pytest.mark.parametrize("nelem", [[9, 7], [4, 3, 3]])
+@pytest.mark.parametrize("lanes", [0, 8, 16, 32, 64])
+def test_block_csr_product(lib, nelem, lanes):
+    """y = A x straight from the block-CSR values (bcsr_spmv_kernel) for every block shape of the path: K (dim x dim), Rw (dim x dim_w), the
+    scalar Laplacian with its long rows, the operator shapes SrT / DivSrT / Curl -- against scipy on the matrix read back, for every
+    lanes-per-node setting, and equal to the SELL-image product (PYNAMA_BLOCK_SELL=1)"""
+    from pynama_amd.elements.spectral import Spectral
+    dim = len(nelem)
+    dw, ds = (1, 3) if dim == 2 else (3, 6)
+    mesh = fo.box_mesh(nelem, [0.0] * dim, [1.0, 0.9, 1.1][:dim], 3)
+    ctx = make_ctx(lib, mesh, boundary_mask(mesh), dim)
+    K, Rw = ctx.mat_create(dim, dim), ctx.mat_create(dim, dw)
+    ctx.assemble_kle(1e3, 1e2, K, -1, Rw, -1)
+    mats = [(K, dim, dim), (Rw, dim, dw)]
+    ops = Spectral(3, dim).operatorTerms()
+    for name in ("SrT", "DivSrT", "Curl"):
+        br, bc, terms, coef = ops[name]
+        M = ctx.mat_create(br, bc)
+        ctx.assemble_operator(lib.Q_NODAL, terms, coef, M)
+        mats.append((M, br, bc))
+    ctx.bc_set(1, boundary_mask(mesh)[:, 0].copy())
+    A = ctx.mat_create(1, 1)
+    ctx.assemble_scalar(lib.FORM_LAPLACE, A, -1)
+    mats.append((A, 1, 1))
+    rng = np.random.default_rng(5)
+    if lanes:
+        os.environ["PYNAMA_BCSR_LANES"] = str(lanes)
+    try:
+        for mid, br, bc in mats:
+            S = mat_to_scipy(ctx, mid, br, bc)
+            xv = rng.standard_normal(mesh.n_node * bc)
+            vx, vy = ctx.vec_create(bc), ctx.vec_create(br)
+            ctx.vec_set(vx, xv)
+            ctx.spmv(mid, vx, vy)
+            y = ctx.vec_get(vy, br)
+            assert rel_err(y, S @ xv) < 1e-13, (br, bc)
+            if not lanes:
+                os.environ["PYNAMA_BLOCK_SELL"] = "1"
+                try:
+                    ctx.spmv(mid, vx, vy)
+                finally:
+                    del os.environ["PYNAMA_BLOCK_SELL"]
+                assert rel_err(ctx.vec_get(vy, br), y) < 1e-13, (br, bc)
+                ctx.spmv(mid, vx, vy)                       # and back: no stale image state
+                assert rel_err(ctx.vec_get(vy, br), y) < 1e-15, (br, bc)
+    finally:
+        os.environ.pop("PYNAMA_BCSR_LANES", None)
     ctx.close()
