@@ -20,7 +20,8 @@ Next to the headline the same run reports, outside the timed region (N = 1 only)
     quadrature path (the reference integrates every cell, spectral.py:117-156), not the
     parallelepiped closed form the uniform box admits;
   * `configs`: the other single-GPU configurations of BASELINE.json (C1 2-D plumbing case, C2
-    128^3 Poisson, C3 128^3 KLE with 3 DOFs per node, C5 5 M tetrahedra with GMRES(30)+Jacobi),
+    128^3 Poisson, C3 128^3 KLE with 3 DOFs per node, C5 5 M tetrahedra with GMRES(30)+Jacobi)
+    and the reference's own element order (HO3_2D: 1024^2, HO3_3D: 64^3 second-order cells, KLE),
     each with its residual check;
   * `matrix_free`: the same CG with the operator recomputed from the mesh.
 
@@ -205,50 +206,216 @@ def config_poisson(_lib, DMPlexDom, Spectral, nelem, cg_iters, name):
 def config_kle(_lib, DMPlexDom, Spectral, n, cg_iters, jitter=0.0):
     """C3: 3 DOFs per node on the 128^3 mesh -- the reference's KLE system stands in for 'linear elasticity' (SURVEY.md 0.3:
     the reference has no elasticity form; K is its vector-valued stiffness with 3x3 blocks).  jitter > 0: general geometry
-    (every cell integrated with 8 + 1 Gauss points, as spectral.py:117-156 does)"""
+    (every cell integrated with 8 + 1 Gauss points, as spectral.py:117-156 does).  Around the solve: the one-off products of
+    solveKLE (base_problem.py:481), the operator chain of evalRHS (:212-232), the matrix-free K, the refresh of K's solver image."""
     dom = DMPlexDom(boxMesh={"nelem": [n, n, n], "lower": [0, 0, 0], "upper": [1, 1, 1]}, jitter=jitter)
     dom.setFemIndexing(2)
     ctx = dom.ctx
-    for t in Spectral(2, 3).deviceTables():
+    sp = Spectral(2, 3)
+    for t in sp.deviceTables():
         ctx.tables_set(*t)
     bm = dom.boundaryMaskLocal()
-    ctx.bc_set(3, np.repeat(bm[:, None], 3, axis=1))
+    mask3 = np.repeat(bm[:, None], 3, axis=1)
+    ctx.bc_set(3, mask3)
     n_rows, nnz = ctx.csr_symbolic()
     K, Krhs, Rw = ctx.mat_create(3, 3), ctx.mat_create(3, 3), ctx.mat_create(3, 3)
-    ctx.assemble_kle(1e3, 1e2, K, Krhs, Rw, -1)
-    med, best = median_assembly(ctx, lambda: ctx.assemble_kle(1e3, 1e2, K, Krhs, Rw, -1), 3)
     B_asm1, B_spmv, B_cg = algorithmic_bytes(n ** 3, n_rows, nnz, ndof=3)
     B_asm = 3 * B_asm1                      # three block matrices leave the assembly: K, Krhs, Rw (4.46 GB each, SURVEY.md 8d)
-    # ... of which the timed calls do not write Krhs again where it is known to be zero (rows away from imposed nodes: the matrix was
-    # assembled for the same Dirichlet set by the warm-up call); the fraction on the bytes that DO move is reported next to the model's
-    n_bnd_nodes = int(bm[:dom.nOwned].astype(bool).sum())
-    B_moved = 2 * B_asm1 + 8.0 * 9 * 27 * 8 * n_bnd_nodes    # K and Rw in full; Krhs: about the 3x3x3 tiles that touch the boundary
+    # ONE assembly figure: every timed call writes all three matrices in full, as a first (cold) assembly does -- model bytes ==
+    # bytes that move.  (Repeated assemblies for an unchanged Dirichlet set may leave the zero blocks of Krhs unwritten: reported next to it.)
+    os.environ["PYNAMA_RHS_FULL_WRITE"] = "1"
+    try:
+        ctx.assemble_kle(1e3, 1e2, K, Krhs, Rw, -1)
+        med, best = median_assembly(ctx, lambda: ctx.assemble_kle(1e3, 1e2, K, Krhs, Rw, -1), 3)
+    finally:
+        del os.environ["PYNAMA_RHS_FULL_WRITE"]
+    med_skip, _ = median_assembly(ctx, lambda: ctx.assemble_kle(1e3, 1e2, K, Krhs, Rw, -1), 3)
     vel = np.zeros((dom.nOwned, 3))
     vel[bm[:dom.nOwned] != 0] = [1.0, 0.0, 0.0]
-    vv, vr, vx = ctx.vec_create(3), ctx.vec_create(3), ctx.vec_create(3)
+    vv, vr, vx, vw, vy = ctx.vec_create(3), ctx.vec_create(3), ctx.vec_create(3), ctx.vec_create(3), ctx.vec_create(3)
     ctx.vec_set(vv, vel.ravel())
-    ctx.spmv(Krhs, vv, vr)                  # zero vorticity: rhs = Krhs v_bc (base_problem.py:479-481)
+    ctx.vec_set(vw, np.random.default_rng(1).standard_normal(n_rows * 3))
+    t_kr, t_rw = [], []
+    for _ in range(5):                      # rhs = Rw w + Krhs v (base_problem.py:479-481): block-CSR values read directly, no image
+        ctx.spmv(Rw, vw, vy)
+        t_rw.append(ctx.timers()["spmv_ms"])
+        ctx.spmv(Krhs, vv, vr)              # zero vorticity: rhs = Krhs v_bc
+        t_kr.append(ctx.timers()["spmv_ms"])
+    # first solve after an assembly: the refresh of K's solver image is inside this wall time and nowhere else
+    ctx.assemble_kle(1e3, 1e2, K, -1, -1, -1)
+    ctx.sync()
+    t0 = time.perf_counter()
+    ctx.solve(K, vr, vx, fixed_iters=5)
+    t1 = time.perf_counter()
+    ctx.solve(K, vr, vx, fixed_iters=5)
+    t2 = time.perf_counter()
+    refresh_ms = 1e3 * ((t1 - t0) - (t2 - t1))
     for _ in range(2):
         info = ctx.solve(K, vr, vx, fixed_iters=cg_iters, profile=1)
     chk = ctx.solve(K, vr, vx, rtol=1e-10, maxit=20000, norm_type=_lib.NORM_UNPRECONDITIONED)
     err = float(np.abs(ctx.vec_get(vx, 3).reshape(-1, 3) - [1.0, 0.0, 0.0]).max())
+    # the same solve with K recomputed from the mesh instead of read from HBM (PETSc: Amat = shell, Pmat = assembled)
+    mfree = None
+    try:
+        ctx.matfree_set(_lib.MATFREE_KLE, 1e3, 1e2)
+        tm = []
+        for _ in range(5):
+            ctx.matfree_apply(vv, vy, _lib.MATFREE_KLE)
+            tm.append(ctx.timers()["spmv_ms"])
+        for _ in range(2):
+            mi = ctx.solve(K, vr, vx, fixed_iters=cg_iters, profile=1, matfree=_lib.MATFREE_KLE)
+        mc = ctx.solve(K, vr, vx, rtol=1e-10, maxit=20000, norm_type=_lib.NORM_UNPRECONDITIONED, matfree=_lib.MATFREE_KLE)
+        mfree = {"product_ms": float(np.median(tm[1:])), "cg_iters_per_s": cg_iters / (mi.solve_ms * 1e-3),
+                 "kernel": "lattice_matfree_kle_kernel (Laplacian per component + rank-9 penalty correction per cell, no matrix values)",
+                 "check": {"cg_iters_to_rtol_1e-10": int(mc.iters), "reason": int(mc.reason), "true_residual_vs_assembled_matrix": float(mc.true_resid),
+                           "solve_ms": float(mc.solve_ms)},
+                 "note": "opt-in (-pynama_mat_free); refused unless the shell reproduces the assembled product on b"}
+    except _lib.PynamaHipError as e:
+        mfree = {"error": str(e)}
+    # operator chain of evalRHS after the solve (base_problem.py:216-232): v(x)v, SrT v, axpy, DivSrT, scale, Curl
+    chain = None
+    try:
+        ops = sp.operatorTerms()
+        mats = {}
+        for name in ("SrT", "DivSrT", "Curl"):
+            br, bc, terms, coef = ops[name]
+            mats[name] = (ctx.mat_create(br, bc), br, bc)
+            ctx.assemble_operator(_lib.Q_NODAL, terms, coef, mats[name][0])
+        v6a, v6b, v3 = ctx.vec_create(6), ctx.vec_create(6), ctx.vec_create(3)
+        parts = {}
+
+        def timed(label, fn, is_spmv):
+            ts = []
+            for _ in range(4):
+                ctx.sync()
+                t_a = time.perf_counter()
+                fn()
+                ctx.sync()
+                ts.append(ctx.timers()["spmv_ms"] if is_spmv else 1e3 * (time.perf_counter() - t_a))
+            parts[label] = float(np.median(ts[1:]))
+        timed("vtensv", lambda: ctx.vec_vtensv(vx, v6b), False)
+        timed("SrT_product", lambda: ctx.spmv(mats["SrT"][0], vx, v6a), True)
+        timed("axpby", lambda: ctx.vec_axpby(v6a, 2.0 * 0.01, v6a, -1.0, v6b), False)
+        timed("DivSrT_product", lambda: ctx.spmv(mats["DivSrT"][0], v6a, v3), True)
+        timed("Curl_product", lambda: ctx.spmv(mats["Curl"][0], v3, vy), True)
+        fr = {}
+        for name, key in (("SrT", "SrT_product"), ("DivSrT", "DivSrT_product"), ("Curl", "Curl_product")):
+            _, br, bc = mats[name]
+            b_op = 8.0 * nnz * br * bc + 4.0 * nnz + 4.0 * (n_rows + 1) + 8.0 * n_rows * (br + bc)
+            fr[name] = {"ms": parts[key], "bytes": b_op, "frac_of_hbm_peak": b_op / (parts[key] * 1e-3) / 1e9 / HBM_PEAK_GBS}
+        chain = {"operator_products": fr, "vtensv_ms_wall": parts["vtensv"], "axpby_ms_wall": parts["axpby"],
+                 "rhs_products_ms": {"Rw": float(np.median(t_rw[1:])), "Krhs": float(np.median(t_kr[1:]))},
+                 "sum_without_solve_ms": float(np.median(t_rw[1:]) + np.median(t_kr[1:]) + sum(parts.values())),
+                 "note": "everything evalRHS does around the KLE solve; products straight from the block-CSR values (bcsr_spmv_kernel), "
+                         "vector kernels as host wall time including the launch"}
+    except _lib.PynamaHipError as e:
+        chain = {"error": str(e)}
     out = {"config": f"C3: 3D KLE (3 DOF/node, alpha_d 1e3, alpha_w 1e2) on {n}^3 Q1 hex, uniform-flow boundary data"
                      + (f", nodes jittered by {jitter} h (general geometry)" if jitter else ""), "n_elem": n ** 3,
            "n_dof": 3 * n_rows, "nnz_blocks": nnz, "assembly_ms_K_Krhs_Rw": med,
            "element_dofs_per_s": n ** 3 * 24 / (med * 1e-3),
            "assembly_frac_of_hbm_peak": B_asm / (med * 1e-3) / 1e9 / HBM_PEAK_GBS,
-           "assembly_frac_on_bytes_moved": B_moved / (med * 1e-3) / 1e9 / HBM_PEAK_GBS,
-           "assembly_note": "assembly_frac_of_hbm_peak uses SURVEY.md 8d's model (three block matrices written once each = "
-                            f"{B_asm / 1e9:.2f} GB); the timed calls leave the zero blocks of Krhs unwritten (same Dirichlet set as the "
-                            f"warm-up call), about {B_moved / 1e9:.2f} GB move",
+           "assembly_note": f"every timed call writes K, Krhs and Rw in full (what a first, cold assembly does): {B_asm / 1e9:.2f} GB by SURVEY.md "
+                            "8d's model = the bytes that move.  A repeated assembly for an unchanged Dirichlet set leaves the zero blocks of "
+                            f"Krhs unwritten and takes {med_skip:.3f} ms",
+           "assembly_ms_rhs_zero_blocks_skipped": med_skip,
            "kernel": "assemble_q1_hex_kle_lattice_kernel (four waves per tile; "
                      + ("general geometry: closed form of the 2x2x2 rule, Gauss points split over the waves for K, node columns for Rw)"
                         if jitter else "closed-form blocks on parallelepipeds)"),
            "cg_iters_per_s": cg_iters / (info.solve_ms * 1e-3), "block_spmv_ms": info.spmv_ms,
            "spmv_frac_of_hbm_peak": B_spmv / (info.spmv_ms * 1e-3) / 1e9 / HBM_PEAK_GBS if info.spmv_ms > 0 else None,
            "cg_iteration_frac_of_hbm_peak": B_cg / (info.solve_ms / cg_iters * 1e-3) / 1e9 / HBM_PEAK_GBS,
-           "format": "block SELL-64, one node-level column pattern id per row (block-CSR byte model of SURVEY.md 8d: 5.29 GB / iteration)",
+           "solver_image_refresh_ms": refresh_ms,
+           "format": "CG: block SELL-64 image of K (lane per scalar row, one node-level column pattern id per row), refreshed by the first solve "
+                     "after an assembly (solver_image_refresh_ms, paid once per K); Krhs, Rw and the operators are multiplied from their "
+                     "block-CSR values and have no image (block-CSR byte model of SURVEY.md 8d: 5.29 GB / iteration)",
+           "matrix_free": mfree, "evalRHS_chain": chain,
            "algorithmic_bytes": {"assembly_3_matrices": B_asm, "spmv": B_spmv, "cg_iteration": B_cg},
+           "check": {"cg_iters_to_rtol_1e-10": int(chk.iters), "reason": int(chk.reason), "true_residual": float(chk.true_resid),
+                     "max_error_vs_exact_uniform_flow": err}}
+    ctx.close()
+    return out
+
+
+def config_ho3(_lib, DMPlexDom, Spectral, dim, nel, cg_iters):
+    """Second-order elements (ngl = 3), the order EVERY case file of the reference sets (src/cases/*.yaml `ngl: 3`; eight of nine are 2-D):
+    KLE system on a structured box, 9-node quadrilaterals / 27-node hexahedra, Gauss(3)^dim + Gauss(2)^dim rules
+    (src/elements/spectral.py:41-43).  Assembly by the row-run kernels (pyn_assemble_ho3.hip), products from the block-CSR values."""
+    dw = 1 if dim == 2 else 3
+    dom = DMPlexDom(boxMesh={"nelem": [nel] * dim, "lower": [0] * dim, "upper": [1] * dim})
+    dom.setFemIndexing(3)
+    ctx = dom.ctx
+    for t in Spectral(3, dim).deviceTables():
+        ctx.tables_set(*t)
+    bm = dom.boundaryMaskLocal()
+    ctx.bc_set(dim, np.repeat(bm[:, None], dim, axis=1))
+    n_rows, nnzb = ctx.csr_symbolic()
+    symbolic_ms = ctx.timers()["symbolic_ms"]
+    topo = ctx.mesh_topology()[0]
+    K, Krhs, Rw = ctx.mat_create(dim, dim), ctx.mat_create(dim, dim), ctx.mat_create(dim, dw)
+    ne, nn = nel ** dim, 3 ** dim
+
+    def b_asm(br, bc):          # SURVEY.md 8(d) per matrix: conn + xyz + rowptr + colidx + values
+        return 4 * nn * ne + 8 * dim * n_rows + 4 * (n_rows + 1) + 4 * nnzb + 8 * nnzb * br * bc
+
+    os.environ["PYNAMA_HO3_REQUIRE"] = "1"          # the generic atomics kernel must not stand in silently
+    os.environ["PYNAMA_RHS_FULL_WRITE"] = "1"       # every timed call writes all three matrices in full: model bytes == bytes that move
+    try:
+        ctx.assemble_kle(1e3, 1e2, K, Krhs, Rw, -1)
+        med, best = median_assembly(ctx, lambda: ctx.assemble_kle(1e3, 1e2, K, Krhs, Rw, -1), 5)
+        del os.environ["PYNAMA_RHS_FULL_WRITE"]
+        med_skip, _ = median_assembly(ctx, lambda: ctx.assemble_kle(1e3, 1e2, K, Krhs, Rw, -1), 3)
+        med_k, _ = median_assembly(ctx, lambda: ctx.assemble_kle(1e3, 1e2, K, -1, -1, -1), 3)
+        med_rw, _ = median_assembly(ctx, lambda: ctx.assemble_kle(1e3, 1e2, -1, -1, Rw, -1), 3)
+    finally:
+        os.environ.pop("PYNAMA_RHS_FULL_WRITE", None)
+        del os.environ["PYNAMA_HO3_REQUIRE"]
+    B3 = 2 * b_asm(dim, dim) + b_asm(dim, dw)
+    N, nnz = n_rows * dim, nnzb * dim * dim
+    B_spmv = 8 * nnz + 4 * nnzb + 4 * (n_rows + 1) + 16 * N          # block-CSR model of SURVEY.md 8(d): one column index per block
+    B_cg = 8 * nnz + 4 * nnzb + 148 * N
+    cte = np.array([1.0, 0.0, 0.0][:dim])
+    vel = np.zeros((dom.nOwned, dim))
+    vel[bm[:dom.nOwned] != 0] = cte
+    vv, vr, vx, vw, vy = ctx.vec_create(dim), ctx.vec_create(dim), ctx.vec_create(dim), ctx.vec_create(dw), ctx.vec_create(dim)
+    ctx.vec_set(vv, vel.ravel())
+    ctx.vec_set(vw, np.random.default_rng(1).standard_normal(n_rows * dw))
+    t_kr, t_rw, t_k = [], [], []
+    for _ in range(6):          # rhs = Rw w + Krhs v (base_problem.py:481): one-off products, straight from the block-CSR values
+        ctx.spmv(Rw, vw, vy)
+        t_rw.append(ctx.timers()["spmv_ms"])
+        ctx.spmv(Krhs, vv, vr)
+        t_kr.append(ctx.timers()["spmv_ms"])
+        ctx.spmv(K, vv, vy)
+        t_k.append(ctx.timers()["spmv_ms"])
+    for _ in range(2):
+        info = ctx.solve(K, vr, vx, fixed_iters=cg_iters, profile=1)
+    chk = ctx.solve(K, vr, vx, rtol=1e-10, maxit=100000, norm_type=_lib.NORM_UNPRECONDITIONED)
+    err = float(np.abs(ctx.vec_get(vx, dim).reshape(-1, dim) - cte).max())
+    avg_row = nnzb * dim / n_rows
+    out = {"config": f"HO3_{dim}D: {dim}-D KLE ({dim} DOF/node, alpha_d 1e3, alpha_w 1e2) on {nel}^{dim} second-order (ngl 3, {nn}-node) cells, "
+                     "uniform-flow boundary data -- the element order of every reference case (src/cases/*.yaml)",
+           "topology": topo, "n_elem": ne, "n_dof": N, "nnz_blocks": nnzb, "symbolic_ms_closed_form": symbolic_ms,
+           "assembly_ms_K_Krhs_Rw": med, "assembly_ms_min": best,
+           "element_dofs_per_s": ne * nn * dim / (med * 1e-3),
+           "assembly_frac_of_hbm_peak": B3 / (med * 1e-3) / 1e9 / HBM_PEAK_GBS,
+           "assembly_note": f"all three matrices written in full by every timed call ({B3 / 1e9:.2f} GB by SURVEY.md 8d's model = the bytes that move); "
+                            "with the zero blocks of Krhs left unwritten (same Dirichlet set as the previous call) the call takes "
+                            f"{med_skip:.3f} ms",
+           "assembly_ms_K_alone": med_k, "assembly_frac_K_alone": b_asm(dim, dim) / (med_k * 1e-3) / 1e9 / HBM_PEAK_GBS,
+           "assembly_ms_Rw_alone": med_rw, "assembly_frac_Rw_alone": b_asm(dim, dw) / (med_rw * 1e-3) / 1e9 / HBM_PEAK_GBS,
+           "kernel": "assemble_ho3_lattice_kernel (one workgroup per run of consecutive node rows of an x-line: LDS image of that piece of "
+                     "the block-CSR values, (row, element, column node) triples one per lane, closed-form blocks on parallelepipeds, "
+                     "ds_add_f64, one coalesced copy out; no HBM atomics, nothing integrated twice)",
+           "cg_iters_per_s": cg_iters / (info.solve_ms * 1e-3), "block_spmv_ms_in_cg": info.spmv_ms,
+           "spmv_frac_of_hbm_peak": B_spmv / (info.spmv_ms * 1e-3) / 1e9 / HBM_PEAK_GBS if info.spmv_ms > 0 else None,
+           "cg_iteration_frac_of_hbm_peak": B_cg / (info.solve_ms / cg_iters * 1e-3) / 1e9 / HBM_PEAK_GBS,
+           "product_ms_one_off": {"K": float(np.median(t_k[1:])), "Krhs": float(np.median(t_kr[1:])), "Rw": float(np.median(t_rw[1:]))},
+           "format": ("block-CSR values read directly (bcsr_spmv_kernel: 16 lanes per node row)"
+                      if avg_row >= 128 else
+                      "CG: block SELL-64 image (lane per scalar row), refreshed once per assembly; one-off products (Krhs v, Rw w): block-CSR "
+                      "values read directly (bcsr_spmv_kernel)") + "; byte model: 8 B per value + 4 B per block of column index + vectors",
+           "algorithmic_bytes": {"assembly_3_matrices": B3, "spmv": B_spmv, "cg_iteration": B_cg},
            "check": {"cg_iters_to_rtol_1e-10": int(chk.iters), "reason": int(chk.reason), "true_residual": float(chk.true_resid),
                      "max_error_vs_exact_uniform_flow": err}}
     ctx.close()
@@ -480,7 +647,9 @@ def main():
                                                        "C2: 3D Poisson on 128^3 Q1 hex, FP64 assembly + Jacobi-PCG")),
                         ("C3", lambda: config_kle(_lib, DMPlexDom, Spectral, 128, 50)),
                         ("C3_general_geometry", lambda: config_kle(_lib, DMPlexDom, Spectral, 128, 50, jitter=0.2)),
-                        ("C5", lambda: config_tets(_lib, DMPlexDom, 94, 300))):
+                        ("C5", lambda: config_tets(_lib, DMPlexDom, 94, 300)),
+                        ("HO3_2D", lambda: config_ho3(_lib, DMPlexDom, Spectral, 2, 1024, 50)),
+                        ("HO3_3D", lambda: config_ho3(_lib, DMPlexDom, Spectral, 3, 64, 50))):
             try:
                 extra[key] = fn()
             except Exception as e:                      # a failing side configuration must not take the headline line with it

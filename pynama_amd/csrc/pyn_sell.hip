@@ -838,7 +838,8 @@ int pyn_sell_spmv_range2(pyn_ctx* c, const DMat& A, const double* x, double* y, 
       lg = gg >= 64 ? 6 : gg >= 32 ? 5 : gg >= 16 ? 4 : 3;
     } else {
       const double avg = (double)c->nnzb * A.bc / (double)std::max<int64_t>(1, c->n_owned);   // entries per scalar row
-      lg = avg >= 160.0 ? 6 : avg >= 56.0 ? 5 : avg >= 20.0 ? 4 : 3;
+      lg = avg >= 56.0 ? 4 : 3;   // measured (tools/block_spmv_case.py): 16 lanes for 81 .. 375 entries per scalar row, 8 below; 32 / 64 lanes lose
+                                  // 5-10 % even on the longest rows (fewer node rows, i.e. fewer independent load streams, per wave)
     }
     const char* ue = getenv("PYNAMA_BCSR_UNROLL");
     const int un = ue ? atoi(ue) : 4;
