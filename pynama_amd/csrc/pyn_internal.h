@@ -82,6 +82,7 @@ struct DMat {
   bool sell_valid = false;     // the image holds the current values
   bool prod_ready = false;     // pyn_sell_ensure has chosen the product kernel for the current values (image / CSR values)
   bool csr_product = false;    // scalar dictionary-mode matrix: the product reads `val` directly (csrl_spmv_kernel), there is no image (decided in pyn_sell_ensure)
+  bool csrlb_product = false;  // 2x2-block dictionary-mode matrix: lane per scalar row over LDS-staged runs of the block-CSR values (csrlb_spmv_kernel), no image
   bool bcsr_product = false;   // block matrix / long scalar rows: the product reads the block-CSR values directly (bcsr_spmv_kernel), no image either
   double* dinv = nullptr;      // 1 / diagonal per scalar row (Jacobi), written by the lattice assemblies in their store
   bool dinv_valid = false;     // phase, else extracted once per matrix version (pyn_dinv_ensure)

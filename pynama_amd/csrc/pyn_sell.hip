@@ -409,6 +409,100 @@ __global__ void __launch_bounds__(64 * CSRL_WAVES) csrl_spmv_kernel(const int32_
   }
 }
 
+// The same for BLOCK matrices whose node rows follow the dictionary (2-D second-order elements: 25 / 15 / 9 column nodes, 2x2 blocks, i.e.
+// 50 / 30 / 18 entries per scalar row): lane = scalar row (i, p), the 64 rows of a slice are one contiguous run of the block-CSR values
+// ((rowptr[i] BR + p len_i) BC), read coalesced, parked in LDS, walked per lane; x entries from the node pattern: (i + t[k / BC]) BC + k % BC.
+// No image (the SELL image of such a matrix pads every slice to its longest row: 20 % on alternating vertex / edge rows), no refresh.
+constexpr int CSRLB_WAVES = 2;
+template <int W, int BR, int BC, bool GL, bool DOT>
+__global__ void __launch_bounds__(64 * CSRLB_WAVES) csrlb_spmv_kernel(const int32_t* __restrict__ rowptr, const int32_t* __restrict__ pid,
+                                                                      const int32_t* __restrict__ tab, int npat, const double* __restrict__ val,
+                                                                      const double* __restrict__ x, double* __restrict__ y, int64_t n_rows,
+                                                                      int64_t n_slices, const int* __restrict__ flag, double* __restrict__ part,
+                                                                      int64_t s_begin, int part_off, int64_t hole_begin, int64_t hole_len) {
+  extern __shared__ double csrl_lds[];   // [CSRLB_WAVES][64 W] values | [(npat + 1)][PAT_W] node pattern table
+  __shared__ double smd[CSRLB_WAVES];
+  if (flag && flag[0]) return;
+  int32_t* ltab = reinterpret_cast<int32_t*>(csrl_lds + CSRLB_WAVES * 64 * W);
+  for (int i = threadIdx.x; i < (npat + 1) * PAT_W; i += 64 * CSRLB_WAVES) ltab[i] = i < npat * PAT_W ? tab[i] : 0;
+  __syncthreads();
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  double* __restrict__ buf = csrl_lds + wv * 64 * W;
+  const int64_t w0 = (int64_t)blockIdx.x * CSRLB_WAVES + wv;
+  const int64_t nw = (int64_t)gridDim.x * CSRLB_WAVES;
+  const int64_t n_nodes = n_rows / BR;
+  double dot = 0.0;
+  for (int64_t sq = s_begin + w0; sq < n_slices; sq += nw) {   // n_slices: logical end (hole removed)
+    const int64_t s = sq >= hole_begin ? sq + hole_len : sq;
+    const int64_t row = s * SH + lane;
+    const bool live = row < n_rows;
+    const int64_t node = live ? row / BR : n_nodes;
+    const int p = live ? (int)(row - node * BR) : 0;
+    const int rp0 = rowptr[node], len = live ? rowptr[node + 1] - rp0 : 0;
+    const int64_t off64 = ((int64_t)rp0 * BR + (int64_t)p * len) * BC;
+    const int L1 = len * BC;
+    // first entry of the slice and its length (lane 0 is always live; dead lanes sit at the end of the array)
+    const int64_t base = ((int64_t)__builtin_amdgcn_readfirstlane((int)(off64 >> 32)) << 32) |
+                         (uint32_t)__builtin_amdgcn_readfirstlane((int)(off64 & 0xffffffff));
+    const int my = (int)(off64 - base);
+    const int total = __builtin_amdgcn_readlane(my + L1, 63);
+    const double* __restrict__ v = val + base;
+    const int32_t* __restrict__ t = ltab + (live ? pid[node] : npat) * PAT_W;
+    const int64_t nb = live ? node : 0;
+    double xg[W];
+    if (GL) {
+      // long rows (W = 50): the run goes global -> LDS without passing through registers (LDS-DMA, 16 B per lane = 1 KiB per wave
+      // instruction, destination = wave base + lane x 16: exactly the contiguous image wanted); an odd last entry by one plain load
+#pragma unroll
+      for (int j = 0; j < (W + 1) / 2; ++j) {
+        const int e = 128 * j + 2 * lane;
+        if (e + 1 < total)
+          __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(v + e),
+                                           (__attribute__((address_space(3))) void*)(buf + 128 * j), 16, 0, 0);
+      }
+#pragma unroll
+      for (int k = 0; k < W; ++k) xg[k] = x[(nb + (k < L1 ? t[k / BC] : 0)) * BC + (k < L1 ? k % BC : 0)];
+      if ((total & 1) && lane == 0) buf[total - 1] = v[total - 1];
+      __builtin_amdgcn_s_waitcnt(0x0070);   // vmcnt(0) lgkmcnt(0): the DMA writes and the one plain LDS write have landed
+    } else {
+      double vr[W];
+#pragma unroll
+      for (int j = 0; j < W; ++j) vr[j] = (64 * j + lane < total) ? v[64 * j + lane] : 0.0;
+#pragma unroll
+      for (int k = 0; k < W; ++k) xg[k] = x[(nb + (k < L1 ? t[k / BC] : 0)) * BC + (k < L1 ? k % BC : 0)];
+#pragma unroll
+      for (int j = 0; j < W; ++j) buf[64 * j + lane] = vr[j];
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    double a0 = 0.0, a1 = 0.0;
+#pragma unroll
+    for (int k = 0; k + 1 < W; k += 2) {
+      a0 = fma(k < L1 ? buf[my + k] : 0.0, xg[k], a0);
+      a1 = fma(k + 1 < L1 ? buf[my + k + 1] : 0.0, xg[k + 1], a1);
+    }
+    if (W & 1) a0 = fma(W - 1 < L1 ? buf[my + W - 1] : 0.0, xg[W - 1], a0);
+    const double acc = a0 + a1;
+    if (live) {
+      y[row] = acc;
+      if (DOT) dot += acc * x[row];
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();   // every lane has read its row before the next run overwrites the buffer
+  }
+  if (DOT) {
+    dot = wsum64(dot);
+    if (lane == 0) smd[wv] = dot;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      double sm = 0.0;
+      for (int i = 0; i < CSRLB_WAVES; ++i) sm += smd[i];
+      part[part_off + blockIdx.x] = sm;
+    }
+  }
+}
+
 // Block matrices: lane = scalar row (i,p); columns come from the NODE-level dictionary
 // (col = (i + off[k / BC]) * BC + k % BC) or from the explicit expanded column array.
 template <int BC, bool PAT, bool DOT>
@@ -717,20 +811,22 @@ int pyn_sell_ensure(pyn_ctx* c, DMat& A, bool solver) {
   }
   A.csr_product = csr_product(c, A, S);
   A.bcsr_product = false;
+  A.csrlb_product = !A.csr_product && A.br == 2 && A.bc == 2 && c->sell_npat > 0 && S->maxw <= 50 && !getenv("PYNAMA_BLOCK_SELL") &&
+                    !getenv("PYNAMA_NO_CSRLB");
   int bm = 0;
-  if (!A.csr_product) {
+  if (!A.csr_product && !A.csrlb_product) {
     bm = bcsr_mode(c, A);
     if (A.br == 1 && A.bc == 1 && !(S->maxw > PAT_W && !getenv("PYNAMA_SELL_IMAGE"))) bm = 0;   // scalar rows inside the dictionary's width keep their kernels
     A.bcsr_product = bm == 1 || (bm == 2 && !solver && !(A.sell_val && A.sell_valid));
   }
-  if (A.csr_product || bm == 1) {   // never an image: the products read A.val
+  if (A.csr_product || A.csrlb_product || bm == 1) {   // never an image: the products read A.val
     if (A.sell_val) {
       (void)hipFree(A.sell_val);
       A.sell_val = nullptr;
     }
     A.sell_valid = false;
   }
-  if (A.csr_product || A.bcsr_product) {
+  if (A.csr_product || A.csrlb_product || A.bcsr_product) {
     A.prod_ready = true;
     return PYN_OK;
   }
@@ -842,7 +938,8 @@ int pyn_sell_spmv_range2(pyn_ctx* c, const DMat& A, const double* x, double* y, 
                                   // 5-10 % even on the longest rows (fewer node rows, i.e. fewer independent load streams, per wave)
     }
     const char* ue = getenv("PYNAMA_BCSR_UNROLL");
-    const int un = ue ? atoi(ue) : 4;
+    const double avg_row = (double)c->nnzb * A.bc / (double)std::max<int64_t>(1, c->n_owned);
+    const int un = ue ? atoi(ue) : (avg_row >= 24.0 ? 8 : 4);   // entries per lane and trip: whole rows in one trip where the registers allow
     const int npw = 64 >> lg;
     const char* wcu = getenv("PYNAMA_BCSR_WGS_PER_CU");
     const int64_t want = (n1 - n0 + 4 * npw - 1) / (4 * npw);
@@ -866,6 +963,8 @@ int pyn_sell_spmv_range2(pyn_ctx* c, const DMat& A, const double* x, double* y, 
       BCSR_LAUNCH_U(RR, CC, 2, DD);             \
     else if (un == 3)                           \
       BCSR_LAUNCH_U(RR, CC, 3, DD);             \
+    else if (un == 8)                           \
+      BCSR_LAUNCH_U(RR, CC, 8, DD);             \
     else                                        \
       BCSR_LAUNCH_U(RR, CC, 4, DD);             \
   } while (0)
@@ -896,6 +995,38 @@ int pyn_sell_spmv_range2(pyn_ctx* c, const DMat& A, const double* x, double* y, 
 #undef BCSR_LAUNCH
     PYN_HIP(hipGetLastError());
     if (grid_out) *grid_out = gridb;
+    return PYN_OK;
+  }
+  if (A.csrlb_product) {   // 2x2 blocks in dictionary mode: lane per scalar row over LDS-staged runs of the block-CSR values
+    const int W = S->maxw <= 18 ? 18 : (S->maxw <= 32 ? 32 : 50);
+    const size_t lds = (size_t)CSRLB_WAVES * 64 * W * sizeof(double) + (size_t)(c->sell_npat + 1) * PAT_W * sizeof(int32_t);
+    const char* gcu = getenv("PYNAMA_CSRLB_WGS_PER_CU");
+#define CSRLB_LAUNCH(WW, DD)                                                                                                              \
+  do {                                                                                                                                    \
+    static int per_cu = 0;                                                                                                                \
+    if (!per_cu) {                                                                                                                        \
+      PYN_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(csrlb_spmv_kernel<WW, 2, 2, (WW > 32), DD>), hipFuncAttributeMaxDynamicSharedMemorySize, \
+                                  (int)(CSRLB_WAVES * 64 * WW * sizeof(double) + (PAT_MAX + 1) * PAT_W * sizeof(int32_t))));             \
+      PYN_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, csrlb_spmv_kernel<WW, 2, 2, (WW > 32), DD>, 64 * CSRLB_WAVES, lds));            \
+      per_cu = std::max(1, per_cu);                                                                                                       \
+    }                                                                                                                                     \
+    gridc = (int)std::max<int64_t>(1, std::min<int64_t>(std::min<int64_t>((s1 - s0 + CSRLB_WAVES - 1) / CSRLB_WAVES, max_grid),         \
+                                                        256 * (gcu ? atoi(gcu) : per_cu)));                                              \
+    PYN_CHECK(poff + gridc <= PYN_MAX_PARTIALS, "partial buffer overflow");                                                               \
+    csrlb_spmv_kernel<WW, 2, 2, (WW > 32), DD><<<gridc, 64 * CSRLB_WAVES, lds, st>>>(c->d_rowptr, c->sell_pid, c->sell_tab, c->sell_npat, A.val, x, y, \
+                                                                          c->n_owned * A.br, s1, DD ? c->d_flag : nullptr,                \
+                                                                          DD ? c->d_part : nullptr, s0, poff, hb, hl);                    \
+  } while (0)
+    int gridc = 1;
+    if (W == 18 && dot) CSRLB_LAUNCH(18, true);
+    else if (W == 18) CSRLB_LAUNCH(18, false);
+    else if (W == 32 && dot) CSRLB_LAUNCH(32, true);
+    else if (W == 32) CSRLB_LAUNCH(32, false);
+    else if (dot) CSRLB_LAUNCH(50, true);
+    else CSRLB_LAUNCH(50, false);
+#undef CSRLB_LAUNCH
+    PYN_HIP(hipGetLastError());
+    if (grid_out) *grid_out = gridc;
     return PYN_OK;
   }
   if (A.csr_product) {   // straight from the CSR values (decided once per pyn_sell_ensure, not per launch)

@@ -23,8 +23,45 @@ import numpy as np
 
 from pynama_amd import _lib
 from pynama_amd.common.comm import get_world
-from pynama_amd.domain.indices import IndicesManager
 from pynama_amd.elements.spectral import _local_lattice
+
+
+class IndicesManager:
+    """Node / DOF bookkeeping of a domain (the role of src/domain/indices.py).  The reference's entity -> node maps driven by
+    PetscSection offsets (:66-114) are the closed-form lattice numbering of DMPlexDom here; what is left is the DOF
+    interleave (:90-92) and the Dirichlet / no-slip node sets (:45-64), which every rank holds globally (borders are closed
+    form: no allgather)."""
+
+    def __init__(self, dim, ngl, comm):
+        self.logger = logging.getLogger(f"[{comm.rank}] IndicesManager Class")
+        self.comm, self.dim, self._ngl = comm, dim, ngl
+        self._sets = {"dirichlet": set(), "noslip": set()}
+
+    def getNGL(self):
+        return self._ngl
+
+    def getNumCompAndNumDof(self, componentsPerField, numFields):
+        """components per field, DOFs per mesh entity (vertex, edge, face[, cell]): an entity of dimension k carries (ngl - 2)^k nodes"""
+        inner = self._ngl - 2
+        return [componentsPerField] * numFields, [componentsPerField * inner ** k for k in range(self.dim + 1)]
+
+    def setDirichletNodes(self, nodes: set):
+        self._sets["dirichlet"].update(nodes)
+
+    def getDirichletNodes(self):
+        self.globalIndicesDIR = set(self._sets["dirichlet"])
+        return self._sets["dirichlet"]
+
+    def setNoSlipNodes(self, nodes: set):
+        self._sets["noslip"].update(nodes)
+
+    def getNoSlipNodes(self):
+        self.globalIndicesNS = set(self._sets["noslip"])
+        return self._sets["noslip"]
+
+    def mapNodesToIndices(self, nodes, dof):
+        """global DOF = node * dof + component, node-major (indices.py:90-92)"""
+        return (np.asarray(list(nodes), dtype=np.int64)[:, None] * dof + np.arange(dof)).ravel().tolist()
 
 
 class SlabPartition:

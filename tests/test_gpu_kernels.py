@@ -992,7 +992,7 @@ def test_lattice_kernels_fuzz_against_generic(lib):
             for x, y in ((A, B), (Ar, Br)):
                 vx, vy = ctx.mat_values(x, 1, 1), ctx.mat_values(y, 1, 1)
                 assert np.abs(vx - vy).max() <= FP_TOL * max(1e-300, np.abs(vy).max()), (case, nelem, size, rank, geom)
-            # KLE (the plan-free kernels need parallelepipeds; jittered meshes take the patch-plan kernels)
+            # KLE (plan-free lattice kernels: closed-form blocks on parallelepipeds, the closed form of the 2x2x2 rule on jittered meshes)
             mask3 = (rng.random((dom.nLocal, 3)) < rng.choice([0.0, 0.15])).astype(np.uint8)
             ctx.bc_set(3, mask3 if mask3.any() else None)
             K, Kr, Rw, K0, Kr0, Rw0 = (ctx.mat_create(3, 3) for _ in range(6))

@@ -35,10 +35,14 @@ for v in variants:
         env = {}
     elif v == "sell":
         env = {"PYNAMA_BLOCK_SELL": "1"}
+    elif v == "bcsr":                       # block-CSR kernel with its default lanes (no LDS-staged lane-per-row kernel)
+        env = {"PYNAMA_NO_CSRLB": "1"}
+    elif v.startswith("lb"):                # LDS-staged lane-per-row kernel with N workgroups per CU
+        env = {"PYNAMA_CSRLB_WGS_PER_CU": v[2:]} if len(v) > 2 else {}
     else:                                   # lanes[uUNROLL][wWGS_PER_CU], e.g. 32u3w6
         import re
         m = re.fullmatch(r"(\d+)(?:u(\d+))?(?:w(\d+))?", v)
-        env = {"PYNAMA_BCSR_LANES": m.group(1)}
+        env = {"PYNAMA_BCSR_LANES": m.group(1), "PYNAMA_NO_CSRLB": "1"}
         if m.group(2):
             env["PYNAMA_BCSR_UNROLL"] = m.group(2)
         if m.group(3):
