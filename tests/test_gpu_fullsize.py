@@ -293,3 +293,116 @@ def test_matrix_free_at_full_size(jitter):
     ctx.matfree_apply(vx, vz, op=_lib.MATFREE_KLE)
     assert rel_err(ctx.vec_get(vz, 3), ctx.vec_get(vy, 3)) < 2e-13
     ctx.close()
+
+
+# ---- entry-by-entry parity, at full size, of the kernels bench.py actually times (no explicit plan: the plan-free
+# ---- lattice / z-marching / KLE lattice kernels; the generic atomics kernel, variant 0, is the independent second opinion) ----------
+def _same_entries(ctx, a, b, br, bc, tol=2e-13):
+    va, vb = ctx.mat_values(a, br, bc), ctx.mat_values(b, br, bc)
+    err = np.abs(va - vb).max() / np.abs(vb).max()
+    assert err < tol, err
+
+
+@pytest.mark.parametrize("jitter", [0.0, 0.2])
+def test_c2_bench_kernels_128cubed_entry_by_entry(jitter):
+    """128^3 scalar Laplacian: the plan-free lattice kernel (uniform mesh: parallelepiped closed form) and the z-marching kernel
+    (jitter 0.2: 2x2x2 rule per cell) against the generic kernel, A and Arhs, with the boundary mask"""
+    from pynama_amd import _lib
+    n = 128
+    dom, ctx = _domain([n, n, n], jitter=jitter)
+    ctx.bc_set(1, dom.boundaryMaskLocal())
+    ctx.csr_symbolic()
+    assert ctx.mesh_topology()[0] == "lattice"
+    A, Ar, B, Br = (ctx.mat_create(1, 1) for _ in range(4))
+    ctx.assemble_scalar(_lib.FORM_LAPLACE, A, Ar, variant=1)            # what bench.py's C2 / headline / general-geometry legs launch
+    ctx.assemble_scalar(_lib.FORM_LAPLACE, B, Br, variant=0)
+    _same_entries(ctx, A, B, 1, 1)
+    _same_entries(ctx, Ar, Br, 1, 1)
+    ctx.close()
+
+
+@pytest.mark.parametrize("jitter", [0.0, 0.2])
+def test_c3_bench_kernels_128cubed_entry_by_entry(jitter):
+    """128^3 KLE: K, Krhs AND Rw of the plan-free KLE lattice kernels (closed-form blocks on the uniform mesh; element pre-pass +
+    closed form of the 2x2x2 rule with jitter 0.2) against the generic kernel"""
+    n = 128
+    dom, ctx = _domain([n, n, n], jitter=jitter)
+    bm = dom.boundaryMaskLocal()
+    ctx.bc_set(3, np.repeat(bm[:, None], 3, axis=1))
+    ctx.csr_symbolic()
+    K, Kr, Rw = (ctx.mat_create(3, 3) for _ in range(3))
+    ctx.assemble_kle(1e3, 1e2, K, Kr, Rw, -1, variant=1)                # no plan set: what bench.py's C3 legs launch
+    ref = ctx.mat_create(3, 3)
+    for target, ids in ((K, (ref, -1, -1)), (Kr, (-1, ref, -1)), (Rw, (-1, -1, ref))):   # one 4.1 GB reference matrix at a time
+        k0, kr0, rw0 = ids
+        if kr0 >= 0:                      # Krhs alone is not a request of the ABI: K goes along into a scratch matrix
+            scratch = ctx.mat_create(3, 3)
+            ctx.assemble_kle(1e3, 1e2, scratch, kr0, -1, -1, variant=0)
+            ctx.mat_destroy(scratch)
+        else:
+            ctx.assemble_kle(1e3, 1e2, k0, kr0, rw0, -1, variant=0)
+        _same_entries(ctx, target, ref, 3, 3)
+    ctx.close()
+
+
+@pytest.mark.parametrize("dim,nel", [(2, 1024), (3, 64)])
+def test_ho3_bench_kernels_entry_by_entry(dim, nel):
+    """bench.py's HO3_2D / HO3_3D meshes (1024^2, 64^3 second-order cells): K, Krhs, Rw of the row-run kernels against the generic
+    kernel entry by entry; K symmetric, rigid translations in its null space; the three product kernels agree"""
+    import os
+    from pynama_amd.domain.dmplex import DMPlexDom
+    from pynama_amd.elements.spectral import Spectral
+    dw = 1 if dim == 2 else 3
+    dom = DMPlexDom(boxMesh={'nelem': [nel] * dim, 'lower': [0.0] * dim, 'upper': [1.0] * dim})
+    dom.setFemIndexing(3)
+    ctx = dom.ctx
+    for t in Spectral(3, dim).deviceTables():
+        ctx.tables_set(*t)
+    bm = dom.boundaryMaskLocal()
+    ctx.bc_set(dim, np.repeat(bm[:, None], dim, axis=1))
+    n_rows, nnzb = ctx.csr_symbolic()
+    assert ctx.mesh_topology()[0] == "lattice-ngl3" and nnzb == (8 * nel + 1) ** dim       # per axis: n - 1 inner vertices x 5, 2 end vertices x 3, n mid nodes x 3
+    K, Kr, Rw = ctx.mat_create(dim, dim), ctx.mat_create(dim, dim), ctx.mat_create(dim, dw)
+    os.environ["PYNAMA_HO3_REQUIRE"] = "1"
+    try:
+        ctx.assemble_kle(1e3, 1e2, K, Kr, Rw, -1)
+    finally:
+        del os.environ["PYNAMA_HO3_REQUIRE"]
+    K0, Kr0 = ctx.mat_create(dim, dim), ctx.mat_create(dim, dim)
+    ctx.assemble_kle(1e3, 1e2, K0, Kr0, -1, -1, variant=0)
+    _same_entries(ctx, K, K0, dim, dim)
+    _same_entries(ctx, Kr, Kr0, dim, dim)
+    ctx.mat_destroy(K0)
+    ctx.mat_destroy(Kr0)
+    Rw0 = ctx.mat_create(dim, dw)
+    ctx.assemble_kle(1e3, 1e2, -1, -1, Rw0, -1, variant=0)
+    _same_entries(ctx, Rw, Rw0, dim, dw)
+    ctx.mat_destroy(Rw0)
+    # products: default kernel == block-CSR group kernel == SELL image, on the masked K
+    rng = np.random.default_rng(3)
+    u, v, Ku, Kv = (ctx.vec_create(dim) for _ in range(4))
+    ctx.vec_set(u, rng.standard_normal(n_rows * dim))
+    ctx.vec_set(v, rng.standard_normal(n_rows * dim))
+    ctx.spmv(K, u, Ku)
+    y0 = ctx.vec_get(Ku, dim)
+    for env in ({"PYNAMA_NO_CSRLB": "1", "PYNAMA_BCSR_MIN_AVG": "0"}, {"PYNAMA_BLOCK_SELL": "1"}):
+        os.environ.update(env)
+        try:
+            ctx.spmv(K, u, Ku)
+        finally:
+            for k in env:
+                del os.environ[k]
+        assert rel_err(ctx.vec_get(Ku, dim), y0) < 1e-13, env
+    ctx.spmv(K, u, Ku)
+    ctx.spmv(K, v, Kv)
+    assert abs(ctx.vec_dot(v, Ku) - ctx.vec_dot(u, Kv)) < 1e-10 * abs(ctx.vec_dot(v, Ku))       # symmetric after the elimination
+    # no mask: translations are annihilated
+    ctx.bc_set(dim, None)
+    ctx.assemble_kle(1e3, 1e2, K, -1, -1, -1)
+    for comp in range(dim):
+        tr = np.zeros((n_rows, dim))
+        tr[:, comp] = 1.0
+        ctx.vec_set(u, tr.ravel())
+        ctx.spmv(K, u, Ku)
+        assert ctx.vec_norm(Ku, 3) < 1e-8 * 1500.5
+    ctx.close()
