@@ -632,7 +632,8 @@ def main():
             del ci
     topo = ctx.mesh_topology()[0]
     world_size, rank = world.size, world.rank
-    nranks_rccl = selftest["nranks_seen_by_rccl"] if selftest else 1
+    nranks_rccl = selftest.get("nranks_seen_by_rccl") if selftest else 1      # None: shared-memory test transport, RCCL counted nothing
+    transport = selftest["transport"] if selftest else "none (one rank, no communicator)"
 
     # the headline context is released before the other configurations allocate theirs
     extra, general = None, None
@@ -702,7 +703,7 @@ def main():
             "config": {"workload": f"3D Poisson, {n}^3 Q1 hex elements, {n_node_global} DOFs, nnz {nnz_global}, "
                                    f"FP64 assembly + Jacobi-PCG ({args.cg_iters} its/step)",
                        "partition": f"z-slabs x{world_size}", "assembly_variant": args.variant, "cg_variant": cg_variant,
-                       "nranks_seen_by_rccl": nranks_rccl, "kernel_source_hash": _lib.source_hash()},
+                       "transport": transport, "nranks_seen_by_rccl": nranks_rccl, "kernel_source_hash": _lib.source_hash()},
             "roofline": roofline(spmv_kernel + (" (SELL-64 + column-pattern dictionary SpMV inside CG)" if spmv_kernel.startswith("sellp") else
                                                 " (SpMV inside CG straight from the CSR values: coalesced 64-row runs transposed through LDS, "
                                                 "column-pattern dictionary)"), B_spmv * share, spmv_mean,

@@ -84,9 +84,11 @@ int pyn_comm_init(pyn_ctx* ctx, int rank, int nranks, const void* unique_id, int
 int pyn_comm_init_shm(pyn_ctx* ctx, int rank, int nranks, const char* path, int64_t cap_bytes);
 int pyn_comm_barrier(pyn_ctx* ctx);               /* device + host barrier over all ranks */
 int pyn_comm_allreduce_f64(pyn_ctx* ctx, double* inout, int n, int op /*0 sum, 1 max*/);
-/* Start-up self-test of the communicator: RCCL's own rank count, all-reduce of 1 and of the rank, one halo exchange of a
- * rank-stamped vector on the main stream and one on the communication stream (the overlapped form of the CG), each checked
- * on the receiver.  info[5]: ranks seen by RCCL, sum(1), sum(rank), ghosts checked (main / communication stream).  The
+/* Start-up self-test of the communicators (all-reduces and halo exchanges have one each): RCCL's own rank count of both, all-reduce
+ * of 1 and of the rank, one halo exchange of a rank-stamped vector on the main stream, one on the communication stream (the
+ * overlapped form of the CG), and one on the communication stream WHILE an all-reduce is queued on the main stream, each checked on
+ * the receiver.  info[6]: ranks counted by RCCL (0: the shared-memory test transport), sum(1), sum(rank), ghosts checked (main /
+ * communication stream), sum(rank + 1) of the all-reduce that ran beside an exchange.  The
  * reference's analogue is implicit: PETSc checks its communicator at KSPSetUp / MatAssemblyEnd (src/solver/ksp_solver.py:19,
  * src/matrices/mat_generator.py:14-17).  Call after pyn_halo_set. */
 int pyn_comm_selftest(pyn_ctx* ctx, double* info, int ninfo);

@@ -250,8 +250,13 @@ class Context:
         """rank count seen by RCCL, all-reduce of 1 / of the rank, rank-stamped halo exchange on both streams (raises on a mismatch)"""
         info = np.zeros(8)
         _check(self.lib.pyn_comm_selftest(self.h, info, info.size))
-        return {"nranks_seen_by_rccl": int(info[0]), "allreduce_sum_ones": info[1], "allreduce_sum_ranks": info[2],
-                "halo_ghosts_checked_main_stream": int(info[3]), "halo_ghosts_checked_comm_stream": int(info[4])}
+        out = {"transport": "rccl" if info[0] > 0 else "shm (test transport: ranks share one GPU, no RCCL)",
+               "allreduce_sum_ones": info[1], "allreduce_sum_ranks": info[2],
+               "halo_ghosts_checked_main_stream": int(info[3]), "halo_ghosts_checked_comm_stream": int(info[4]),
+               "allreduce_beside_exchange_sum_ranks_plus_1": info[5]}
+        if info[0] > 0:
+            out["nranks_seen_by_rccl"] = int(info[0])      # counted by RCCL itself (ncclCommCount of both communicators)
+        return out
 
     def halo_set(self, n_owned, n_ghost, neigh, send_ptr, send_idx, recv_ptr):
         neigh = _i32(neigh)

@@ -14,16 +14,25 @@
 
 // layout of the shared-memory TEST transport (see pyn_comm_init_shm below)
 struct pyn_shm_hdr {
-  std::atomic<int> count;
+  std::atomic<int> count;    // barrier of the all-reduces (host thread of every rank)
   std::atomic<int> sense;
   int nranks;
   int64_t cap;   // outbox capacity per rank, bytes
+  std::atomic<int> hcount;   // barrier of the halo exchanges (stream callbacks): its own object, so that an exchange in flight on the
+  std::atomic<int> hsense;   // communication stream and an all-reduce on the main stream can never pair up with each other
 };
 struct pyn_shm_comm {
   unsigned char* base = nullptr;
   size_t size = 0;
-  int rank = 0, nranks = 1, local_sense = 0;
+  int rank = 0, nranks = 1, local_sense = 0, halo_sense = 0;
   int64_t cap = 0;
+  // asynchronous exchange: pinned staging per stream slot (0: main stream, 1: communication stream); a failure inside a stream
+  // callback is parked here and reported by the next call that can return it
+  double* stage_out[2] = {nullptr, nullptr};
+  double* stage_in[2] = {nullptr, nullptr};
+  size_t stage_in_cap[2] = {0, 0};
+  std::atomic<int> failed{0};
+  char fail_msg[256] = "";
   pyn_shm_hdr* hdr() const { return reinterpret_cast<pyn_shm_hdr*>(base); }
   double* ar(int r) const { return reinterpret_cast<double*>(base + 4096) + (size_t)r * 64; }
   int64_t* dir(int src) const { return reinterpret_cast<int64_t*>(base + 4096 + (size_t)nranks * 512) + (size_t)src * nranks * 2; }
@@ -119,8 +128,14 @@ extern "C" int pyn_ctx_destroy(pyn_ctx* c) {
   if (!c) return PYN_OK;
   (void)hipSetDevice(c->device);
   (void)hipStreamSynchronize(c->stream);
+  if (c->comm_halo) ncclCommDestroy(c->comm_halo);
   if (c->comm) ncclCommDestroy(c->comm);
   if (c->shm) {
+    (void)hipStreamSynchronize(c->comm_stream);
+    for (int k = 0; k < 2; ++k) {
+      (void)hipHostFree(c->shm->stage_out[k]);
+      (void)hipHostFree(c->shm->stage_in[k]);
+    }
     munmap(c->shm->base, c->shm->size);
     delete c->shm;
     c->shm = nullptr;
@@ -188,20 +203,65 @@ int pyn_ensure_work(pyn_ctx* c, size_t bytes) {
 // Shared-memory TEST transport: ranks are processes that may share one GPU; every exchange is staged through a POSIX
 // shared-memory file (device -> host copy, process barrier, host -> device copy).  Slow by construction; it exists so that
 // the distributed solver can be run end to end with world_size > 1 on a one-GPU box, where RCCL refuses duplicate devices.
-static int shm_barrier(pyn_shm_comm* m) {
-  pyn_shm_hdr* h = m->hdr();
-  m->local_sense ^= 1;
-  if (h->count.fetch_add(1, std::memory_order_acq_rel) == m->nranks - 1) {
-    h->count.store(0, std::memory_order_relaxed);
-    h->sense.store(m->local_sense, std::memory_order_release);
-    return PYN_OK;
+static bool shm_barrier_on(std::atomic<int>& count, std::atomic<int>& sense, int& local, int nranks) {
+  local ^= 1;
+  if (count.fetch_add(1, std::memory_order_acq_rel) == nranks - 1) {
+    count.store(0, std::memory_order_relaxed);
+    sense.store(local, std::memory_order_release);
+    return true;
   }
   const auto t0 = std::chrono::steady_clock::now();
-  while (h->sense.load(std::memory_order_acquire) != m->local_sense) {
-    if (std::chrono::steady_clock::now() - t0 > std::chrono::seconds(120)) PYN_CHECK(false, "shared-memory barrier: a rank did not arrive within 120 s");
+  while (sense.load(std::memory_order_acquire) != local) {
+    if (std::chrono::steady_clock::now() - t0 > std::chrono::seconds(120)) return false;
     sched_yield();
   }
+  return true;
+}
+
+static int shm_barrier(pyn_shm_comm* m) {
+  pyn_shm_hdr* h = m->hdr();
+  PYN_CHECK(shm_barrier_on(h->count, h->sense, m->local_sense, m->nranks), "shared-memory barrier: a rank did not arrive within 120 s");
   return PYN_OK;
+}
+
+// One halo exchange of the test transport, host side, run as a STREAM CALLBACK (hipLaunchHostFunc) between the device -> host copy
+// of the packed send buffer and the host -> device copies of the ghosts: the stream that carries the exchange stalls in here until
+// every rank has published its outbox, while the other stream of the process keeps computing -- the overlapped CG really races its
+// interior product against the exchange, as it does over RCCL.  No HIP call in here.
+struct ShmExchange {
+  pyn_shm_comm* m;
+  int slot, bs;
+  size_t send_bytes;
+  std::vector<int> neigh;
+  std::vector<int64_t> send_ptr, recv_ptr;
+};
+
+static void shm_exchange_host(void* arg) {
+  ShmExchange* e = static_cast<ShmExchange*>(arg);
+  pyn_shm_comm* m = e->m;
+  pyn_shm_hdr* h = m->hdr();
+  auto fail = [&](const char* what) {
+    if (!m->failed.exchange(1)) snprintf(m->fail_msg, sizeof(m->fail_msg), "shared-memory halo exchange: %s", what);
+  };
+  if (e->send_bytes) memcpy(m->outbox(m->rank), m->stage_out[e->slot], e->send_bytes);
+  for (size_t k = 0; k < e->neigh.size(); ++k) {
+    int64_t* d = m->dir(m->rank) + (size_t)e->neigh[k] * 2;
+    d[0] = e->send_ptr[k] * e->bs;
+    d[1] = (e->send_ptr[k + 1] - e->send_ptr[k]) * e->bs;
+  }
+  if (!shm_barrier_on(h->hcount, h->hsense, m->halo_sense, m->nranks)) fail("a rank did not arrive within 120 s");
+  for (size_t k = 0; k < e->neigh.size(); ++k) {
+    const int src = e->neigh[k];
+    const int64_t* d = m->dir(src) + (size_t)m->rank * 2;
+    const int64_t nr = (e->recv_ptr[k + 1] - e->recv_ptr[k]) * e->bs;
+    if (d[1] != nr) {
+      fail("halo plan mismatch between two ranks");
+      continue;
+    }
+    if (nr) memcpy(m->stage_in[e->slot] + e->recv_ptr[k] * e->bs, reinterpret_cast<const double*>(m->outbox(src)) + d[0], (size_t)nr * sizeof(double));
+  }
+  if (!shm_barrier_on(h->hcount, h->hsense, m->halo_sense, m->nranks)) fail("a rank did not arrive within 120 s");   // outboxes may be rewritten
+  delete e;
 }
 
 extern "C" int pyn_comm_init_shm(pyn_ctx* c, int rank, int nranks, const char* path, int64_t cap_bytes) {
@@ -235,6 +295,7 @@ int pyn_allreduce_dev(pyn_ctx* c, double* dbuf, int n, int op, hipStream_t st) {
   }
   if (!c->shm) return PYN_OK;
   pyn_shm_comm* m = c->shm;
+  PYN_CHECK(!m->failed.load(), "%s", m->fail_msg);
   PYN_CHECK(n <= 64, "shared-memory all-reduce: at most 64 values");
   double loc[64];
   PYN_HIP(hipMemcpyAsync(loc, dbuf, n * sizeof(double), hipMemcpyDeviceToHost, st));
@@ -275,6 +336,11 @@ extern "C" int pyn_comm_init(pyn_ctx* c, int rank, int nranks, const void* uid, 
   memcpy(&id, uid, sizeof(id));
   PYN_HIP(hipSetDevice(c->device));
   PYN_NCCL(ncclCommInitRank(&c->comm, nranks, id, rank));
+  // a SECOND communicator for the halo exchanges: the overlapped CG issues them on the communication stream while an all-reduce of
+  // the previous step may still be queued on the main stream -- with their own communicator nothing rests on how RCCL orders the
+  // operations of ONE communicator across streams
+  PYN_NCCL(ncclCommSplit(c->comm, 0, rank, &c->comm_halo, nullptr));
+  PYN_CHECK(c->comm_halo != nullptr, "ncclCommSplit returned no communicator for the halo exchanges");
   return PYN_OK;
 }
 
@@ -312,8 +378,14 @@ extern "C" int pyn_comm_selftest(pyn_ctx* c, double* info, int ninfo) {
   PYN_CHECK(pyn_has_comm(c), "self-test needs a communicator");
   PYN_HIP(hipSetDevice(c->device));
   int seen = c->nranks;
-  if (c->comm) PYN_NCCL(ncclCommCount(c->comm, &seen));
-  info[0] = seen;
+  if (c->comm) {
+    PYN_NCCL(ncclCommCount(c->comm, &seen));
+    int seen_h = 0, rank_h = -1;
+    PYN_NCCL(ncclCommCount(c->comm_halo, &seen_h));
+    PYN_NCCL(ncclCommUserRank(c->comm_halo, &rank_h));
+    PYN_CHECK(seen_h == seen && rank_h == c->rank, "halo communicator: %d ranks / rank %d, want %d / %d", seen_h, rank_h, seen, c->rank);
+  }
+  info[0] = c->comm ? seen : 0;      // ranks counted by RCCL itself; 0 = the shared-memory test transport is in use
   PYN_CHECK(seen == c->nranks, "RCCL communicator has %d ranks, the launcher declared %d", seen, c->nranks);
   double v[2] = {1.0, (double)c->rank};
   PYN_TRY(pyn_comm_allreduce_f64(c, v, 2, 0));
@@ -327,8 +399,8 @@ extern "C" int pyn_comm_selftest(pyn_ctx* c, double* info, int ninfo) {
   DevTmp x;
   PYN_HIP(x.alloc((size_t)na * sizeof(double)));
   std::vector<double> ghosts((size_t)c->n_ghost);
-  for (int pass = 0; pass < 2; ++pass) {
-    const double base = pass == 0 ? 1.0 : 101.0;   // stamp = base + rank
+  for (int pass = 0; pass < 3; ++pass) {
+    const double base = 1.0 + 100.0 * pass;   // stamp = base + rank
     selftest_fill_kernel<<<1024, 256, 0, c->stream>>>(x.as<double>(), c->n_owned, na, base + c->rank);
     if (pass == 0) {
       PYN_TRY(pyn_halo_exchange(c, x.as<double>(), 1));
@@ -337,15 +409,30 @@ extern "C" int pyn_comm_selftest(pyn_ctx* c, double* info, int ninfo) {
       PYN_HIP(hipStreamWaitEvent(c->comm_stream, c->ev_vec, 0));
       PYN_TRY(pyn_halo_exchange_on(c, x.as<double>(), 1, c->comm_stream));
       PYN_HIP(hipEventRecord(c->ev_halo, c->comm_stream));
+      if (pass == 2) {   // one overlapped step: an all-reduce queued on the MAIN stream while the exchange is in flight on the other
+        const double mine[2] = {1.0, (double)(c->rank + 1)};
+        PYN_HIP(hipMemcpyAsync(c->d_scal + 40, mine, sizeof(mine), hipMemcpyHostToDevice, c->stream));
+        PYN_TRY(pyn_allreduce_dev(c, c->d_scal + 40, 2, 0, c->stream));
+      }
       PYN_HIP(hipStreamWaitEvent(c->stream, c->ev_halo, 0));
+      if (pass == 2) {
+        double got[2] = {0.0, 0.0};
+        PYN_HIP(hipMemcpyAsync(got, c->d_scal + 40, sizeof(got), hipMemcpyDeviceToHost, c->stream));
+        PYN_HIP(hipStreamSynchronize(c->stream));
+        const double w2 = 0.5 * c->nranks * (c->nranks + 1);
+        PYN_CHECK(got[0] == (double)c->nranks && got[1] == w2, "all-reduce beside an exchange in flight: (%g, %g), want (%d, %g)", got[0], got[1],
+                  c->nranks, w2);
+        if (ninfo >= 6) info[5] = got[1];
+      }
     }
     PYN_HIP(hipMemcpyAsync(ghosts.data(), x.as<double>() + c->n_owned, (size_t)c->n_ghost * sizeof(double), hipMemcpyDeviceToHost, c->stream));
     PYN_HIP(hipStreamSynchronize(c->stream));
     for (size_t k = 0; k < c->neigh.size(); ++k)
       for (int64_t j = c->recv_ptr[k]; j < c->recv_ptr[k + 1]; ++j)
-        PYN_CHECK(ghosts[(size_t)j] == base + c->neigh[k], "halo self-test (%s stream): ghost %lld from rank %d holds %g, want %g",
-                  pass ? "communication" : "main", (long long)j, c->neigh[k], ghosts[(size_t)j], base + c->neigh[k]);
-    info[3 + pass] = (double)c->n_ghost;
+        PYN_CHECK(ghosts[(size_t)j] == base + c->neigh[k], "halo self-test (%s): ghost %lld from rank %d holds %g, want %g",
+                  pass == 0 ? "main stream" : pass == 1 ? "communication stream" : "communication stream beside an all-reduce", (long long)j,
+                  c->neigh[k], ghosts[(size_t)j], base + c->neigh[k]);
+    if (pass < 2) info[3 + pass] = (double)c->n_ghost;
   }
   return PYN_OK;
 }
@@ -396,36 +483,34 @@ int pyn_halo_exchange_on(pyn_ctx* c, double* x, int bs, hipStream_t st) {
     int grid = (int)std::min<int64_t>((tot + 255) / 256, 1024);
     pack_send_kernel<<<grid, 256, 0, st>>>(x, c->d_send_idx, c->d_send_buf, c->n_send, bs);
   }
-  if (c->shm) {   // test transport: outbox in shared memory, directory entry (offset, count) per destination
+  if (c->shm) {   // test transport, stream ordered like the RCCL one: device -> pinned host, host callback (outbox, barrier, inbox), host -> device
     pyn_shm_comm* m = c->shm;
+    PYN_CHECK(!m->failed.load(), "%s", m->fail_msg);
     const size_t bytes = (size_t)c->n_send * bs * sizeof(double);
     PYN_CHECK((int64_t)bytes <= m->cap, "halo (%zu bytes) exceeds the shared-memory outbox", bytes);
-    if (bytes) PYN_HIP(hipMemcpyAsync(m->outbox(m->rank), c->d_send_buf, bytes, hipMemcpyDeviceToHost, st));
-    PYN_HIP(hipStreamSynchronize(st));
-    for (size_t k = 0; k < c->neigh.size(); ++k) {
-      int64_t* d = m->dir(m->rank) + (size_t)c->neigh[k] * 2;
-      d[0] = c->send_ptr[k] * bs;
-      d[1] = (c->send_ptr[k + 1] - c->send_ptr[k]) * bs;
+    const int slot = st == c->comm_stream ? 1 : 0;
+    if (!m->stage_out[slot]) PYN_HIP(hipHostMalloc((void**)&m->stage_out[slot], (size_t)m->cap, hipHostMallocDefault));
+    const size_t in_bytes = (size_t)c->n_ghost * bs * sizeof(double);
+    if (in_bytes > m->stage_in_cap[slot]) {
+      PYN_HIP(hipStreamSynchronize(st));   // an earlier exchange of this slot may still be copying from the old buffer
+      if (m->stage_in[slot]) PYN_HIP(hipHostFree(m->stage_in[slot]));
+      m->stage_in[slot] = nullptr;
+      PYN_HIP(hipHostMalloc((void**)&m->stage_in[slot], (size_t)c->n_ghost * 6 * sizeof(double), hipHostMallocDefault));
+      m->stage_in_cap[slot] = (size_t)c->n_ghost * 6 * sizeof(double);
     }
-    PYN_TRY(shm_barrier(m));
-    for (size_t k = 0; k < c->neigh.size(); ++k) {
-      const int src = c->neigh[k];
-      const int64_t* d = m->dir(src) + (size_t)m->rank * 2;
-      const int64_t nr = (c->recv_ptr[k + 1] - c->recv_ptr[k]) * bs;
-      PYN_CHECK(d[1] == nr, "halo plan mismatch with rank %d: it sends %lld values, %lld expected", src, (long long)d[1], (long long)nr);
-      if (nr)
-        PYN_HIP(hipMemcpyAsync(x + (c->n_owned + c->recv_ptr[k]) * bs, reinterpret_cast<const double*>(m->outbox(src)) + d[0],
-                               (size_t)nr * sizeof(double), hipMemcpyHostToDevice, st));
-    }
-    PYN_HIP(hipStreamSynchronize(st));
-    return shm_barrier(m);   // outboxes may be rewritten
+    if (bytes) PYN_HIP(hipMemcpyAsync(m->stage_out[slot], c->d_send_buf, bytes, hipMemcpyDeviceToHost, st));
+    ShmExchange* e = new ShmExchange{m, slot, bs, bytes, c->neigh, c->send_ptr, c->recv_ptr};
+    PYN_HIP(hipLaunchHostFunc(st, shm_exchange_host, e));
+    if (in_bytes)
+      PYN_HIP(hipMemcpyAsync(x + c->n_owned * bs, m->stage_in[slot], in_bytes, hipMemcpyHostToDevice, st));
+    return PYN_OK;
   }
   PYN_NCCL(ncclGroupStart());
   for (size_t k = 0; k < c->neigh.size(); ++k) {
     int64_t ns = c->send_ptr[k + 1] - c->send_ptr[k];
     int64_t nr = c->recv_ptr[k + 1] - c->recv_ptr[k];
-    if (ns) PYN_NCCL(ncclSend(c->d_send_buf + c->send_ptr[k] * bs, (size_t)ns * bs, ncclDouble, c->neigh[k], c->comm, st));
-    if (nr) PYN_NCCL(ncclRecv(x + (c->n_owned + c->recv_ptr[k]) * bs, (size_t)nr * bs, ncclDouble, c->neigh[k], c->comm, st));
+    if (ns) PYN_NCCL(ncclSend(c->d_send_buf + c->send_ptr[k] * bs, (size_t)ns * bs, ncclDouble, c->neigh[k], c->comm_halo, st));
+    if (nr) PYN_NCCL(ncclRecv(x + (c->n_owned + c->recv_ptr[k]) * bs, (size_t)nr * bs, ncclDouble, c->neigh[k], c->comm_halo, st));
   }
   PYN_NCCL(ncclGroupEnd());
   return PYN_OK;

@@ -176,7 +176,8 @@ struct pyn_ctx {
 
   // communicator
   int rank = 0, nranks = 1;
-  ncclComm_t comm = nullptr;
+  ncclComm_t comm = nullptr;            // all-reduces (main stream)
+  ncclComm_t comm_halo = nullptr;       // halo exchanges (split off `comm`): either stream, never shares a communicator with an all-reduce
   struct pyn_shm_comm* shm = nullptr;   // TEST transport (pyn_comm_init_shm): host-staged exchange through POSIX shared memory, so
                                         // that several ranks can share ONE GPU (RCCL refuses that); never used by bench / product runs
   bool detached = false;  // ranks declared without a transport: ghosts are supplied by the caller

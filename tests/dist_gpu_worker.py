@@ -29,6 +29,9 @@ dom.setFemIndexing(2)
 ctx = dom.ctx
 for t in Spectral(2, 3).deviceTables():
     ctx.tables_set(*t)
+st = ctx.comm_selftest()              # the start-up self-test of bench.py --gpus N on the test transport (RCCL counts nothing here)
+assert st["transport"].startswith("shm") and "nranks_seen_by_rccl" not in st and st["allreduce_sum_ones"] == size, st
+assert st["allreduce_beside_exchange_sum_ranks_plus_1"] == size * (size + 1) / 2, st
 glob = fo.box_mesh(nelem, [0.0] * 3, [1.0] * 3, 2, jitter=jitter)
 tb = fo.Tables(2, 3)
 rng = np.random.default_rng(5)

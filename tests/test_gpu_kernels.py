@@ -612,6 +612,12 @@ def test_rccl_one_rank_halo_exchange_and_collectives(lib):
     for t in Spectral(2, 3).deviceTables():
         ctx.tables_set(*t)
     ctx.csr_symbolic()
+    # start-up self-test (what bench.py --gpus N runs first): both communicators counted by RCCL, rank-stamped exchanges on either
+    # stream, and an all-reduce queued on the main stream while an exchange is in flight on the communication stream
+    st = ctx.comm_selftest()
+    assert st["transport"] == "rccl" and st["nranks_seen_by_rccl"] == 1
+    assert st["allreduce_sum_ones"] == 1.0 and st["allreduce_beside_exchange_sum_ranks_plus_1"] == 1.0
+    assert st["halo_ghosts_checked_main_stream"] == per_plane == st["halo_ghosts_checked_comm_stream"]
     A = ctx.mat_create(1, 1)
     ctx.assemble_scalar(lib.FORM_LAPLACE, A)
     assert sp_rel_err(mat_to_scipy(ctx, A, 1, 1), ref) < FP_TOL
