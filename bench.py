@@ -218,18 +218,24 @@ def config_kle(_lib, DMPlexDom, Spectral, n, cg_iters, jitter=0.0):
     mask3 = np.repeat(bm[:, None], 3, axis=1)
     ctx.bc_set(3, mask3)
     n_rows, nnz = ctx.csr_symbolic()
-    K, Krhs, Rw = ctx.mat_create(3, 3), ctx.mat_create(3, 3), ctx.mat_create(3, 3)
+    # Krhs is a COMPACT imposed-column matrix: the node rows next to an imposed node, as the reference preallocates it
+    # (mat_generator.py:42-58, 91) -- every assembly writes all of it, nothing is skipped, nothing else is stored
+    K, Krhs, Rw = ctx.mat_create(3, 3), ctx.mat_create_rhs(3, 3), ctx.mat_create(3, 3)
     B_asm1, B_spmv, B_cg = algorithmic_bytes(n ** 3, n_rows, nnz, ndof=3)
-    B_asm = 3 * B_asm1                      # three block matrices leave the assembly: K, Krhs, Rw (4.46 GB each)
-    # ONE assembly figure: every timed call writes all three matrices in full, as a first (cold) assembly does -- model bytes ==
-    # bytes that move.  (Repeated assemblies for an unchanged Dirichlet set may leave the zero blocks of Krhs unwritten: reported next to it.)
+    kr_blocks, kr_rows = ctx.mat_stored(Krhs)
+    B_krhs = 8.0 * 9 * kr_blocks + 4.0 * n_rows          # its values + the per-row start the kernels look up
+    B_asm = 2 * B_asm1 + B_krhs             # K and Rw by SURVEY.md 8d's model (4.46 GB each) + the compact Krhs: the bytes that move
+    ctx.assemble_kle(1e3, 1e2, K, Krhs, Rw, -1)
+    med, best = median_assembly(ctx, lambda: ctx.assemble_kle(1e3, 1e2, K, Krhs, Rw, -1), 3)
+    # the same with a full-pattern Krhs (the layout of rounds 1-2: 4.1 GB more to write, or to skip once it is known to hold zeros)
+    Kfull = ctx.mat_create(3, 3)
     os.environ["PYNAMA_RHS_FULL_WRITE"] = "1"
     try:
-        ctx.assemble_kle(1e3, 1e2, K, Krhs, Rw, -1)
-        med, best = median_assembly(ctx, lambda: ctx.assemble_kle(1e3, 1e2, K, Krhs, Rw, -1), 3)
+        ctx.assemble_kle(1e3, 1e2, K, Kfull, Rw, -1)
+        med_full, _ = median_assembly(ctx, lambda: ctx.assemble_kle(1e3, 1e2, K, Kfull, Rw, -1), 3)
     finally:
         del os.environ["PYNAMA_RHS_FULL_WRITE"]
-    med_skip, _ = median_assembly(ctx, lambda: ctx.assemble_kle(1e3, 1e2, K, Krhs, Rw, -1), 3)
+    ctx.mat_destroy(Kfull)
     vel = np.zeros((dom.nOwned, 3))
     vel[bm[:dom.nOwned] != 0] = [1.0, 0.0, 0.0]
     vv, vr, vx, vw, vy = ctx.vec_create(3), ctx.vec_create(3), ctx.vec_create(3), ctx.vec_create(3), ctx.vec_create(3)
@@ -315,10 +321,15 @@ def config_kle(_lib, DMPlexDom, Spectral, n, cg_iters, jitter=0.0):
            "n_dof": 3 * n_rows, "nnz_blocks": nnz, "assembly_ms_K_Krhs_Rw": med,
            "element_dofs_per_s": n ** 3 * 24 / (med * 1e-3),
            "assembly_frac_of_hbm_peak": B_asm / (med * 1e-3) / 1e9 / HBM_PEAK_GBS,
-           "assembly_note": f"every timed call writes K, Krhs and Rw in full (what a first, cold assembly does): {B_asm / 1e9:.2f} GB by SURVEY.md "
-                            "8d's model = the bytes that move.  A repeated assembly for an unchanged Dirichlet set leaves the zero blocks of "
-                            f"Krhs unwritten and takes {med_skip:.3f} ms",
-           "assembly_ms_rhs_zero_blocks_skipped": med_skip,
+           "assembly_note": f"K and Rw in full + the COMPACT Krhs ({kr_rows} of {n_rows} node rows, {8.0 * 9 * kr_blocks / 1e9:.2f} GB instead of "
+                            f"{8.0 * 9 * nnz / 1e9:.2f} GB): {B_asm / 1e9:.2f} GB = the bytes every call moves, first call included -- nothing is "
+                            f"skipped or cached.  With a full-pattern Krhs written in full (three matrices of SURVEY.md 8d's model, "
+                            f"{3 * B_asm1 / 1e9:.2f} GB) the call takes {med_full:.3f} ms = {3 * B_asm1 / (med_full * 1e-3) / 1e9 / HBM_PEAK_GBS:.3f} of the roofline",
+           "assembly_ms_full_pattern_krhs": med_full,
+           "krhs_compact": {"node_rows_stored": kr_rows, "node_rows": n_rows, "values_GB": 8.0 * 9 * kr_blocks / 1e9,
+                            "product_ms": float(np.median(t_kr[1:])),
+                            "product_frac_of_hbm_peak": (8.0 * 9 * kr_blocks + 4.0 * kr_blocks + 8.0 * kr_rows + 48.0 * n_rows)
+                            / (float(np.median(t_kr[1:])) * 1e-3) / 1e9 / HBM_PEAK_GBS},
            "kernel": "assemble_q1_hex_kle_lattice_kernel (four waves per tile; "
                      + ("general geometry: closed form of the 2x2x2 rule, Gauss points split over the waves for K, node columns for Rw)"
                         if jitter else "closed-form blocks on parallelepipeds)"),
@@ -352,25 +363,22 @@ def config_ho3(_lib, DMPlexDom, Spectral, dim, nel, cg_iters):
     n_rows, nnzb = ctx.csr_symbolic()
     symbolic_ms = ctx.timers()["symbolic_ms"]
     topo = ctx.mesh_topology()[0]
-    K, Krhs, Rw = ctx.mat_create(dim, dim), ctx.mat_create(dim, dim), ctx.mat_create(dim, dw)
+    K, Krhs, Rw = ctx.mat_create(dim, dim), ctx.mat_create_rhs(dim, dim), ctx.mat_create(dim, dw)     # Krhs compact: rows next to imposed nodes
     ne, nn = nel ** dim, 3 ** dim
+    kr_blocks, kr_rows = ctx.mat_stored(Krhs)
 
     def b_asm(br, bc):          # SURVEY.md 8(d) per matrix: conn + xyz + rowptr + colidx + values
         return 4 * nn * ne + 8 * dim * n_rows + 4 * (n_rows + 1) + 4 * nnzb + 8 * nnzb * br * bc
 
     os.environ["PYNAMA_HO3_REQUIRE"] = "1"          # the generic atomics kernel must not stand in silently
-    os.environ["PYNAMA_RHS_FULL_WRITE"] = "1"       # every timed call writes all three matrices in full: model bytes == bytes that move
     try:
         ctx.assemble_kle(1e3, 1e2, K, Krhs, Rw, -1)
         med, best = median_assembly(ctx, lambda: ctx.assemble_kle(1e3, 1e2, K, Krhs, Rw, -1), 5)
-        del os.environ["PYNAMA_RHS_FULL_WRITE"]
-        med_skip, _ = median_assembly(ctx, lambda: ctx.assemble_kle(1e3, 1e2, K, Krhs, Rw, -1), 3)
         med_k, _ = median_assembly(ctx, lambda: ctx.assemble_kle(1e3, 1e2, K, -1, -1, -1), 3)
         med_rw, _ = median_assembly(ctx, lambda: ctx.assemble_kle(1e3, 1e2, -1, -1, Rw, -1), 3)
     finally:
-        os.environ.pop("PYNAMA_RHS_FULL_WRITE", None)
         del os.environ["PYNAMA_HO3_REQUIRE"]
-    B3 = 2 * b_asm(dim, dim) + b_asm(dim, dw)
+    B3 = b_asm(dim, dim) + b_asm(dim, dw) + 8.0 * dim * dim * kr_blocks + 4.0 * n_rows     # K, Rw in full + the compact Krhs
     N, nnz = n_rows * dim, nnzb * dim * dim
     B_spmv = 8 * nnz + 4 * nnzb + 4 * (n_rows + 1) + 16 * N          # block-CSR model of SURVEY.md 8(d): one column index per block
     B_cg = 8 * nnz + 4 * nnzb + 148 * N
@@ -399,9 +407,8 @@ def config_ho3(_lib, DMPlexDom, Spectral, dim, nel, cg_iters):
            "assembly_ms_K_Krhs_Rw": med, "assembly_ms_min": best,
            "element_dofs_per_s": ne * nn * dim / (med * 1e-3),
            "assembly_frac_of_hbm_peak": B3 / (med * 1e-3) / 1e9 / HBM_PEAK_GBS,
-           "assembly_note": f"all three matrices written in full by every timed call ({B3 / 1e9:.2f} GB by SURVEY.md 8d's model = the bytes that move); "
-                            "with the zero blocks of Krhs left unwritten (same Dirichlet set as the previous call) the call takes "
-                            f"{med_skip:.3f} ms",
+           "assembly_note": f"K and Rw in full (SURVEY.md 8d's model per matrix) + the compact Krhs ({kr_rows} of {n_rows} node rows, "
+                            f"{8.0 * dim * dim * kr_blocks / 1e9:.2f} GB): {B3 / 1e9:.2f} GB = the bytes every call moves",
            "assembly_ms_K_alone": med_k, "assembly_frac_K_alone": b_asm(dim, dim) / (med_k * 1e-3) / 1e9 / HBM_PEAK_GBS,
            "assembly_ms_Rw_alone": med_rw, "assembly_frac_Rw_alone": b_asm(dim, dw) / (med_rw * 1e-3) / 1e9 / HBM_PEAK_GBS,
            "kernel": "assemble_ho3_lattice_kernel (one workgroup per run of consecutive node rows of an x-line: LDS image of that piece of "

@@ -150,6 +150,16 @@ int pyn_patch_plan_set_kind(pyn_ctx* ctx, int kind, int n_patch, const int32_t* 
  * Handles are small non-negative ints.  A vector with block size b has (n_owned+n_ghost)*b
  * entries; only the owned part is meaningful to the caller. */
 int pyn_mat_create(pyn_ctx* ctx, int br, int bc, int* mat_id);      /* mat_generator.py:95-99 */
+/* Krhs / Krhsfs / Arhs ("imposed-column" matrices: -K_e[free, bc] and the unit diagonal of the imposed DOFs, zero elsewhere) in COMPACT
+ * form: only the node rows with an imposed node in their neighbourhood are stored -- the preallocation the reference makes for Krhs
+ * (src/matrices/mat_generator.py:42-58, 91: `drhs_nnz` counts the Dirichlet columns of a row).  Laid out for the Dirichlet set current
+ * at creation (pyn_bc_set first); an assembly under another set lays it out again.  Valid as the Krhs / Krhsfs / Arhs argument of the
+ * assemblies, in pyn_spmv (rows that are not stored are zero rows), pyn_mat_add_values (entries in stored rows), pyn_mat_zero,
+ * pyn_mat_get_values (the graph's full layout is returned) and pyn_mat_destroy; not a system matrix for pyn_solve.  A matrix made by
+ * pyn_mat_create serves as Krhs as well (full pattern: 11 x the memory at 128^3, every product streams it whole). */
+int pyn_mat_create_rhs(pyn_ctx* ctx, int br, int bc, int* mat_id);
+/* what the matrix really stores: graph blocks (x br x bc doubles) and node rows -- Mat.getInfo() / printMatsInfo (mat_generator.py:120-130) */
+int pyn_mat_stored_blocks(pyn_ctx* ctx, int mat_id, int64_t* blocks, int64_t* node_rows);
 int pyn_mat_destroy(pyn_ctx* ctx, int mat_id);                      /* Mat.destroy(): values, solver image and Jacobi data are released, the handle dies */
 int pyn_mat_zero(pyn_ctx* ctx, int mat_id);
 /* Host insertion path, Mat.setValues(rows, cols, vals, addv) (src/cases/base_problem.py:531-547, src/matrices/mat_generator.py:

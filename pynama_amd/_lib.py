@@ -73,6 +73,8 @@ SIGNATURES = {
     "pyn_patch_plan_set": [_P, _I, _P, _P],
     "pyn_patch_plan_set_kind": [_P, _I, _I, _P, _P],
     "pyn_mat_create": [_P, _I, _I, C.POINTER(_I)],
+    "pyn_mat_create_rhs": [_P, _I, _I, C.POINTER(_I)],
+    "pyn_mat_stored_blocks": [_P, _I, C.POINTER(_L), C.POINTER(_L)],
     "pyn_mat_destroy": [_P, _I],
     "pyn_mat_zero": [_P, _I],
     "pyn_mat_add_values": [_P, _I, _I, _pi32, _I, _pi32, _pf64, _I],
@@ -279,6 +281,7 @@ class Context:
         assert xyz.shape[1] == dim
         _check(self.lib.pyn_mesh_set(self.h, dim, nn, n_elem, n_node, conn, xyz))
         self.dim, self.nn, self.n_elem, self.n_node = dim, nn, n_elem, n_node
+        self._bc_last = None
         if not getattr(self, "_halo", False):
             self.n_owned, self.n_ghost = n_node, 0
 
@@ -293,12 +296,19 @@ class Context:
         _check(self.lib.pyn_elem_tables_set(self.h, which, w.size, w, _f64(H), _f64(Hrs), _f64(HrsCoo)))
 
     def bc_set(self, ndof, mask):
+        """Dirichlet mask per local DOF.  A mask identical to the one on the device is not sent again: the library stamps every
+        pyn_bc_set as a new Dirichlet set (compact Krhs layouts, skipped zero blocks and cached element lists are tied to the stamp)."""
         if mask is None:
+            self._bc_last = None
             _check(self.lib.pyn_bc_set(self.h, 0, None))
             return
         m = np.ascontiguousarray(mask, dtype=np.uint8)
         assert m.size == self.n_node * ndof
+        last = getattr(self, "_bc_last", None)
+        if last is not None and last[0] == ndof and last[1].shape == m.shape and np.array_equal(last[1], m):
+            return
         _check(self.lib.pyn_bc_set(self.h, ndof, m.ctypes.data_as(_P)))
+        self._bc_last = (ndof, m.copy())
 
     # -- graph
     def csr_symbolic(self):
@@ -330,6 +340,18 @@ class Context:
         i = _I(-1)
         _check(self.lib.pyn_mat_create(self.h, br, bc, C.byref(i)))
         return i.value
+
+    def mat_create_rhs(self, br, bc) -> int:
+        """compact imposed-column matrix (Krhs / Krhsfs / Arhs): only the node rows next to an imposed node are stored"""
+        i = _I(-1)
+        _check(self.lib.pyn_mat_create_rhs(self.h, br, bc, C.byref(i)))
+        return i.value
+
+    def mat_stored(self, mid):
+        """(graph blocks, node rows) the matrix stores: the whole graph, or the boundary layer of a compact imposed-column matrix"""
+        b, r = _L(0), _L(0)
+        _check(self.lib.pyn_mat_stored_blocks(self.h, mid, C.byref(b), C.byref(r)))
+        return b.value, r.value
 
     def mat_values(self, mid, br, bc):
         v = np.empty(self.nnzb * br * bc, np.float64)

@@ -40,6 +40,11 @@ struct AsmArgs {
   // no-slip / free-slip split (NoSlipFreeSlip.buildKLEMats, base_problem.py:329-454): DOF classes in
   // bcmask are 0 free, 1 tangential at a no-slip wall (free in the FS solve), 2 imposed in both solves
   double *Kfs, *Krhsfs, *Rwfs, *Rdfs;
+  // compact imposed-column targets (pyn_rhs.hip): first block of every owned node row in Krhs / Krhsfs, -1 = row not stored; null = the
+  // matrix has the graph's full pattern
+  const int32_t *rcrow, *rcrow_fs;
+  // element subset (elements with an imposed node: the ones that feed an imposed-column matrix); null = all elements
+  const int32_t* esel;
   // dense mode
   const double* corners;  // single element
   double *out0, *out1, *out2;
@@ -133,7 +138,8 @@ __global__ void __launch_bounds__(BLOCK) assemble_generic_kernel(AsmArgs A) {
   const int dw = dim == 2 ? 1 : 3;
   const int64_t e_end = DENSE ? 1 : A.n_elem;
 
-  for (int64_t e = blockIdx.x; e < e_end; e += gridDim.x) {
+  for (int64_t eq = blockIdx.x; eq < e_end; eq += gridDim.x) {
+    const int64_t e = (!DENSE && A.esel) ? A.esel[eq] : eq;
     __syncthreads();
     // ---- gather corners + connectivity
     for (int t = tid; t < nn; t += BLOCK) ids[t] = DENSE ? t : A.conn[e * nn + t];
@@ -182,7 +188,7 @@ __global__ void __launch_bounds__(BLOCK) assemble_generic_kernel(AsmArgs A) {
     // ---- entries.  ab (node pair) is the fast index so that a thread keeps the same pair
     //      across components when nn*nn is a multiple of BLOCK (Q1 hex: 64 pairs = 64 lanes).
     const int npair = nn * nn;
-    int last_ab = -1, slot = 0, r_lo = 0, r_len = 0;
+    int last_ab = -1, slot = 0, r_lo = 0, r_len = 0, r_cr = 0, r_crfs = 0;   // r_cr / r_crfs: row start inside Krhs / Krhsfs
     auto locate = [&](int ab, int a, int b) {
       if (ab != last_ab) {
         last_ab = ab;
@@ -191,6 +197,8 @@ __global__ void __launch_bounds__(BLOCK) assemble_generic_kernel(AsmArgs A) {
           r_lo = A.rowptr[row];
           r_len = A.rowptr[row + 1] - r_lo;
           slot = find_slot(A.colidx, r_lo, r_len, ids[b]);
+          r_cr = A.rcrow ? A.rcrow[row] : r_lo;
+          r_crfs = A.rcrow_fs ? A.rcrow_fs[row] : r_lo;
         } else {
           r_len = -1;
         }
@@ -349,7 +357,8 @@ __global__ void __launch_bounds__(BLOCK) assemble_generic_kernel(AsmArgs A) {
                       if (cj == 0) {
                         if (A.K) atomicAdd(&A.K[off], vv);
                       } else if (A.Krhs) {
-                        atomicAdd(&A.Krhs[off], -vv);
+                        const int cr = A.rcrow ? A.rcrow[row] : lo;
+                        if (cr >= 0) atomicAdd(&A.Krhs[((int64_t)cr * dim + (int64_t)p * len + sl) * dim + q], -vv);
                       }
                     }
                   }
@@ -426,7 +435,7 @@ __global__ void __launch_bounds__(BLOCK) assemble_generic_kernel(AsmArgs A) {
           if (mr) continue;
           int64_t off = (int64_t)r_lo + slot;
           if (mc) {
-            if (A.Krhs) atomicAdd(&A.Krhs[off], -v);
+            if (A.Krhs && r_cr >= 0) atomicAdd(&A.Krhs[(int64_t)r_cr + slot], -v);
           } else if (A.K) {
             atomicAdd(&A.K[off], v);
           }
@@ -497,12 +506,13 @@ __global__ void __launch_bounds__(BLOCK) assemble_generic_kernel(AsmArgs A) {
                 if (ci == 0) {                                   // base_problem.py:426-427 / 388-390
                   if (cj == 0) {
                     if (A.K) atomicAdd(&A.K[off], vv);
-                  } else if (A.Krhs) {
-                    atomicAdd(&A.Krhs[off], -vv);
+                  } else if (A.Krhs && r_cr >= 0) {
+                    atomicAdd(&A.Krhs[((int64_t)r_cr * dim + (int64_t)p * r_len + slot) * dim + q], -vv);
                   }
                 }
                 if (A.Kfs && ((ci == 1 && cj <= 1) || (ci == 0 && cj == 1))) atomicAdd(&A.Kfs[off], vv);   // :396-407
-                if (A.Krhsfs && ci <= 1 && cj == 2) atomicAdd(&A.Krhsfs[off], -vv);                        // :417-422
+                if (A.Krhsfs && ci <= 1 && cj == 2 && r_crfs >= 0)                                         // :417-422
+                  atomicAdd(&A.Krhsfs[((int64_t)r_crfs * dim + (int64_t)p * r_len + slot) * dim + q], -vv);
               }
             }
       }
@@ -625,7 +635,8 @@ __global__ void __launch_bounds__(BLOCK) assemble_generic_kernel(AsmArgs A) {
 // keeps only the doubly imposed DOFs eliminated, Krhsfs gets 1 on those (:449-450).
 __global__ void bc_identity_kernel(const int32_t* __restrict__ rowptr, const int32_t* __restrict__ colidx,
                                    const uint8_t* __restrict__ mask, int64_t n_owned, int ndof, double* __restrict__ K,
-                                   double* __restrict__ Krhs, double* __restrict__ Kfs, double* __restrict__ Krhsfs) {
+                                   double* __restrict__ Krhs, double* __restrict__ Kfs, double* __restrict__ Krhsfs,
+                                   const int32_t* __restrict__ rcrow, const int32_t* __restrict__ rcrow_fs) {
   for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < n_owned * ndof; t += (int64_t)gridDim.x * blockDim.x) {
     const int cls = mask[t];
     if (!cls) continue;
@@ -635,9 +646,15 @@ __global__ void bc_identity_kernel(const int32_t* __restrict__ rowptr, const int
     int slot = find_slot(colidx, lo, len, (int)i);
     int64_t off = ((int64_t)lo * ndof + (int64_t)p * len + slot) * ndof + p;
     if (K) K[off] = 1.0;
-    if (Krhs) Krhs[off] = 1.0;
+    if (Krhs) {
+      const int cr = rcrow ? rcrow[i] : lo;      // (an imposed row is always stored by a compact matrix)
+      if (cr >= 0) Krhs[((int64_t)cr * ndof + (int64_t)p * len + slot) * ndof + p] = 1.0;
+    }
     if (Kfs && cls == 1) Kfs[off] -= 1.0;
-    if (Krhsfs && cls == 2) Krhsfs[off] = 1.0;
+    if (Krhsfs && cls == 2) {
+      const int cr = rcrow_fs ? rcrow_fs[i] : lo;
+      if (cr >= 0) Krhsfs[((int64_t)cr * ndof + (int64_t)p * len + slot) * ndof + p] = 1.0;
+    }
   }
 }
 
@@ -652,7 +669,8 @@ __global__ void __launch_bounds__(256) assemble_p1_laplace_kernel(const int32_t*
                                                                     const int32_t* __restrict__ colidx,
                                                                     const uint8_t* __restrict__ bcmask,
                                                                     const double* __restrict__ hrs, double wsum,
-                                                                    double* __restrict__ A, double* __restrict__ Arhs) {
+                                                                    double* __restrict__ A, double* __restrict__ Arhs,
+                                                                    const int32_t* __restrict__ rcrow) {
   constexpr int NN = DIM + 1;
   const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (e >= n_elem) return;
@@ -708,9 +726,11 @@ __global__ void __launch_bounds__(256) assemble_p1_laplace_kernel(const int32_t*
 #pragma unroll
       for (int x = 0; x < DIM; ++x) v += G[x][a] * G[x][b];
       v *= cw;
-      const int64_t off = (int64_t)lo + find_slot(colidx, lo, len, ids[b]);
+      const int sl = find_slot(colidx, lo, len, ids[b]);
+      const int64_t off = (int64_t)lo + sl;
       if (mc[b]) {
-        if (Arhs) atomicAdd(&Arhs[off], -v);
+        const int cr = rcrow ? rcrow[ids[a]] : lo;
+        if (Arhs && cr >= 0) atomicAdd(&Arhs[(int64_t)cr + sl], -v);
       } else if (A) {
         atomicAdd(&A[off], v);
       }
@@ -767,7 +787,8 @@ __global__ void __launch_bounds__(256) assemble_kle_ho_mfma_kernel(AsmArgs A, in
       }
     }
 
-  for (int64_t e = blockIdx.x; e < A.n_elem; e += gridDim.x) {
+  for (int64_t eq = blockIdx.x; eq < A.n_elem; eq += gridDim.x) {
+    const int64_t e = A.esel ? A.esel[eq] : eq;
     __syncthreads();
     for (int t = tid; t < nn; t += 256) ids[t] = A.conn[e * nn + t];
     for (int t = tid; t < nc * dim; t += 256) {
@@ -900,7 +921,8 @@ __global__ void __launch_bounds__(256) assemble_kle_ho_mfma_kernel(AsmArgs A, in
               if (cj == 0) {
                 if (A.K) atomicAdd(&A.K[off], v);
               } else if (A.Krhs) {
-                atomicAdd(&A.Krhs[off], -v);
+                const int cr = A.rcrow ? A.rcrow[row] : lo;
+                if (cr >= 0) atomicAdd(&A.Krhs[((int64_t)cr * dim + (int64_t)p * len + sl) * dim + q], -v);
               }
             }
           }
@@ -947,6 +969,7 @@ int fill_args(pyn_ctx* c, AsmArgs& A, int form) {
   A.alpha_d = A.alpha_w = 0.0;
   A.K = A.Krhs = A.Rw = A.Rd = nullptr;
   A.Kfs = A.Krhsfs = A.Rwfs = A.Rdfs = nullptr;
+  A.rcrow = A.rcrow_fs = A.esel = nullptr;
   A.corners = nullptr;
   A.out0 = A.out1 = A.out2 = nullptr;
   A.gscratch = nullptr;
@@ -1031,19 +1054,30 @@ static bool rhs_is_clean(pyn_ctx* c, int id) {
   return s == PYN_RHS_ANY || s == c->bc_stamp;
 }
 
-static int mat_ptr(pyn_ctx* c, int id, int br, int bc, const char* name, double** out) {
+// crow != null: the argument may be a compact imposed-column matrix (Krhs, Krhsfs, Arhs); its row selection is brought to the current
+// Dirichlet set (values zeroed when it had to be rebuilt) and handed back, null for a matrix with the graph's full pattern
+static int mat_ptr(pyn_ctx* c, int id, int br, int bc, const char* name, double** out, const int32_t** crow = nullptr) {
   *out = nullptr;
+  if (crow) *crow = nullptr;
   if (id < 0) return PYN_OK;
   PYN_TRY(pyn_check_mat(c, id, name));
   DMat& m = c->mats[id];
   PYN_CHECK(m.br == br && m.bc == bc, "%s must have block shape %dx%d (has %dx%d)", name, br, bc, m.br, m.bc);
+  PYN_CHECK(crow || !m.rhs_compact, "%s: a compact imposed-column matrix (pyn_mat_create_rhs) can only be the Krhs / Arhs target", name);
+  if (m.rhs_compact) {
+    PYN_TRY(pyn_rhs_ensure(c, m, true));   // laid out for the Dirichlet set of THIS assembly
+    *crow = m.c_crow;
+  }
   m.touch();  // values are about to change
   *out = m.val;
   return PYN_OK;
 }
 
+// blocks stored by the matrix behind a raw value pointer of this assembly (the compact Krhs target, or the graph's count)
+static int64_t rhs_blocks(const pyn_ctx* c, int id) { return id >= 0 ? pyn_mat_blocks(c, c->mats[id]) : c->nnzb; }
+
 static int run_assembly(pyn_ctx* c, int form, double alpha_d, double alpha_w, double* K, double* Krhs, double* Rw,
-                        double* Rd, int variant) {
+                        double* Rd, int variant, int64_t krhs_blocks) {
   PYN_CHECK(c->d_rowptr, "pyn_csr_symbolic first");
   const int ndof = form == PYN_FORM_KLE ? c->dim : 1;
   if (c->d_bcmask) PYN_CHECK(c->bc_ndof == ndof, "bc mask has ndof=%d, form needs %d", c->bc_ndof, ndof);
@@ -1056,14 +1090,36 @@ static int run_assembly(pyn_ctx* c, int form, double alpha_d, double alpha_w, do
   A.Krhs = Krhs;
   A.Rw = Rw;
   A.Rd = Rd;
+  A.rcrow = c->asm_rcrow;
   PYN_HIP(hipEventRecord(c->ev0, c->stream));
   bool handled = false;
+  c->asm_krhs_pending = false;
   if (variant != 0) PYN_TRY(pyn_assemble_q1_tiled(c, form, alpha_d, alpha_w, K, Krhs, Rw, Rd, &handled));
+  if (handled && c->asm_krhs_pending) {
+    // the kernel family that took K cannot address a compact Krhs: -K_e[free, bc] comes from the elements that hold an imposed node
+    // (a few per cent of the mesh) through the generic kernel, into the zeroed compact matrix
+    PYN_TRY(pyn_bc_elements(c));
+    PYN_HIP(hipMemsetAsync(Krhs, 0, (size_t)krhs_blocks * ndof * ndof * sizeof(double), c->stream));
+    if (c->n_esel > 0) {
+      AsmArgs B = A;
+      B.K = B.Rw = B.Rd = nullptr;
+      B.esel = c->d_esel;
+      B.n_elem = c->n_esel;
+      PYN_TRY(launch_generic<false>(c, B, c->n_esel));
+    }
+    if (c->d_bcmask) {
+      int64_t n = c->n_owned * ndof;
+      int grid = (int)std::min<int64_t>((n + 255) / 256, 4096);
+      bc_identity_kernel<<<grid, 256, 0, c->stream>>>(c->d_rowptr, c->d_colidx, c->d_bcmask, c->n_owned, ndof, nullptr, Krhs, nullptr, nullptr,
+                                                    c->asm_rcrow, nullptr);
+    }
+    c->asm_krhs_pending = false;
+  }
   if (!handled) {  // scatter-add path: values start from zero (the tiled path writes every entry itself)
     const int dw = c->dim == 2 ? 1 : 3;
     const size_t nb = (size_t)c->nnzb * sizeof(double);
     if (K) PYN_HIP(hipMemsetAsync(K, 0, nb * ndof * ndof, c->stream));
-    if (Krhs) PYN_HIP(hipMemsetAsync(Krhs, 0, nb * ndof * ndof, c->stream));
+    if (Krhs) PYN_HIP(hipMemsetAsync(Krhs, 0, (size_t)krhs_blocks * ndof * ndof * sizeof(double), c->stream));
     if (Rw) PYN_HIP(hipMemsetAsync(Rw, 0, nb * ndof * dw, c->stream));
     if (Rd) PYN_HIP(hipMemsetAsync(Rd, 0, nb * ndof, c->stream));
     const QuadTab& q0 = c->quad[0];
@@ -1071,10 +1127,10 @@ static int run_assembly(pyn_ctx* c, int form, double alpha_d, double alpha_w, do
       const int grid = (int)((c->n_elem + 255) / 256);
       if (c->dim == 3)
         assemble_p1_laplace_kernel<3><<<grid, 256, 0, c->stream>>>(c->d_conn, c->d_xyz, c->n_elem, c->n_owned, c->d_rowptr,
-                                                                  c->d_colidx, c->d_bcmask, q0.Hrs, q0.wsum, K, Krhs);
+                                                                  c->d_colidx, c->d_bcmask, q0.Hrs, q0.wsum, K, Krhs, c->asm_rcrow);
       else
         assemble_p1_laplace_kernel<2><<<grid, 256, 0, c->stream>>>(c->d_conn, c->d_xyz, c->n_elem, c->n_owned, c->d_rowptr,
-                                                                  c->d_colidx, c->d_bcmask, q0.Hrs, q0.wsum, K, Krhs);
+                                                                  c->d_colidx, c->d_bcmask, q0.Hrs, q0.wsum, K, Krhs, c->asm_rcrow);
       PYN_HIP(hipGetLastError());
     } else {
       PYN_TRY(launch_generic<false>(c, A, c->n_elem));
@@ -1083,7 +1139,8 @@ static int run_assembly(pyn_ctx* c, int form, double alpha_d, double alpha_w, do
   if (!handled && c->d_bcmask && (K || Krhs)) {
     int64_t n = c->n_owned * ndof;
     int grid = (int)std::min<int64_t>((n + 255) / 256, 4096);
-    bc_identity_kernel<<<grid, 256, 0, c->stream>>>(c->d_rowptr, c->d_colidx, c->d_bcmask, c->n_owned, ndof, K, Krhs, nullptr, nullptr);
+    bc_identity_kernel<<<grid, 256, 0, c->stream>>>(c->d_rowptr, c->d_colidx, c->d_bcmask, c->n_owned, ndof, K, Krhs, nullptr, nullptr,
+                                                    c->asm_rcrow, nullptr);
   }
   PYN_HIP(hipEventRecord(c->ev1, c->stream));
   PYN_HIP(hipStreamSynchronize(c->stream));
@@ -1098,13 +1155,15 @@ extern "C" int pyn_assemble_kle(pyn_ctx* c, double alpha_d, double alpha_w, int 
   PYN_HIP(hipSetDevice(c->device));
   const int dim = c->dim, dw = dim == 2 ? 1 : 3;
   double *pK, *pKr, *pRw, *pRd;
-  c->asm_rhs_clean = Krhs != K && rhs_is_clean(c, Krhs);
   PYN_TRY(mat_ptr(c, K, dim, dim, "K", &pK));
-  PYN_TRY(mat_ptr(c, Krhs, dim, dim, "Krhs", &pKr));
+  c->asm_rhs_clean = Krhs != K && rhs_is_clean(c, Krhs);   // (read before mat_ptr marks the matrix as changing)
+  PYN_TRY(mat_ptr(c, Krhs, dim, dim, "Krhs", &pKr, &c->asm_rcrow));
+  if (c->asm_rcrow) c->asm_rhs_clean = false;              // a compact matrix has no zero blocks to skip: every stored row is written
   PYN_TRY(mat_ptr(c, Rw, dim, dw, "Rw", &pRw));
   PYN_TRY(mat_ptr(c, Rd, dim, 1, "Rd", &pRd));
-  const int rc = run_assembly(c, PYN_FORM_KLE, alpha_d, alpha_w, pK, pKr, pRw, pRd, variant);
+  const int rc = run_assembly(c, PYN_FORM_KLE, alpha_d, alpha_w, pK, pKr, pRw, pRd, variant, rhs_blocks(c, Krhs));
   c->asm_rhs_clean = false;
+  c->asm_rcrow = nullptr;
   if (rc == PYN_OK && pKr && pK) c->mats[Krhs].rhs_clean = c->bc_stamp;   // exactly the imposed-column matrix of this Dirichlet set
   return rc;
 }
@@ -1118,9 +1177,12 @@ extern "C" int pyn_assemble_kle_noslip(pyn_ctx* c, double alpha_d, double alpha_
   const int shapes[8][2] = {{dim, dim}, {dim, dim}, {dim, dw}, {dim, 1}, {dim, dim}, {dim, dim}, {dim, dw}, {dim, 1}};
   const char* names[8] = {"K", "Krhs", "Rw", "Rd", "Kfs", "Krhsfs", "Rwfs", "Rdfs"};
   double* ptr[8];
+  const int32_t* crow[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
   for (int k = 0; k < 8; ++k) {
-    PYN_TRY(mat_ptr(c, mat_ids[k], shapes[k][0], shapes[k][1], names[k], &ptr[k]));
-    if (ptr[k]) PYN_HIP(hipMemsetAsync(ptr[k], 0, (size_t)c->nnzb * shapes[k][0] * shapes[k][1] * sizeof(double), c->stream));
+    const bool rhs = k == 1 || k == 5;       // Krhs, Krhsfs may be compact imposed-column matrices
+    PYN_TRY(mat_ptr(c, mat_ids[k], shapes[k][0], shapes[k][1], names[k], &ptr[k], rhs ? &crow[k] : nullptr));
+    if (ptr[k])
+      PYN_HIP(hipMemsetAsync(ptr[k], 0, (size_t)rhs_blocks(c, mat_ids[k]) * shapes[k][0] * shapes[k][1] * sizeof(double), c->stream));
   }
   AsmArgs A;
   PYN_TRY(fill_args(c, A, PYN_FORM_KLE));
@@ -1135,11 +1197,14 @@ extern "C" int pyn_assemble_kle_noslip(pyn_ctx* c, double alpha_d, double alpha_
   A.Krhsfs = ptr[5];
   A.Rwfs = ptr[6];
   A.Rdfs = ptr[7];
+  A.rcrow = crow[1];
+  A.rcrow_fs = crow[5];
   PYN_HIP(hipEventRecord(c->ev0, c->stream));
   PYN_TRY(launch_generic<false>(c, A, c->n_elem));
   int64_t n = c->n_owned * dim;
   int grid = (int)std::min<int64_t>((n + 255) / 256, 4096);
-  bc_identity_kernel<<<grid, 256, 0, c->stream>>>(c->d_rowptr, c->d_colidx, c->d_bcmask, c->n_owned, dim, A.K, A.Krhs, A.Kfs, A.Krhsfs);
+  bc_identity_kernel<<<grid, 256, 0, c->stream>>>(c->d_rowptr, c->d_colidx, c->d_bcmask, c->n_owned, dim, A.K, A.Krhs, A.Kfs, A.Krhsfs, A.rcrow,
+                                                A.rcrow_fs);
   PYN_HIP(hipEventRecord(c->ev1, c->stream));
   PYN_HIP(hipStreamSynchronize(c->stream));
   float ms = 0;
@@ -1155,7 +1220,8 @@ extern "C" int pyn_assemble_scalar(pyn_ctx* c, int form, int Aid, int Arhs, int 
   double *pA, *pAr;
   c->asm_rhs_clean = Arhs != Aid && rhs_is_clean(c, Arhs);
   PYN_TRY(mat_ptr(c, Aid, 1, 1, "A", &pA));
-  PYN_TRY(mat_ptr(c, Arhs, 1, 1, "Arhs", &pAr));
+  PYN_TRY(mat_ptr(c, Arhs, 1, 1, "Arhs", &pAr, &c->asm_rcrow));
+  if (c->asm_rcrow) c->asm_rhs_clean = false;
   // the Jacobi data of A: kernels that see whole rows (lattice store phases) write 1 / diagonal on the way out
   c->asm_dinv = nullptr;
   c->asm_dinv_written = false;
@@ -1164,10 +1230,11 @@ extern "C" int pyn_assemble_scalar(pyn_ctx* c, int form, int Aid, int Arhs, int 
     if (!m.dinv) PYN_HIP(hipMalloc((void**)&m.dinv, (size_t)c->n_owned * sizeof(double)));
     c->asm_dinv = m.dinv;
   }
-  const int rc = run_assembly(c, form, 0.0, 0.0, pA, pAr, nullptr, nullptr, variant);
+  const int rc = run_assembly(c, form, 0.0, 0.0, pA, pAr, nullptr, nullptr, variant, rhs_blocks(c, Arhs));
   if (rc == PYN_OK && c->asm_dinv && c->asm_dinv_written) c->mats[Aid].dinv_valid = true;
   c->asm_dinv = nullptr;
   c->asm_rhs_clean = false;
+  c->asm_rcrow = nullptr;
   if (rc == PYN_OK && pAr && pA) c->mats[Arhs].rhs_clean = c->bc_stamp;
   return rc;
 }

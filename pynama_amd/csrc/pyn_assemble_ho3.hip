@@ -53,6 +53,7 @@ struct Ho3Args {
   double* A;
   double* Arhs;
   int rhs_clean;          // Arhs holds zeros wherever this Dirichlet set leaves zeros: runs without an imposed DOF skip it
+  const int32_t* rcrow;   // Arhs is a COMPACT imposed-column matrix (pyn_rhs.hip): first block of every owned node row in it, -1 = not stored
   int par_y, par_z;       // class of the x-lines of this launch (parity of the local y / z index)
   int nruns, nly;         // runs per x-line, lines of this class per plane (3-D)
   int so0;                // first owned plane (3-D) / line (2-D), as an owned index, whose local index has the parity of the class
@@ -406,7 +407,7 @@ __global__ void __launch_bounds__(256) assemble_ho3_lattice_kernel(Ho3Args T) {
   double* __restrict__ outR = T.Arhs;
   if (!routed) {
     const int total = rowoff[nrows] * BB;
-    const bool zr = outR && !T.rhs_clean;
+    const bool zr = outR && !T.rhs_clean && !T.rcrow;   // (a compact matrix stores no row of a run without imposed DOFs)
     for (int i = tid; i < total; i += 256) {
       outA[gbase + i] = img[i];
       if (zr) outR[gbase + i] = 0.0;
@@ -420,6 +421,12 @@ __global__ void __launch_bounds__(256) assemble_ho3_lattice_kernel(Ho3Args T) {
     const int base = rowoff[r] * BB, len = rowoff[r + 1] - rowoff[r], L1 = len * BC;
     const int rowbits = nb[((BZW >> 1) * BYW + 2) * BXW + r + 2];
     const int nxy = n_x * n_y;
+    // Arhs: same place as in A for a matrix with the graph's pattern, the row's own start in a compact one
+    int64_t rbase = gbase + base;
+    if (MAT != M_RW && outR && T.rcrow) {
+      const int rr = T.rcrow[row0 + r];
+      rbase = rr >= 0 ? (int64_t)rr * BB : -1;
+    }
     for (int j = tid; j < len * BB; j += 256) {
       const int p = BR == 1 ? 0 : (j >= L1) + (BR == 3 ? (j >= 2 * L1) : 0);
       const int rem = j - p * L1;
@@ -448,7 +455,7 @@ __global__ void __launch_bounds__(256) assemble_ho3_lattice_kernel(Ho3Args T) {
         vr = 0.0;
       }
       outA[gbase + base + j] = va;
-      if (MAT != M_RW && outR) outR[gbase + base + j] = vr;
+      if (MAT != M_RW && outR && rbase >= 0) outR[rbase + j] = vr;
     }
   }
 }
@@ -526,6 +533,7 @@ void fill_lattice_args(const pyn_ctx* c, Ho3Args& T) {
   T.alpha_d = T.alpha_w = 0.0;
   T.A = T.Arhs = nullptr;
   T.rhs_clean = 0;
+  T.rcrow = nullptr;
   T.par_y = T.par_z = 0;
   T.nruns = T.nly = 0;
   T.so0 = 0;
@@ -793,6 +801,7 @@ int pyn_assemble_ho3_lattice(pyn_ctx* c, int form, double alpha_d, double alpha_
     T.A = K;
     T.Arhs = Krhs;
     T.rhs_clean = c->asm_rhs_clean ? 1 : 0;
+    T.rcrow = c->asm_rcrow;
     if (L.dim == 3)
       PYN_TRY((launch_ho3_r<3, M_LAP>(c, T)));
     else
@@ -804,6 +813,7 @@ int pyn_assemble_ho3_lattice(pyn_ctx* c, int form, double alpha_d, double alpha_
     T.A = K;
     T.Arhs = Krhs;
     T.rhs_clean = c->asm_rhs_clean ? 1 : 0;
+    T.rcrow = c->asm_rcrow;
     if (L.dim == 3)
       PYN_TRY((launch_ho3_r<3, M_K>(c, T)));
     else
@@ -813,6 +823,7 @@ int pyn_assemble_ho3_lattice(pyn_ctx* c, int form, double alpha_d, double alpha_
     T.A = Rw;
     T.Arhs = nullptr;
     T.rhs_clean = 0;
+    T.rcrow = nullptr;
     if (L.dim == 3)
       PYN_TRY((launch_ho3_r<3, M_RW>(c, T)));
     else

@@ -1405,7 +1405,7 @@ __global__ void __launch_bounds__(256, GEN && RW && !KLE_RW_M_OUTER ? 2 : 3) ass
       const int64_t base = (int64_t)rlo[l * TX] * 9;
       for (int i = lane; i < LINE; i += 64) {
         outA[base + i] = acc[l * LINE + i];
-        if (!RW && outR && !L.rhs_clean) outR[base + i] = 0.0;
+        if (!RW && outR && !L.rhs_clean && !L.rcrow) outR[base + i] = 0.0;   // (a compact Krhs stores no row of a tile without imposed nodes)
       }
     }
     return;
@@ -1423,6 +1423,12 @@ __global__ void __launch_bounds__(256, GEN && RW && !KLE_RW_M_OUTER ? 2 : 3) ass
     const int bi = ((rz + 1) * LT::BY + ry + 1) * LT::BX + rx + 1;
     const bool rowbc = (nbc[bi] >> pp) & 1;
     const int64_t gbase = ((int64_t)rl * 3 + (int64_t)pp * len) * 3;
+    // Krhs: the same offset in a matrix with the graph's pattern; through the row's own start in a compact one (-1: row not stored)
+    int64_t rbase = gbase;
+    if (!RW && outR && L.rcrow) {
+      const int rr = L.rcrow[((int64_t)(z0 + rz) * ny + y) * nx + x];
+      rbase = rr >= 0 ? ((int64_t)rr * 3 + (int64_t)pp * len) * 3 : -1;
+    }
     for (int idx = lane; idx < len * 3; idx += 64) {
       const int k = idx / 3, q = idx - k * 3;
       const int kz = (k >= cc) + (k >= 2 * cc);
@@ -1443,7 +1449,7 @@ __global__ void __launch_bounds__(256, GEN && RW && !KLE_RW_M_OUTER ? 2 : 3) ass
         vr = 0.0;
       }
       outA[gbase + idx] = va;
-      if (!RW && outR) outR[gbase + idx] = vr;
+      if (!RW && outR && rbase >= 0) outR[rbase + idx] = vr;
     }
   }
 }
@@ -1607,6 +1613,7 @@ static int lat_fill_args(pyn_ctx* c, LatArgs& T, double* A, double* Arhs, int* m
   T.Arhs = Arhs;
   T.dinv = nullptr;
   T.rhs_clean = c->asm_rhs_clean ? 1 : 0;
+  T.rcrow = c->asm_rcrow;
   const char* ab = getenv("PYNAMA_LATTICE_ABLATE");  // diagnostics: 1 = no element phase, 4 = no plain-tile store path
   T.ablate = ab ? atoi(ab) : 0;
   T.lean = c->q1_gauss_standard && !getenv("PYNAMA_NO_LEAN") ? 1 : 0;

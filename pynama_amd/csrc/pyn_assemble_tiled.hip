@@ -1307,9 +1307,16 @@ int pyn_assemble_q1_tiled(pyn_ctx* c, int form, double alpha_d, double alpha_w, 
     if (*handled) return PYN_OK;
     PYN_CHECK(!getenv("PYNAMA_HO3_REQUIRE"), "PYNAMA_HO3_REQUIRE: the ngl = 3 lattice kernels declined this assembly (non-affine cell or tables missing)");
   }
+  // Kernel families that cannot address a COMPACT imposed-column target (c->asm_rcrow) assemble K (and Rw) alone; run_assembly then
+  // fills the compact Krhs from the elements that hold an imposed node.  Native: the ngl = 3 row-run kernels above, the KLE lattice kernels.
+  double* const KrhsN = c->asm_rcrow ? nullptr : Krhs;
+  const bool pend = Krhs && c->asm_rcrow;
   if (form == PYN_FORM_LAPLACE && K && !Rw && !Rd && c->lat.valid && !c->plan[0].user) {
-    PYN_TRY(pyn_assemble_lattice(c, K, Krhs, handled));
-    if (*handled) return PYN_OK;
+    PYN_TRY(pyn_assemble_lattice(c, K, KrhsN, handled));
+    if (*handled) {
+      c->asm_krhs_pending = pend;
+      return PYN_OK;
+    }
   }
   if (form == PYN_FORM_KLE && (K || (Rw && !Krhs)) && !Rd && !c->plan[1].user) {   // (Rw alone is a legal request of the ABI)
     PYN_TRY(pyn_assemble_kle_lattice(c, alpha_d, alpha_w, K, Krhs, Rw, handled));
@@ -1317,7 +1324,11 @@ int pyn_assemble_q1_tiled(pyn_ctx* c, int form, double alpha_d, double alpha_w, 
   }
   if (form == PYN_FORM_KLE && K && !Rd) PYN_TRY(ensure_default_plan(c, 1));
   if (form == PYN_FORM_LAPLACE && K && !Rw && !Rd) PYN_TRY(ensure_default_plan(c, 0));
-  if (form == PYN_FORM_KLE && K && !Rd) return assemble_kle_tiled(c, alpha_d, alpha_w, K, Krhs, Rw, handled);
+  if (form == PYN_FORM_KLE && K && !Rd) {
+    PYN_TRY(assemble_kle_tiled(c, alpha_d, alpha_w, K, KrhsN, Rw, handled));
+    if (*handled) c->asm_krhs_pending = pend;
+    return PYN_OK;
+  }
   PatchPlan& P = c->plan[0];
   if (!P.npatch || form != PYN_FORM_LAPLACE || !K || Rw || Rd) return PYN_OK;
   const bool tets = c->dim == 3 && c->nn == 4 && c->quad[0].const_grad && !getenv("PYNAMA_NO_P1_TILED");
@@ -1345,7 +1356,8 @@ int pyn_assemble_q1_tiled(pyn_ctx* c, int form, double alpha_d, double alpha_w, 
   T.aff = getenv("PYNAMA_NO_AFFINE") ? nullptr : c->d_aff;
   T.lean = c->q1_gauss_standard && !getenv("PYNAMA_NO_LEAN") ? 1 : 0;
   T.A = K;
-  T.Arhs = Krhs;
+  T.Arhs = KrhsN;
+  c->asm_krhs_pending = pend;
   size_t lds = (size_t)P.maxrows * P.maxlen * sizeof(double) + (size_t)P.maxrows * 3 * sizeof(int);
   const char* ab = getenv("PYNAMA_TILED_ABLATE");  // diagnostics only: 1 = no LDS adds, 2 = no quadrature
   const int abl = ab ? atoi(ab) : 0;

@@ -145,7 +145,9 @@ extern "C" int pyn_ctx_destroy(pyn_ctx* c) {
     (void)hipFree(m.sell_val);
     (void)hipFree(m.dinv);
     m.release_lu();
+    pyn_rhs_release(m);
   }
+  (void)hipFree(c->d_esel);
   pyn_sell_drop_structure(c);
   for (auto& v : c->vecs) (void)hipFree(v.d);
   for (int k = 0; k < 3; ++k) (void)hipFree(c->mf_mask[k]);
@@ -719,6 +721,7 @@ extern "C" int pyn_mat_destroy(pyn_ctx* c, int id) {
   (void)hipFree(m.sell_val);
   (void)hipFree(m.dinv);
   m.release_lu();
+  pyn_rhs_release(m);
   m = DMat();   // live = false: the handle is dead, its slot is not reused (handles stay stable)
   return PYN_OK;
 }
@@ -729,7 +732,8 @@ extern "C" int pyn_mat_destroy(pyn_ctx* c, int id) {
 // device path is owner-computes: there is no off-process stash).
 __global__ void mat_add_values_kernel(const int32_t* __restrict__ rowptr, const int32_t* __restrict__ colidx, double* __restrict__ val,
                                       int64_t n_owned, int br, int bc, int nr, const int32_t* __restrict__ rows, int nc,
-                                      const int32_t* __restrict__ cols, const double* __restrict__ v, int insert, int* __restrict__ bad) {
+                                      const int32_t* __restrict__ cols, const double* __restrict__ v, int insert, int* __restrict__ bad,
+                                      const int32_t* __restrict__ crow) {
   for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < nr * nc; e += gridDim.x * blockDim.x) {
     const int r = rows[e / nc], cidx = cols[e % nc];
     if (r < 0 || cidx < 0) continue;                 // PETSc: negative indices are ignored
@@ -747,7 +751,12 @@ __global__ void mat_add_values_kernel(const int32_t* __restrict__ rowptr, const 
       atomicExch(bad, 1);
       continue;
     }
-    double* dst = val + ((int64_t)lo * br + (int64_t)p * len + l) * bc + q;
+    const int vlo = crow ? crow[i] : lo;      // compact imposed-column matrix: the row may not be stored
+    if (vlo < 0) {
+      if (v[e] != 0.0) atomicExch(bad, 2);
+      continue;
+    }
+    double* dst = val + ((int64_t)vlo * br + (int64_t)p * len + l) * bc + q;
     if (insert) *dst = v[e];
     else atomicAdd(dst, v[e]);
   }
@@ -770,12 +779,15 @@ extern "C" int pyn_mat_add_values(pyn_ctx* c, int id, int nr, const int32_t* row
   PYN_HIP(hipMemcpyAsync(dr, rows, nr * sizeof(int32_t), hipMemcpyHostToDevice, c->stream));
   PYN_HIP(hipMemcpyAsync(dc, cols, nc * sizeof(int32_t), hipMemcpyHostToDevice, c->stream));
   PYN_HIP(hipMemsetAsync(dbad, 0, sizeof(int), c->stream));
+  PYN_TRY(pyn_rhs_ensure(c, m));
   m.touch();
   mat_add_values_kernel<<<std::min((nr * nc + 255) / 256, 1024), 256, 0, c->stream>>>(c->d_rowptr, c->d_colidx, m.val, c->n_owned, m.br, m.bc, nr, dr,
-                                                                                nc, dc, dv, insert, dbad);
+                                                                                nc, dc, dv, insert, dbad, m.rhs_compact ? m.c_crow : nullptr);
   int bad = 0;
   PYN_HIP(hipMemcpyAsync(&bad, dbad, sizeof(int), hipMemcpyDeviceToHost, c->stream));
   PYN_HIP(hipStreamSynchronize(c->stream));
+  PYN_CHECK(bad != 2, "pyn_mat_add_values: a nonzero entry lies in a row that the compact imposed-column matrix does not store (no "
+                      "imposed node next to it under the Dirichlet set the matrix was laid out for)");
   PYN_CHECK(!bad, "pyn_mat_add_values: an entry lies outside the node graph of the mesh (no new nonzeros can be allocated)");
   return PYN_OK;
 }
@@ -783,7 +795,8 @@ extern "C" int pyn_mat_add_values(pyn_ctx* c, int id, int nr, const int32_t* row
 extern "C" int pyn_mat_zero(pyn_ctx* c, int id) {
   PYN_TRY(pyn_check_mat(c, id, "pyn_mat_zero"));
   DMat& m = c->mats[id];
-  PYN_HIP(hipMemsetAsync(m.val, 0, (size_t)c->nnzb * m.br * m.bc * sizeof(double), c->stream));
+  PYN_TRY(pyn_rhs_ensure(c, m));
+  PYN_HIP(hipMemsetAsync(m.val, 0, (size_t)pyn_mat_blocks(c, m) * m.br * m.bc * sizeof(double), c->stream));
   m.touch();
   m.rhs_clean = PYN_RHS_ANY;
   return PYN_OK;
@@ -793,7 +806,16 @@ extern "C" int pyn_mat_get_values(pyn_ctx* c, int id, double* val) {
   PYN_TRY(pyn_check_mat(c, id, "pyn_mat_get_values"));
   PYN_CHECK(val, "val is NULL");
   DMat& m = c->mats[id];
-  PYN_HIP(hipMemcpyAsync(val, m.val, (size_t)c->nnzb * m.br * m.bc * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+  const size_t bytes = (size_t)c->nnzb * m.br * m.bc * sizeof(double);
+  if (m.rhs_compact) {      // the caller sees the graph's layout: zeros in the rows the matrix does not store
+    DevTmp full;
+    PYN_HIP(full.alloc(bytes));
+    PYN_TRY(pyn_rhs_expand(c, m, full.as<double>()));
+    PYN_HIP(hipMemcpyAsync(val, full.p, bytes, hipMemcpyDeviceToHost, c->stream));
+    PYN_HIP(hipStreamSynchronize(c->stream));
+    return PYN_OK;
+  }
+  PYN_HIP(hipMemcpyAsync(val, m.val, bytes, hipMemcpyDeviceToHost, c->stream));
   PYN_HIP(hipStreamSynchronize(c->stream));
   return PYN_OK;
 }

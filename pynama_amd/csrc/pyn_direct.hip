@@ -307,6 +307,7 @@ extern "C" int pyn_solve_direct(pyn_ctx* c, int mat_id, int bv, int xv, pyn_solv
   PYN_CHECK(bv != xv, "b and x must differ");
   DMat& A = c->mats[mat_id];
   PYN_CHECK(A.br == A.bc, "matrix must be square");
+  PYN_CHECK(!A.rhs_compact, "a compact imposed-column matrix (pyn_mat_create_rhs) is a right-hand-side operator, not a system matrix");
   PYN_CHECK(c->vecs[bv].bs == A.br && c->vecs[xv].bs == A.br, "vector block size mismatch");
   PYN_CHECK(c->nranks == 1 && c->n_ghost == 0, "the dense direct solve runs on one rank");
   const int64_t n = c->n_owned * A.br;

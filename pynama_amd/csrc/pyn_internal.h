@@ -94,6 +94,15 @@ struct DMat {
   // which Dirichlet set (pyn_ctx::bc_stamp) the stored values are known to be exactly that matrix -- or all zero (PYN_RHS_ANY: a fresh
   // or zeroed matrix fits every set); the lattice kernels then leave the zero blocks of tiles without imposed nodes unwritten.
   int64_t rhs_clean = -2;      // PYN_RHS_UNKNOWN
+  // COMPACT imposed-column matrix (pyn_mat_create_rhs): only the node rows with an imposed node in their neighbourhood (themselves
+  // included) are stored -- what the reference preallocates for Krhs (src/matrices/mat_generator.py:42-58, 91: `drhs_nnz`).  Stored rows
+  // keep the graph's full column list; `val` holds c_nnzb blocks.  The selection belongs to ONE Dirichlet set (c_stamp).
+  bool rhs_compact = false;
+  int64_t c_stamp = -1;        // pyn_ctx::bc_stamp of the selection (-1: none yet)
+  int64_t c_nr = 0, c_nnzb = 0;
+  int32_t* c_crow = nullptr;   // [n_owned] first block of the node's row in `val`, -1: row not stored
+  int32_t* c_rsel = nullptr;   // [c_nr] stored node rows, ascending
+  int32_t* c_cptr = nullptr;   // [c_nr + 1] first block of every stored row
   bool live = false;
   void touch() {               // the values are about to change
     sell_valid = prod_ready = dinv_valid = lu_valid = false;
@@ -253,6 +262,12 @@ struct pyn_ctx {
   double* asm_dinv = nullptr;
   bool asm_dinv_written = false;
   bool asm_rhs_clean = false;   // the Krhs / Arhs target of the assembly in flight holds zeros wherever this Dirichlet set leaves zeros
+  const int32_t* asm_rcrow = nullptr;      // ... is a COMPACT matrix: first block of every owned node row in it (-1: not stored), else null
+  const int32_t* asm_rcrow_fs = nullptr;   // the same for Krhsfs of the no-slip split
+  bool asm_krhs_pending = false;           // the kernel family that took K left the compact Krhs to the generic kernel (run_assembly)
+  // elements with an imposed node (the only ones that feed an imposed-column matrix), per Dirichlet set
+  int32_t* d_esel = nullptr;
+  int64_t n_esel = 0, esel_stamp = -1;
   // general-geometry KLE: off-diagonal element Laplacians [28][ne] between the pre-pass and the tile kernel (grown on demand)
   double* d_kle_lel = nullptr;
   size_t kle_lel_bytes = 0;
@@ -282,6 +297,12 @@ int pyn_sell_spmv_range2(pyn_ctx* c, const DMat& A, const double* x, double* y, 
                          int64_t b1, int poff, int max_grid, hipStream_t st, int* grid_out);
 int pyn_sell_spmv_range(pyn_ctx* c, const DMat& A, const double* x, double* y, bool dot, int64_t s0, int64_t s1, int poff,
                         int max_grid, hipStream_t st, int* grid_out);
+// compact imposed-column matrices (pyn_rhs.hip)
+int pyn_rhs_ensure(pyn_ctx* c, DMat& M, bool relayout = false);   // row selection + storage (values zeroed when laid out); relayout: for the CURRENT Dirichlet set
+void pyn_rhs_release(DMat& M);
+int pyn_rhs_expand(pyn_ctx* c, const DMat& M, double* full);   // full-pattern copy of the values (zeros in the rows not stored)
+int pyn_bc_elements(pyn_ctx* c);                        // c->d_esel / n_esel for the current Dirichlet set
+int64_t pyn_mat_blocks(const pyn_ctx* c, const DMat& M);        // blocks stored by the matrix (graph entries, or the compact count)
 int pyn_lattice_detect(pyn_ctx* c, const int32_t* conn_host);  // pyn_assemble_tiled.hip
 bool pyn_q1_affine_tables_standard(const double* aff);
 int pyn_mesh_all_affine(pyn_ctx* c, int* out);                        // pyn_assemble_tiled.hip

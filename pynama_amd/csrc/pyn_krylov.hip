@@ -612,6 +612,7 @@ extern "C" int pyn_mat_get_diagonal(pyn_ctx* c, int mat_id, int vec_id) {
   PYN_TRY(pyn_check_mat(c, mat_id, "get_diagonal"));
   PYN_TRY(pyn_check_vec(c, vec_id, "get_diagonal"));
   PYN_CHECK(c->vecs[vec_id].bs == c->mats[mat_id].br, "block size mismatch");
+  PYN_CHECK(!c->mats[mat_id].rhs_compact, "get_diagonal: not available for a compact imposed-column matrix");
   return pyn_extract_diag_inv(c, c->mats[mat_id], c->vecs[vec_id].d, false);
 }
 
@@ -624,6 +625,7 @@ extern "C" int pyn_mat_axpy(pyn_ctx* c, int ym, double a, int xm) {
   PYN_TRY(pyn_check_mat(c, xm, "mat_axpy x"));
   DMat &Y = c->mats[ym], &X = c->mats[xm];
   PYN_CHECK(Y.br == X.br && Y.bc == X.bc, "block shape mismatch");
+  PYN_CHECK(!Y.rhs_compact && !X.rhs_compact, "mat_axpy: not available for compact imposed-column matrices");
   int64_t n = c->nnzb * Y.br * Y.bc;
   Y.touch();
   mat_axpy_kernel<<<vgrid(n), 256, 0, c->stream>>>(Y.val, a, X.val, n);
@@ -651,6 +653,7 @@ extern "C" int pyn_mat_row_scale(pyn_ctx* c, int mat_id, int vec_id) {
   PYN_TRY(pyn_check_vec(c, vec_id, "row_scale"));
   DMat& A = c->mats[mat_id];
   PYN_CHECK(c->vecs[vec_id].bs == A.br, "block size mismatch");
+  PYN_CHECK(!A.rhs_compact, "row_scale: not available for a compact imposed-column matrix");
   int64_t rows = c->n_owned * A.br;
   A.touch();
   int grid = (int)std::max<int64_t>(1, std::min<int64_t>((rows * 64 + 255) / 256, 8192));
@@ -668,7 +671,13 @@ extern "C" int pyn_spmv(pyn_ctx* c, int mat_id, int xv, int yv) {
   PYN_HIP(hipSetDevice(c->device));
   PYN_HIP(hipEventRecord(c->ev0, c->stream));
   PYN_TRY(pyn_halo_exchange(c, c->vecs[xv].d, A.bc));
-  if (pyn_sell_supported(A) && !getenv("PYNAMA_NO_SELL")) {  // multiply through the SELL-64 image
+  if (A.rhs_compact) {   // rows that are not stored are zero rows: y = 0, then the stored rows from their block-CSR values
+    PYN_TRY(pyn_rhs_ensure(c, A));
+    PYN_HIP(hipMemsetAsync(c->vecs[yv].d, 0, (size_t)c->n_owned * A.br * sizeof(double), c->stream));
+    PYN_TRY(pyn_sell_ensure(c, A, false));
+    PYN_HIP(hipEventRecord(c->ev0, c->stream));
+    PYN_TRY(pyn_sell_spmv(c, A, c->vecs[xv].d, c->vecs[yv].d, false, nullptr));
+  } else if (pyn_sell_supported(A) && !getenv("PYNAMA_NO_SELL")) {  // multiply through the SELL-64 image
     PYN_TRY(pyn_sell_ensure(c, A, false));
     PYN_HIP(hipEventRecord(c->ev0, c->stream));  // time the product, not the (one-off) conversion
     PYN_TRY(pyn_sell_spmv(c, A, c->vecs[xv].d, c->vecs[yv].d, false, nullptr));
@@ -1345,6 +1354,7 @@ extern "C" int pyn_solve(pyn_ctx* c, int mat_id, int bv, int xv, const pyn_solve
   PYN_CHECK(bv != xv, "b and x must differ");
   DMat& A = c->mats[mat_id];
   PYN_CHECK(A.br == A.bc, "matrix must be square");
+  PYN_CHECK(!A.rhs_compact, "a compact imposed-column matrix (pyn_mat_create_rhs) is a right-hand-side operator, not a system matrix");
   PYN_CHECK(c->vecs[bv].bs == A.br && c->vecs[xv].bs == A.br, "vector block size mismatch");
   PYN_CHECK(opts->method == PYN_KSP_CG || opts->method == PYN_KSP_GMRES, "unknown method %d", opts->method);
   PYN_CHECK(opts->pc == PYN_PC_NONE || opts->pc == PYN_PC_JACOBI, "unknown preconditioner %d", opts->pc);

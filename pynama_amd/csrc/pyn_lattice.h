@@ -38,6 +38,8 @@ struct LatArgs {
   double* dinv = nullptr;              // 1 / diagonal per owned row, written with the rows (may be null)
   int rhs_clean = 0;                   // Arhs already holds zeros wherever this Dirichlet set leaves zeros (DMat::rhs_clean): tiles without
                                        // an imposed node in their node box do not write their (all-zero) Arhs rows again
+  const int32_t* rcrow = nullptr;      // Arhs is a COMPACT imposed-column matrix: first block of every owned node row in it, -1 = not stored
+                                       // (honoured by the KLE lattice kernels; the scalar kernels are never handed a compact target)
   unsigned long long* dbg = nullptr;   // diagnostics (PYNAMA_MARCH_STAMPS): per-phase s_memtime stamps of the marching kernels
 };
 

@@ -569,7 +569,9 @@ template <int BR, int BC, int U, bool DOT>
 __global__ void __launch_bounds__(256) bcsr_spmv_kernel(const int32_t* __restrict__ rowptr, const int32_t* __restrict__ colidx,
                                                         const double* __restrict__ val, const double* __restrict__ x, double* __restrict__ y,
                                                         int lg, int64_t n0, int64_t n1, int64_t hole_begin, int64_t hole_len,
-                                                        const int* __restrict__ flag, double* __restrict__ part, int part_off) {
+                                                        const int* __restrict__ flag, double* __restrict__ part, int part_off,
+                                                        const int32_t* __restrict__ rsel, const int32_t* __restrict__ cptr) {
+  // rsel / cptr: COMPACT matrix (pyn_rhs.hip) -- logical row t is node row rsel[t], its values start at block cptr[t]
   __shared__ double smd[4];
   if (flag && flag[0]) return;
   // U entries per lane and trip: U column loads, U x gathers and U BR value loads in flight
@@ -578,31 +580,36 @@ __global__ void __launch_bounds__(256) bcsr_spmv_kernel(const int32_t* __restric
   const int64_t w0 = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6), nw = (int64_t)gridDim.x * 4;
   double dot = 0.0;
   // row offsets one step ahead: a node's loads start without a dependent load in front of them
-  int nlo = 0, nhi = 0;
+  int nlo = 0, nhi = 0, nvl = 0;
+  int64_t ni = 0;
   {
     const int64_t tl = n0 + w0 * npw + sub;
     if (tl < n1) {
-      const int64_t i = tl >= hole_begin ? tl + hole_len : tl;
-      nlo = rowptr[i];
-      nhi = rowptr[i + 1];
+      const int64_t tq = tl >= hole_begin ? tl + hole_len : tl;
+      ni = rsel ? rsel[tq] : tq;
+      nlo = rowptr[ni];
+      nhi = rowptr[ni + 1];
+      nvl = rsel ? cptr[tq] : nlo;
     }
   }
   for (int64_t tb = n0 + w0 * npw; tb < n1; tb += nw * npw) {   // n1: logical end (hole removed)
     const int64_t tl = tb + sub;
     const bool live = tl < n1;
-    const int64_t i = tl >= hole_begin ? tl + hole_len : tl;
-    const int lo = nlo, len = nhi - nlo;
+    const int64_t i = ni;
+    const int lo = nlo, len = nhi - nlo, vlo = nvl;
     {
       const int64_t t2 = tl + nw * npw;
-      nlo = nhi = 0;
+      nlo = nhi = nvl = 0;
       if (t2 < n1) {
-        const int64_t i2 = t2 >= hole_begin ? t2 + hole_len : t2;
-        nlo = rowptr[i2];
-        nhi = rowptr[i2 + 1];
+        const int64_t tq = t2 >= hole_begin ? t2 + hole_len : t2;
+        ni = rsel ? rsel[tq] : tq;
+        nlo = rowptr[ni];
+        nhi = rowptr[ni + 1];
+        nvl = rsel ? cptr[tq] : nlo;
       }
     }
     const int L1 = len * BC;
-    const double* __restrict__ v = val + (int64_t)lo * (BR * BC);
+    const double* __restrict__ v = val + (int64_t)vlo * (BR * BC);
     const int32_t* __restrict__ ci = colidx + lo;
     double acc[BR];
 #pragma unroll
@@ -811,6 +818,13 @@ int pyn_sell_ensure(pyn_ctx* c, DMat& A, bool solver) {
   }
   A.csr_product = csr_product(c, A, S);
   A.bcsr_product = false;
+  if (A.rhs_compact) {   // stored rows only, from their block-CSR values
+    PYN_CHECK(bcsr_shape(A.br, A.bc), "no block-CSR product for block shape %dx%d", A.br, A.bc);
+    A.csr_product = A.csrlb_product = false;
+    A.bcsr_product = true;
+    A.prod_ready = true;
+    return PYN_OK;
+  }
   A.csrlb_product = !A.csr_product && A.br == 2 && A.bc == 2 && c->sell_npat > 0 && S->maxw <= 50 && !getenv("PYNAMA_BLOCK_SELL") &&
                     !getenv("PYNAMA_NO_CSRLB");
   int bm = 0;
@@ -921,7 +935,12 @@ int pyn_sell_spmv_range2(pyn_ctx* c, const DMat& A, const double* x, double* y, 
   if (A.bcsr_product) {   // block-CSR values, G lanes per node row; slice boundaries become node boundaries (floor: a node that straddles
                           // an interior and a boundary slice has no ghost column, either side may take it)
     auto node_of = [&](int64_t sl) { return std::min<int64_t>(c->n_owned, sl * SH / A.br); };
-    const int64_t na0 = node_of(a0), na1 = node_of(a1), nb0 = node_of(b0), nb1 = node_of(b1);
+    int64_t na0 = node_of(a0), na1 = node_of(a1), nb0 = node_of(b0), nb1 = node_of(b1);
+    if (A.rhs_compact) {   // whole products only (a right-hand-side operator is never split for a halo overlap): all stored rows
+      PYN_CHECK(a0 == 0 && b1 == S->ns && a1 == b0 && !dot, "compact imposed-column matrix: whole products only");
+      na0 = 0;
+      na1 = nb0 = nb1 = A.c_nr;
+    }
     const int64_t nhb = na1, nhl = nb0 - na1, n0 = na0, n1 = nb1 - nhl;
     if (n0 >= n1) {
       if (grid_out) *grid_out = 0;
@@ -955,7 +974,8 @@ int pyn_sell_spmv_range2(pyn_ctx* c, const DMat& A, const double* x, double* y, 
     gridb = (int)std::max<int64_t>(1, std::min<int64_t>(std::min<int64_t>(want, max_grid), 256 * (wcu ? atoi(wcu) : per_cu)));             \
     PYN_CHECK(poff + gridb <= PYN_MAX_PARTIALS, "partial buffer overflow");                                                                \
     bcsr_spmv_kernel<RR, CC, UU, DD><<<gridb, 256, 0, st>>>(c->d_rowptr, c->d_colidx, A.val, x, y, lg, n0, n1, nhb, nhl,                   \
-                                                            DD ? c->d_flag : nullptr, DD ? c->d_part : nullptr, poff);                    \
+                                                            DD ? c->d_flag : nullptr, DD ? c->d_part : nullptr, poff,                     \
+                                                            A.rhs_compact ? A.c_rsel : nullptr, A.rhs_compact ? A.c_cptr : nullptr);      \
   } while (0)
 #define BCSR_LAUNCH(RR, CC, DD)                 \
   do {                                          \

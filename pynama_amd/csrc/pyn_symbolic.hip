@@ -40,8 +40,10 @@ static int pyn_symbolic_reset_dependents(pyn_ctx* c) {
     (void)hipFree(m.sell_val);
     (void)hipFree(m.dinv);
     m.release_lu();
+    pyn_rhs_release(m);
   }
   c->mats.clear();
+  c->esel_stamp = -1;
   pyn_sell_drop_structure(c);
   c->lat.std_ok = -1;  // closed-form row offsets are re-verified against the new graph
   c->plan_unfit[0] = c->plan_unfit[1] = false;

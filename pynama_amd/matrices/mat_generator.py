@@ -19,9 +19,12 @@ from pynama_amd.vectors import Vec
 class DeviceMat:
     """PETSc.Mat look-alike bound to a device matrix handle."""
 
-    def __init__(self, ctx, br, bc, name=None):
+    def __init__(self, ctx, br, bc, name=None, rhs=False):
+        """rhs: an imposed-column matrix (Krhs, Krhsfs: -K_e[free, bc] + the unit diagonal of the imposed DOFs) kept COMPACT -- only the
+        node rows next to an imposed node are stored, the preallocation of mat_generator.py:42-58, 91 (`drhs_nnz`); laid out for the
+        Dirichlet mask current on the device (Context.bc_set), again by an assembly under another one"""
         self.ctx, self.br, self.bc = ctx, br, bc
-        self.id = ctx.mat_create(br, bc)
+        self.id = ctx.mat_create_rhs(br, bc) if rhs else ctx.mat_create(br, bc)
         self._gen = getattr(ctx, "graph_gen", 0)
         self._name = name
         self._assembled = False
@@ -113,7 +116,8 @@ class DeviceMat:
         return v
 
     def getInfo(self):
-        nnz = self.ctx.nnzb * self.br * self.bc
+        blocks, _ = self.ctx.mat_stored(self.id)
+        nnz = blocks * self.br * self.bc
         return {"memory": nnz * 8 + self.ctx.nnzb * 4, "nz_allocated": nnz, "nz_used": nnz, "nz_unneeded": 0}
 
 
@@ -173,7 +177,9 @@ class Mat:
         self.K = DeviceMat(self.ctx, self.dim, self.dim, "K")
         self.Rw = DeviceMat(self.ctx, self.dim, self.dim_w, "Rw")
         self.Rd = DeviceMat(self.ctx, self.dim, 1, "Rd")
-        self.Krhs = DeviceMat(self.ctx, self.dim, self.dim, "Krhs")
+        # Krhs: rows next to an imposed node only, as the reference preallocates it (:42-58, 91) -- the Dirichlet mask goes to the device first
+        self.ctx.bc_set(self.dim, self.dom.dirichletMaskLocal(self.dim))
+        self.Krhs = DeviceMat(self.ctx, self.dim, self.dim, "Krhs", rhs=True)
         self.mats = [self.K, self.Rw, self.Rd, self.Krhs]
 
     def createEmptyMat(self, rows, cols, d_nonzero, offset_nonzero):

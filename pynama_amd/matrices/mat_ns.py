@@ -12,9 +12,10 @@ class MatNS(Mat):
         self.globalIndicesDIR = set(indicesDIR)
         self.globalIndicesNS = set(indicesNS)
         d, dw = self.dim, self.dim_w
-        mk = lambda br, bc, name: DeviceMat(self.ctx, br, bc, name)
-        self.K, self.Rw, self.Rd, self.Krhs = mk(d, d, "K"), mk(d, dw, "Rw"), mk(d, 1, "Rd"), mk(d, d, "Krhs")
-        self.Kfs, self.Rwfs, self.Rdfs, self.Krhsfs = mk(d, d, "Kfs"), mk(d, dw, "Rwfs"), mk(d, 1, "Rdfs"), mk(d, d, "Krhsfs")
+        mk = lambda br, bc, name, rhs=False: DeviceMat(self.ctx, br, bc, name, rhs=rhs)
+        # Krhs / Krhsfs: compact imposed-column matrices (rows next to an imposed node; laid out by the assembly for its DOF classes)
+        self.K, self.Rw, self.Rd, self.Krhs = mk(d, d, "K"), mk(d, dw, "Rw"), mk(d, 1, "Rd"), mk(d, d, "Krhs", True)
+        self.Kfs, self.Rwfs, self.Rdfs, self.Krhsfs = mk(d, d, "Kfs"), mk(d, dw, "Rwfs"), mk(d, 1, "Rdfs"), mk(d, d, "Krhsfs", True)
         self.mats = [self.K, self.Rw, self.Rd, self.Krhs, self.Kfs, self.Rwfs, self.Rdfs, self.Krhsfs]
 
     def assembleAll(self):
