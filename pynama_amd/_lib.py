@@ -289,7 +289,7 @@ class Context:
         """('lattice', nx, ny, nz) for structured Q1 hex meshes, ('general', 0, 0, 0) otherwise"""
         k, a, b, c = _I(0), _I(0), _I(0), _I(0)
         _check(self.lib.pyn_mesh_topology(self.h, C.byref(k), C.byref(a), C.byref(b), C.byref(c)))
-        return (("general", "lattice", "lattice-ngl3")[k.value], a.value, b.value, c.value)
+        return (("general", "lattice", "lattice-ngl3", "lattice-q1-2d")[k.value], a.value, b.value, c.value)
 
     def tables_set(self, which, w, H, Hrs, HrsCoo):
         w = _f64(w)

@@ -1301,6 +1301,7 @@ static int check_operator(pyn_ctx* c, int rule, int br, int bc, int nterms, cons
 extern "C" int pyn_assemble_operator(pyn_ctx* c, int rule, int nterms, const int32_t* terms, const double* coef, int mat_id) {
   PYN_TRY(pyn_check_mat(c, mat_id, "pyn_assemble_operator"));
   DMat& M = c->mats[mat_id];
+  PYN_CHECK(!M.rhs_compact, "pyn_assemble_operator: the target must have the graph's full pattern");
   PYN_TRY(check_operator(c, rule, M.br, M.bc, nterms, terms, coef));
   PYN_HIP(hipSetDevice(c->device));
   int32_t* dt = nullptr;
@@ -1317,8 +1318,12 @@ extern "C" int pyn_assemble_operator(pyn_ctx* c, int rule, int nterms, const int
   A.K = M.val;
   M.touch();
   PYN_HIP(hipEventRecord(c->ev0, c->stream));
-  PYN_HIP(hipMemsetAsync(M.val, 0, (size_t)c->nnzb * M.br * M.bc * sizeof(double), c->stream));
-  PYN_TRY(launch_generic<false>(c, A, c->n_elem));
+  bool handled = false;   // structured meshes of parallelepipeds: the row-run kernels (no atomics, every row written once)
+  PYN_TRY(pyn_assemble_ho3_operator(c, rule, M.br, M.bc, nterms, terms, coef, M.val, &handled));
+  if (!handled) {
+    PYN_HIP(hipMemsetAsync(M.val, 0, (size_t)c->nnzb * M.br * M.bc * sizeof(double), c->stream));
+    PYN_TRY(launch_generic<false>(c, A, c->n_elem));
+  }
   PYN_HIP(hipEventRecord(c->ev1, c->stream));
   PYN_HIP(hipStreamSynchronize(c->stream));
   float ms = 0;

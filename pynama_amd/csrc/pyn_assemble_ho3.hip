@@ -21,6 +21,11 @@
 //   Rw[(a,p),(b,k)] = detJ sum_{(p,k,d,s) in curl_w} s Ji_d. Uf_.[a][b] + alpha_w detJ sum_{(k,p,d,s) in curl_v} s Ji_d. Ur_.[b][a]
 // (spectral.py:124-156 written out; checked against the oracle's quadrature loop).  Meshes with a non-affine element keep the
 // generic workgroup-per-element kernel.
+//
+// The same row-run scheme serves FIRST-order lattices (NGL = 2) where no dedicated kernel exists: 2-D Q1 quadrilaterals (K, Krhs, Rw,
+// scalar Laplacian) and, on every lattice (2-D / 3-D, ngl 2 / 3), the first-order operators SrT / DivSrT / Curl of
+// Spectral.getElemKLEOperators (src/elements/spectral.py:159-218; Operators.setValues, src/matrices/mat_generator.py:157-170): at the
+// nodal rule  M[(a,p),(b,q)] = detJ sum_t [row_t = p, col_t = q] coef_t sum_x Ji[der_t][x] Un_x[a][b],  Un_x[a][b] = sum_g w H[a] Hrs_x[b].
 #include <hipcub/hipcub.hpp>
 
 #include <algorithm>
@@ -32,15 +37,25 @@ namespace {
 // lattice offset (x, y[, z]) in {0, 1, 2} of local node a: the reference's vertex / edge / face / interior order
 // (spectral.py:346-431, fixture tests/golden/g2_tables.npz `order_*`); 2-D carries the x ~ -r, y ~ -s flip of SURVEY.md A.2
 constexpr int LOC2[9][2] = {{0, 0}, {2, 0}, {2, 2}, {0, 2}, {1, 0}, {2, 1}, {1, 2}, {0, 1}, {1, 1}};
+// first-order cells: the corners in DMPlex closure order (src/tests/test_domain.py:26-30, 94-104)
+constexpr int LOQ2[4][2] = {{0, 0}, {1, 0}, {1, 1}, {0, 1}};
+constexpr int LOQ3[8][3] = {{0, 0, 0}, {0, 1, 0}, {1, 1, 0}, {1, 0, 0}, {0, 0, 1}, {1, 0, 1}, {1, 1, 1}, {0, 1, 1}};
 constexpr int LOC3[27][3] = {{0, 0, 0}, {0, 2, 0}, {2, 2, 0}, {2, 0, 0}, {0, 0, 2}, {2, 0, 2}, {2, 2, 2}, {0, 2, 2}, {0, 1, 0},
                              {1, 2, 0}, {2, 1, 0}, {1, 0, 0}, {1, 0, 2}, {2, 1, 2}, {1, 2, 2}, {0, 1, 2}, {2, 0, 1}, {0, 0, 1},
                              {0, 2, 1}, {2, 2, 1}, {1, 1, 0}, {1, 1, 2}, {1, 0, 1}, {1, 2, 1}, {2, 1, 1}, {0, 1, 1}, {1, 1, 1}};
 
-inline int tens_of(int dim, int a) {
-  return dim == 2 ? LOC2[a][1] * 3 + LOC2[a][0] : (LOC3[a][2] * 3 + LOC3[a][1]) * 3 + LOC3[a][0];
+inline int loc_of(int dim, int ngl, int a, int d) {
+  if (ngl == 2) return dim == 2 ? LOQ2[a][d] : LOQ3[a][d];
+  return dim == 2 ? LOC2[a][d] : LOC3[a][d];
+}
+inline int tens_of(int dim, int ngl, int a) {
+  int t = 0;
+  for (int d = dim - 1; d >= 0; --d) t = t * ngl + loc_of(dim, ngl, a, d);
+  return t;
 }
 
-enum { M_K = 0, M_RW = 1, M_LAP = 2 };
+enum { M_K = 0, M_RW = 1, M_LAP = 2, M_OP = 3 };
+constexpr int MAX_TERMS = 32;
 
 struct Ho3Args {
   int EX, EY, EZ, NX, NY, npl, p_own0, n_own;
@@ -58,15 +73,21 @@ struct Ho3Args {
   int nruns, nly;         // runs per x-line, lines of this class per plane (3-D)
   int so0;                // first owned plane (3-D) / line (2-D), as an owned index, whose local index has the parity of the class
   int img_len;            // doubles of LDS behind the kernel
+  int step;               // distance (owned index) between two lines of a class along the slow axis: 2 (ngl 3), 1 (ngl 2)
+  // first-order operator form (M_OP): block shape and the (row component, column component, derivative axis, coefficient) terms
+  int obr, obc, nterms;
+  int t_row[MAX_TERMS], t_col[MAX_TERMS], t_der[MAX_TERMS];
+  double t_coef[MAX_TERMS];
 };
 
+template <int NGL>
 __device__ __forceinline__ void axis_range(int c, int N, int& lo, int& n) {
-  const int h = (c & 1) ? 1 : 2;
+  const int h = NGL == 2 ? 1 : ((c & 1) ? 1 : 2);
   lo = max(0, c - h);
   n = min(N - 1, c + h) - lo + 1;
 }
 
-// exact k / n for 0 <= k < 2048, n in {3, 5, 9, 15, 25}
+// exact k / n for 0 <= k < 2048, n in {2, 3, 4, 5, 6, 9, 15, 25}
 __device__ __forceinline__ int small_div(int k, int n) { return (k * (65536 / n + 1)) >> 16; }
 
 // corner cn of an element (first 2^dim local nodes) as lattice bits x | y << 1 | z << 2 -- LOC2 / LOC3 halved, spelled out for device code
@@ -80,11 +101,19 @@ constexpr bool corner_bits_match() {
   return true;
 }
 static_assert(corner_bits_match(), "corner tables out of step with the local node order");
+constexpr bool q1_corners_match() {
+  for (int cn = 0; cn < 4; ++cn)
+    if (CB2[cn] != (LOQ2[cn][0] | (LOQ2[cn][1] << 1))) return false;
+  for (int cn = 0; cn < 8; ++cn)
+    if (CB3[cn] != (LOQ3[cn][0] | (LOQ3[cn][1] << 1) | (LOQ3[cn][2] << 2))) return false;
+  return true;
+}
+static_assert(q1_corners_match(), "first-order corner table out of step");
 
 template <int DIM>
-__global__ void __launch_bounds__(256) ho3_geom_kernel(const int32_t* __restrict__ conn, const double* __restrict__ xyz, int64_t n_elem,
+__global__ void __launch_bounds__(256) ho3_geom_kernel(const int32_t* __restrict__ conn, const double* __restrict__ xyz, int64_t n_elem, int NN,
                                                        const double* __restrict__ hcoo, double* __restrict__ geom, int* __restrict__ not_affine) {
-  constexpr int NN = DIM == 3 ? 27 : 9, NC = 1 << DIM, GS = DIM == 3 ? 10 : 6;
+  constexpr int NC = 1 << DIM, GS = DIM == 3 ? 10 : 6;
   const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (e >= n_elem) return;
   double X[NC][DIM];
@@ -106,7 +135,7 @@ __global__ void __launch_bounds__(256) ho3_geom_kernel(const int32_t* __restrict
       J[r * DIM + x] = s;
     }
   double det;
-  if (DIM == 2) {
+  if constexpr (DIM == 2) {
     det = J[0] * J[3] - J[1] * J[2];
     const double rr = 1.0 / det;
     Ji[0] = J[3] * rr;
@@ -131,7 +160,7 @@ __global__ void __launch_bounds__(256) ho3_geom_kernel(const int32_t* __restrict
 #pragma unroll
   for (int i = 0; i < DIM * DIM; ++i) g[i] = Ji[i];
   g[DIM * DIM] = det;
-  if (DIM == 2) g[5] = 0.0;
+  if constexpr (DIM == 2) g[5] = 0.0;
   if (not_affine) {
     // corner cn sits at the lattice offsets LOC[cn] / 2: a parallelepiped is X_o + sum_d bit_d (X_d - X_o)
     constexpr int cb2[4] = {0, 1, 3, 2}, cb3[8] = {0, 2, 3, 1, 4, 5, 7, 6};   // = CB2 / CB3
@@ -171,11 +200,11 @@ __global__ void ho3_pack_bits_kernel(const uint8_t* __restrict__ mask, int64_t n
   bits[i] = (uint8_t)m;
 }
 
-// one block of the element matrix of element `g` (J^-1, detJ) for the local node pair (a, b) in tensor order
-template <int DIM, int MAT>
+// one block of the element matrix of element `g` (J^-1, detJ) for the local node pair (a, b) in tensor order; NN = nodes per element
+template <int DIM, int NN, int MAT>
 __device__ __forceinline__ void ho3_block(const double* __restrict__ g, const double* __restrict__ tabs, int a, int b, double alpha_d,
                                           double alpha_w, double (&v)[3][3]) {
-  constexpr int NN = DIM == 3 ? 27 : 9, N2 = NN * NN, DD = DIM * DIM;
+  constexpr int N2 = NN * NN, DD = DIM * DIM;
   double Ji[DIM][DIM];
 #pragma unroll
   for (int x = 0; x < DIM; ++x)
@@ -187,6 +216,19 @@ __device__ __forceinline__ void ho3_block(const double* __restrict__ g, const do
 #pragma unroll
     for (int q = 0; q < 3; ++q) v[p][q] = 0.0;
   const int ab = a * NN + b;
+  if (MAT == M_OP) {   // v[0][d] = detJ sum_x Ji[d][x] Un_x[a][b]: H_a grad_d N_b at the nodal rule; the caller places the terms
+    double un[DIM];
+#pragma unroll
+    for (int x = 0; x < DIM; ++x) un[x] = tabs[(2 * DD + 2 * DIM + x) * N2 + ab];
+#pragma unroll
+    for (int d = 0; d < DIM; ++d) {
+      double s0 = 0.0;
+#pragma unroll
+      for (int x = 0; x < DIM; ++x) s0 = fma(Ji[d][x], un[x], s0);
+      v[0][d] = det * s0;
+    }
+    return;
+  }
   if (MAT == M_K || MAT == M_LAP) {
     double tf[DIM][DIM];
 #pragma unroll
@@ -286,13 +328,14 @@ __device__ __forceinline__ void ho3_block(const double* __restrict__ g, const do
   }
 }
 
-template <int DIM, int MAT, int R>
+template <int DIM, int NGL, int MAT, int R>
 __global__ void __launch_bounds__(256) assemble_ho3_lattice_kernel(Ho3Args T) {
-  constexpr int NN = DIM == 3 ? 27 : 9, GS = DIM == 3 ? 10 : 6;
-  constexpr int BR = MAT == M_LAP ? 1 : DIM;
-  constexpr int BC = MAT == M_K ? DIM : (MAT == M_RW ? (DIM == 3 ? 3 : 1) : 1);
-  constexpr int BB = BR * BC;
-  constexpr int BXW = R + 4, BYW = 5, BZW = DIM == 3 ? 5 : 1;
+  constexpr int M = NGL - 1, NN = DIM == 3 ? NGL * NGL * NGL : NGL * NGL, GS = DIM == 3 ? 10 : 6;
+  constexpr int BRc = MAT == M_LAP ? 1 : DIM;
+  constexpr int BCc = MAT == M_K ? DIM : (MAT == M_RW ? (DIM == 3 ? 3 : 1) : 1);
+  const int BR = MAT == M_OP ? T.obr : BRc, BC = MAT == M_OP ? T.obc : BCc;   // compile-time constants except for the operators
+  const int BB = BR * BC;
+  constexpr int BXW = R + 2 * M, BYW = 2 * M + 1, BZW = DIM == 3 ? 2 * M + 1 : 1;   // node box around the run: M nodes on every side
   extern __shared__ double img[];
   __shared__ int rowoff[R + 1];
   __shared__ int srank[5], splane[5];   // slow axis: sorted position of neighbour plane j, and its inverse
@@ -306,17 +349,17 @@ __global__ void __launch_bounds__(256) assemble_ho3_lattice_kernel(Ho3Args T) {
   int cy, cz = 0, so;   // local y / z index of the line, owned index along the slow axis
   if (DIM == 3) {
     const int iy = bid % T.nly;
-    so = T.so0 + 2 * (bid / T.nly);
-    cy = 2 * iy + T.par_y;
+    so = T.so0 + T.step * (bid / T.nly);
+    cy = NGL == 3 ? 2 * iy + T.par_y : iy;
     cz = T.p_own0 + so;
   } else {
-    so = T.so0 + 2 * bid;
+    so = T.so0 + T.step * bid;
     cy = T.p_own0 + so;
   }
   const int NYL = DIM == 3 ? T.NY : T.npl;   // extent of the y axis
   int ylo, n_y, zlo = 0, n_z = 1;
-  axis_range(cy, NYL, ylo, n_y);
-  if (DIM == 3) axis_range(cz, T.npl, zlo, n_z);
+  axis_range<NGL>(cy, NYL, ylo, n_y);
+  if (DIM == 3) axis_range<NGL>(cz, T.npl, zlo, n_z);
   const int slo = DIM == 3 ? zlo : ylo, n_s = DIM == 3 ? n_z : n_y;
   const int64_t row0 = DIM == 3 ? ((int64_t)so * T.NY + cy) * NX + x0 : (int64_t)so * NX + x0;
   const int rp0 = T.rowptr[row0];
@@ -333,7 +376,7 @@ __global__ void __launch_bounds__(256) assemble_ho3_lattice_kernel(Ho3Args T) {
   if (T.nbits) {
     for (int i = tid; i < BXW * BYW * BZW; i += 256) {
       const int bx = i % BXW, by = (i / BXW) % BYW, bz = i / (BXW * BYW);
-      const int x = x0 - 2 + bx, y = cy - 2 + by, z = cz - 2 + bz;
+      const int x = x0 - M + bx, y = cy - M + by, z = cz - M + bz;
       int m = 0;
       if (x >= 0 && x < NX && y >= 0 && y < NYL && (DIM == 2 || (z >= 0 && z < T.npl))) {
         const int64_t id = DIM == 3 ? (int64_t)T.P[z] + (int64_t)y * NX + x : (int64_t)T.P[y] + x;
@@ -346,22 +389,34 @@ __global__ void __launch_bounds__(256) assemble_ho3_lattice_kernel(Ho3Args T) {
   for (int i = tid; i < T.img_len; i += 256) img[i] = 0.0;
   const int routed = __syncthreads_or(any);
 
-  // ---- the (row, element, column node) triples of the run
-  const int ny_e = (cy & 1) ? 1 : 2, nz_e = DIM == 3 ? ((cz & 1) ? 1 : 2) : 1;
+  // ---- the (row, element, column node) triples of the run.  ngl 3: rows alternate vertex-like (two elements along x) / mid-node
+  //      (one), enumerated per row pair with three x-slots; ngl 2: every row has two elements along x
+  const int ny_e = (NGL == 2 || !(cy & 1)) ? 2 : 1, nz_e = DIM == 3 ? ((NGL == 2 || !(cz & 1)) ? 2 : 1) : 1;
   const int nyz = ny_e * nz_e, sh = nyz == 4 ? 2 : (nyz == 2 ? 1 : 0);
-  const int nu = ((nrows + 1) >> 1) * 3 * nyz * NN;
+  const int nu = (NGL == 3 ? ((nrows + 1) >> 1) * 3 : nrows * 2) * nyz * NN;
   const int EYL = T.EY;
   for (int u = tid; u < nu; u += 256) {
     const int t0 = u / NN, b = u - t0 * NN;
     const int yz = t0 & (nyz - 1), t1 = t0 >> sh;
-    const int pr = t1 / 3, xs = t1 - pr * 3;
-    const int cx = x0 + 2 * pr + (xs == 2);
-    const int ex = (x0 >> 1) + pr - (xs == 0);
+    int cx, ex, la_x;
+    if (NGL == 3) {
+      const int pr = t1 / 3, xs = t1 - pr * 3;
+      cx = x0 + 2 * pr + (xs == 2);
+      ex = (x0 >> 1) + pr - (xs == 0);
+      la_x = xs == 0 ? 2 : (xs == 1 ? 0 : 1);
+    } else {
+      const int pr = t1 >> 1, xs = t1 & 1;
+      cx = x0 + pr;
+      ex = cx - 1 + xs;
+      la_x = 1 - xs;
+    }
     if (cx >= NX || ex < 0 || ex >= T.EX) continue;
-    const int la_x = xs == 0 ? 2 : (xs == 1 ? 0 : 1);
     const int ys = yz & (ny_e - 1), zs = ny_e == 2 ? yz >> 1 : yz;
     int ey, la_y, ez = 0, la_z = 0;
-    if (cy & 1) {
+    if (NGL == 2) {
+      ey = cy - 1 + ys;
+      la_y = 1 - ys;
+    } else if (cy & 1) {
       ey = cy >> 1;
       la_y = 1;
     } else {
@@ -370,7 +425,10 @@ __global__ void __launch_bounds__(256) assemble_ho3_lattice_kernel(Ho3Args T) {
     }
     if (ey < 0 || ey >= EYL) continue;
     if (DIM == 3) {
-      if (cz & 1) {
+      if (NGL == 2) {
+        ez = cz - 1 + zs;
+        la_z = 1 - zs;
+      } else if (cz & 1) {
         ez = cz >> 1;
         la_z = 1;
       } else {
@@ -380,24 +438,32 @@ __global__ void __launch_bounds__(256) assemble_ho3_lattice_kernel(Ho3Args T) {
       if (ez < 0 || ez >= T.EZ) continue;
     }
     const int64_t e = ex + (int64_t)T.EX * (ey + (int64_t)EYL * ez);
-    const int a = (la_z * 3 + la_y) * 3 + la_x;
-    const int lbx = b % 3, lby = (b / 3) % 3, lbz = b / 9;
+    const int a = (la_z * NGL + la_y) * NGL + la_x;
+    const int lbx = b % NGL, lby = (b / NGL) % NGL, lbz = b / (NGL * NGL);
     int xlo, n_x;
-    axis_range(cx, NX, xlo, n_x);
-    const int kx = 2 * ex + lbx - xlo, ky = 2 * ey + lby - ylo;
+    axis_range<NGL>(cx, NX, xlo, n_x);
+    const int kx = M * ex + lbx - xlo, ky = M * ey + lby - ylo;
     int k;
     if (DIM == 3)
-      k = (srank[2 * ez + lbz - zlo] * n_y + ky) * n_x + kx;
+      k = (srank[M * ez + lbz - zlo] * n_y + ky) * n_x + kx;
     else
       k = srank[ky] * n_x + kx;
     const int r = cx - x0;
     const int base = rowoff[r] * BB, len = rowoff[r + 1] - rowoff[r];
     double v[3][3];
-    ho3_block<DIM, MAT>(T.geom + e * GS, T.tabs, a, b, T.alpha_d, T.alpha_w, v);
+    ho3_block<DIM, NN, MAT>(T.geom + e * GS, T.tabs, a, b, T.alpha_d, T.alpha_w, v);
+    if (MAT == M_OP) {
+      for (int t = 0; t < T.nterms; ++t) {
+        const int d = T.t_der[t];
+        const double g = d == 0 ? v[0][0] : (d == 1 ? v[0][1] : v[0][2]);
+        atomicAdd(&img[base + (T.t_row[t] * len + k) * BC + T.t_col[t]], T.t_coef[t] * g);
+      }
+    } else {
 #pragma unroll
-    for (int p = 0; p < BR; ++p)
+      for (int p = 0; p < BRc; ++p)
 #pragma unroll
-      for (int q = 0; q < BC; ++q) atomicAdd(&img[base + (p * len + k) * BC + q], v[p][q]);
+        for (int q = 0; q < BCc; ++q) atomicAdd(&img[base + (p * len + k) * BCc + q], v[p][q]);
+    }
   }
   __syncthreads();
 
@@ -414,12 +480,12 @@ __global__ void __launch_bounds__(256) assemble_ho3_lattice_kernel(Ho3Args T) {
     }
     return;
   }
-  for (int r = 0; r < nrows; ++r) {
+  for (int r = 0; r < nrows; ++r) {   // (never the operators: they carry no Dirichlet elimination, mat_generator.py:157-170)
     const int cx = x0 + r;
     int xlo, n_x;
-    axis_range(cx, NX, xlo, n_x);
+    axis_range<NGL>(cx, NX, xlo, n_x);
     const int base = rowoff[r] * BB, len = rowoff[r + 1] - rowoff[r], L1 = len * BC;
-    const int rowbits = nb[((BZW >> 1) * BYW + 2) * BXW + r + 2];
+    const int rowbits = nb[((BZW >> 1) * BYW + M) * BXW + r + M];
     const int nxy = n_x * n_y;
     // Arhs: same place as in A for a matrix with the graph's pattern, the row's own start in a compact one
     int64_t rbase = gbase + base;
@@ -428,9 +494,9 @@ __global__ void __launch_bounds__(256) assemble_ho3_lattice_kernel(Ho3Args T) {
       rbase = rr >= 0 ? (int64_t)rr * BB : -1;
     }
     for (int j = tid; j < len * BB; j += 256) {
-      const int p = BR == 1 ? 0 : (j >= L1) + (BR == 3 ? (j >= 2 * L1) : 0);
+      const int p = BRc == 1 ? 0 : (j >= L1) + (BRc == 3 ? (j >= 2 * L1) : 0);
       const int rem = j - p * L1;
-      const int k = rem / BC, q = rem - k * BC;
+      const int k = rem / BCc, q = rem - k * BCc;
       int dx, dy, dz = 0;
       if (DIM == 3) {
         const int kz = small_div(k, nxy), r2 = k - kz * nxy;
@@ -447,7 +513,7 @@ __global__ void __launch_bounds__(256) assemble_ho3_lattice_kernel(Ho3Args T) {
       double va, vr;
       if ((rowbits >> p) & 1) {   // imposed row: unit diagonal in K and Krhs (mat_generator.py:113-118), nothing in Rw
         va = vr = (MAT != M_RW && dx == 0 && dy == 0 && dz == 0 && q == p) ? 1.0 : 0.0;
-      } else if (MAT != M_RW && ((nb[((dz + (BZW >> 1)) * BYW + dy + 2) * BXW + r + 2 + dx] >> q) & 1)) {
+      } else if (MAT != M_RW && ((nb[((dz + (BZW >> 1)) * BYW + dy + M) * BXW + r + M + dx] >> q) & 1)) {
         va = 0.0;                  // imposed column of a free row: -K_e[free, bc] goes to Krhs (base_problem.py:531-533)
         vr = -v;
       } else {
@@ -472,7 +538,14 @@ __device__ __forceinline__ void ho3_row_coords(const Ho3Args& T, int dim, int64_
   }
 }
 
-__global__ void ho3_rowlen_kernel(Ho3Args T, int dim, int64_t n_rows, int32_t* __restrict__ len) {
+__device__ __forceinline__ void axis_range_rt(int ngl, int c, int N, int& lo, int& n) {
+  if (ngl == 2)
+    axis_range<2>(c, N, lo, n);
+  else
+    axis_range<3>(c, N, lo, n);
+}
+
+__global__ void ho3_rowlen_kernel(Ho3Args T, int dim, int ngl, int64_t n_rows, int32_t* __restrict__ len) {
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i > n_rows) return;
   if (i == n_rows) {
@@ -481,20 +554,21 @@ __global__ void ho3_rowlen_kernel(Ho3Args T, int dim, int64_t n_rows, int32_t* _
   }
   int cx, cy, cz, lo, n_x, n_y, n_z = 1;
   ho3_row_coords(T, dim, i, cx, cy, cz);
-  axis_range(cx, T.NX, lo, n_x);
-  axis_range(cy, dim == 3 ? T.NY : T.npl, lo, n_y);
-  if (dim == 3) axis_range(cz, T.npl, lo, n_z);
+  axis_range_rt(ngl, cx, T.NX, lo, n_x);
+  axis_range_rt(ngl, cy, dim == 3 ? T.NY : T.npl, lo, n_y);
+  if (dim == 3) axis_range_rt(ngl, cz, T.npl, lo, n_z);
   len[i] = n_x * n_y * n_z;
 }
 
-__global__ void ho3_columns_kernel(Ho3Args T, int dim, int64_t n_rows, const int32_t* __restrict__ rowptr, int32_t* __restrict__ colidx) {
+__global__ void ho3_columns_kernel(Ho3Args T, int dim, int ngl, int64_t n_rows, const int32_t* __restrict__ rowptr,
+                                   int32_t* __restrict__ colidx) {
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n_rows) return;
   int cx, cy, cz, xlo, ylo, zlo = 0, n_x, n_y, n_z = 1;
   ho3_row_coords(T, dim, i, cx, cy, cz);
-  axis_range(cx, T.NX, xlo, n_x);
-  axis_range(cy, dim == 3 ? T.NY : T.npl, ylo, n_y);
-  if (dim == 3) axis_range(cz, T.npl, zlo, n_z);
+  axis_range_rt(ngl, cx, T.NX, xlo, n_x);
+  axis_range_rt(ngl, cy, dim == 3 ? T.NY : T.npl, ylo, n_y);
+  if (dim == 3) axis_range_rt(ngl, cz, T.npl, zlo, n_z);
   const int slo = dim == 3 ? zlo : ylo, n_s = dim == 3 ? n_z : n_y;
   int k = rowptr[i];
   // planes (x-lines in 2-D) in ascending order of their first node id: selection over <= 5 candidates
@@ -538,53 +612,107 @@ void fill_lattice_args(const pyn_ctx* c, Ho3Args& T) {
   T.nruns = T.nly = 0;
   T.so0 = 0;
   T.img_len = 0;
+  T.step = L.ngl == 3 ? 2 : 1;
+  T.obr = T.obc = 1;
+  T.nterms = 0;
 }
 
-template <int DIM, int MAT, int R>
+template <int DIM, int NGL, int MAT, int R>
 int launch_ho3(pyn_ctx* c, Ho3Args T) {
-  constexpr int BR = MAT == M_LAP ? 1 : DIM;
-  constexpr int BC = MAT == M_K ? DIM : (MAT == M_RW ? (DIM == 3 ? 3 : 1) : 1);
+  const int BR = MAT == M_OP ? T.obr : (MAT == M_LAP ? 1 : DIM);
+  const int BC = MAT == M_OP ? T.obc : (MAT == M_K ? DIM : (MAT == M_RW ? (DIM == 3 ? 3 : 1) : 1));
   const Ho3Lattice& L = c->ho3;
   T.nruns = (L.NX + R - 1) / R;
   static bool attr_done = false;
   if (!attr_done) {
-    PYN_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(assemble_ho3_lattice_kernel<DIM, MAT, R>),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));
+    PYN_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(assemble_ho3_lattice_kernel<DIM, NGL, MAT, R>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));
     attr_done = true;
   }
-  for (int pz = 0; pz < (DIM == 3 ? 2 : 1); ++pz)
-    for (int py = 0; py < 2; ++py) {
+  // ngl 3: one launch per class of x-lines (parity of y, z), its LDS sized for that class; ngl 2: every line is of one class
+  const int ncls = NGL == 3 ? 2 : 1;
+  for (int pz = 0; pz < (DIM == 3 ? ncls : 1); ++pz)
+    for (int py = 0; py < ncls; ++py) {
       T.par_y = py;
       T.par_z = pz;
-      const int ps = DIM == 3 ? pz : py;                        // parity along the slow axis
-      T.so0 = ((L.p_own0 & 1) == ps) ? 0 : 1;
-      const int nslow = T.so0 < L.n_own ? (L.n_own - T.so0 + 1) / 2 : 0;
-      T.nly = DIM == 3 ? (py == 0 ? L.EY + 1 : L.EY) : 1;
+      int nslow;
+      if (NGL == 3) {
+        const int ps = DIM == 3 ? pz : py;                      // parity along the slow axis
+        T.so0 = ((L.p_own0 & 1) == ps) ? 0 : 1;
+        nslow = T.so0 < L.n_own ? (L.n_own - T.so0 + 1) / 2 : 0;
+        T.nly = DIM == 3 ? (py == 0 ? L.EY + 1 : L.EY) : 1;
+      } else {
+        T.so0 = 0;
+        nslow = L.n_own;
+        T.nly = DIM == 3 ? L.NY : 1;
+      }
       const int64_t grid = (int64_t)T.nruns * T.nly * nslow;
       if (grid == 0) continue;
-      PYN_CHECK(grid < (int64_t)INT32_MAX, "ngl = 3 lattice assembly: %lld workgroups", (long long)grid);
-      const int n_y = py ? 3 : 5, n_z = DIM == 3 ? (pz ? 3 : 5) : 1;
-      T.img_len = (R / 2) * (5 + 3) * n_y * n_z * BR * BC;
+      PYN_CHECK(grid < (int64_t)INT32_MAX, "lattice row-run assembly: %lld workgroups", (long long)grid);
+      if (NGL == 3) {
+        const int n_y = py ? 3 : 5, n_z = DIM == 3 ? (pz ? 3 : 5) : 1;
+        T.img_len = ((R + 1) / 2) * (5 + 3) * n_y * n_z * BR * BC;
+      } else {
+        T.img_len = R * (DIM == 3 ? 27 : 9) * BR * BC;
+      }
       const size_t lds = (size_t)T.img_len * sizeof(double);
-      PYN_CHECK(lds <= 96 * 1024, "ngl = 3 lattice assembly: %zu B of LDS per run", lds);
-      assemble_ho3_lattice_kernel<DIM, MAT, R><<<(int)grid, 256, lds, c->stream>>>(T);
+      PYN_CHECK(lds <= 128 * 1024, "lattice row-run assembly: %zu B of LDS per run", lds);
+      assemble_ho3_lattice_kernel<DIM, NGL, MAT, R><<<(int)grid, 256, lds, c->stream>>>(T);
     }
   PYN_HIP(hipGetLastError());
   return PYN_OK;
 }
 
+// rows per run: tuned on 1024^2 / 64^3 (ngl 3); PYNAMA_HO3_RUN overrides (tests walk every length)
 template <int DIM, int MAT>
 int launch_ho3_r(pyn_ctx* c, const Ho3Args& T) {
   const char* e = getenv("PYNAMA_HO3_RUN");
   const int r = e ? atoi(e) : 0;
-  if (DIM == 3) {
-    if (r == 2) return launch_ho3<DIM, MAT, 2>(c, T);
-    if (r == 8) return launch_ho3<DIM, MAT, 8>(c, T);
-    return launch_ho3<DIM, MAT, 4>(c, T);
+  if (c->ho3.ngl == 2) {
+    if (DIM == 3) return launch_ho3<3, 2, MAT, 8>(c, T);
+    return launch_ho3<2, 2, MAT, 32>(c, T);
   }
-  if (r == 16) return launch_ho3<DIM, MAT, 16>(c, T);
-  if (r == 64) return launch_ho3<DIM, MAT, 64>(c, T);
-  return launch_ho3<DIM, MAT, 32>(c, T);
+  if (DIM == 3) {
+    if (MAT == M_OP) return launch_ho3<3, 3, MAT, 2>(c, T);      // up to 6 x 3 values per graph edge: two rows per run fill the LDS
+    if (r == 2) return launch_ho3<3, 3, MAT, 2>(c, T);
+    if (r == 8) return launch_ho3<3, 3, MAT, 8>(c, T);
+    return launch_ho3<3, 3, MAT, 4>(c, T);
+  }
+  if (MAT == M_OP) return launch_ho3<2, 3, MAT, 16>(c, T);
+  if (r == 16) return launch_ho3<2, 3, MAT, 16>(c, T);
+  if (r == 64) return launch_ho3<2, 3, MAT, 64>(c, T);
+  return launch_ho3<2, 3, MAT, 32>(c, T);
+}
+
+// geometry pre-pass (+ the once-per-mesh check that every cell is a parallelogram / parallelepiped); *ok = the closed forms apply
+int ho3_prepare(pyn_ctx* c, bool* ok) {
+  *ok = false;
+  Ho3Lattice& L = c->ho3;
+  hipStream_t s = c->stream;
+  const int gs = L.dim == 3 ? 10 : 6;
+  if (!L.d_geom) PYN_HIP(hipMalloc((void**)&L.d_geom, (size_t)c->n_elem * gs * sizeof(double)));
+  const int ge = (int)((c->n_elem + 255) / 256);
+  DevTmp flag;
+  int* d_flag = nullptr;
+  if (L.affine < 0) {   // once per mesh
+    PYN_HIP(flag.alloc(sizeof(int)));
+    PYN_HIP(hipMemsetAsync(flag.p, 0, sizeof(int), s));
+    d_flag = flag.as<int>();
+  }
+  // J^-1, detJ of every element (part of the numeric phase: runs inside the timed region of every assembly)
+  if (L.dim == 3)
+    ho3_geom_kernel<3><<<ge, 256, 0, s>>>(c->d_conn, c->d_xyz, c->n_elem, c->nn, c->quad[0].HrsCoo, L.d_geom, d_flag);
+  else
+    ho3_geom_kernel<2><<<ge, 256, 0, s>>>(c->d_conn, c->d_xyz, c->n_elem, c->nn, c->quad[0].HrsCoo, L.d_geom, d_flag);
+  PYN_HIP(hipGetLastError());
+  if (d_flag) {
+    int h = 1;
+    PYN_HIP(hipMemcpyAsync(&h, d_flag, sizeof(int), hipMemcpyDeviceToHost, s));
+    PYN_HIP(hipStreamSynchronize(s));
+    L.affine = h ? 0 : 1;
+  }
+  *ok = L.affine == 1 && !getenv("PYNAMA_NO_HO3_LATTICE");
+  return PYN_OK;
 }
 
 }  // namespace
@@ -597,27 +725,30 @@ void pyn_ho3_release(pyn_ctx* c) {
   L = Ho3Lattice();
 }
 
-// Is the connectivity that of a structured ngl = 3 mesh (the reference's box mesh, src/domain/dmplex.py:8-21, 42-61, or a rank's
-// slab of one)?  Host, once per pyn_mesh_set; every entry of `conn` is checked against the closed form the kernels use.
+// Is the connectivity that of a structured mesh of tensor-product cells of order 1 or 2 (ngl 2 / 3: the reference's box mesh,
+// src/domain/dmplex.py:8-21, 42-61, or a rank's slab of one)?  Host, once per pyn_mesh_set; every entry of `conn` is checked against
+// the closed form the kernels use.
 int pyn_ho3_detect(pyn_ctx* c, const int32_t* conn) {
   pyn_ho3_release(c);
   const int dim = c->dim, nn = c->nn;
-  if (!((dim == 2 && nn == 9) || (dim == 3 && nn == 27)) || c->n_elem < 1 || getenv("PYNAMA_NO_HO3")) return PYN_OK;
+  const int ngl = (nn == 9 || nn == 27) ? 3 : 2;
+  if (!((dim == 2 && (nn == 9 || nn == 4)) || (dim == 3 && (nn == 27 || nn == 8))) || c->n_elem < 1 || getenv("PYNAMA_NO_HO3")) return PYN_OK;
+  const int m = ngl - 1;
   int a_of[27];
-  for (int a = 0; a < nn; ++a) a_of[tens_of(dim, a)] = a;
+  for (int a = 0; a < nn; ++a) a_of[tens_of(dim, ngl, a)] = a;
   const int a0 = a_of[0];
   const int64_t ne = c->n_elem;
   int64_t EX = 1;
-  while (EX < ne && conn[EX * nn + a0] == conn[a0] + 2 * EX) ++EX;
+  while (EX < ne && conn[EX * nn + a0] == conn[a0] + m * EX) ++EX;
   if (ne % EX) return PYN_OK;
-  const int64_t NX = 2 * EX + 1;
+  const int64_t NX = m * EX + 1;
   int64_t EY, EZ = 0, NY = 0, PS, EL;   // EL: element layers along the slow axis
   if (dim == 3) {
     EY = 1;
-    while (EY * EX < ne && conn[EY * EX * nn + a0] == conn[a0] + 2 * EY * NX) ++EY;
+    while (EY * EX < ne && conn[EY * EX * nn + a0] == conn[a0] + m * EY * NX) ++EY;
     if ((ne / EX) % EY) return PYN_OK;
     EZ = ne / (EX * EY);
-    NY = 2 * EY + 1;
+    NY = m * EY + 1;
     PS = NX * NY;
     EL = EZ;
   } else {
@@ -625,16 +756,16 @@ int pyn_ho3_detect(pyn_ctx* c, const int32_t* conn) {
     PS = NX;
     EL = EY;
   }
-  const int64_t npl = 2 * EL + 1;
+  const int64_t npl = m * EL + 1;
   if (PS * npl != c->n_node || PS > INT32_MAX / 4) return PYN_OK;
   std::vector<int32_t> P((size_t)npl, -1);
   const int64_t per_layer = ne / EL;
+  const int stride_s = dim == 3 ? ngl * ngl : ngl;     // tensor stride of the slow axis
   for (int64_t l = 0; l < EL; ++l)
-    for (int j = 0; j < 3; ++j) {
-      const int t = dim == 3 ? j * 9 : j * 3;
-      const int32_t base = conn[l * per_layer * nn + a_of[t]];
-      if (P[2 * l + j] >= 0 && P[2 * l + j] != base) return PYN_OK;
-      P[2 * l + j] = base;
+    for (int j = 0; j < ngl; ++j) {
+      const int32_t base = conn[l * per_layer * nn + a_of[j * stride_s]];
+      if (P[m * l + j] >= 0 && P[m * l + j] != base) return PYN_OK;
+      P[m * l + j] = base;
     }
   for (int64_t e = 0; e < ne; ++e) {
     const int64_t ex = e % EX, ey = dim == 3 ? (e / EX) % EY : 0, el = e / per_layer;
@@ -642,9 +773,9 @@ int pyn_ho3_detect(pyn_ctx* c, const int32_t* conn) {
     for (int a = 0; a < nn; ++a) {
       int64_t id;
       if (dim == 3)
-        id = (int64_t)P[2 * el + LOC3[a][2]] + (2 * ey + LOC3[a][1]) * NX + 2 * ex + LOC3[a][0];
+        id = (int64_t)P[m * el + loc_of(3, ngl, a, 2)] + (m * ey + loc_of(3, ngl, a, 1)) * NX + m * ex + loc_of(3, ngl, a, 0);
       else
-        id = (int64_t)P[2 * el + LOC2[a][1]] + 2 * ex + LOC2[a][0];
+        id = (int64_t)P[m * el + loc_of(2, ngl, a, 1)] + m * ex + loc_of(2, ngl, a, 0);
       if (q[a] != id) return PYN_OK;
     }
   }
@@ -665,6 +796,7 @@ int pyn_ho3_detect(pyn_ctx* c, const int32_t* conn) {
   PYN_HIP(hipMemcpy(L.d_P, P.data(), npl * sizeof(int32_t), hipMemcpyHostToDevice));
   L.P = P;
   L.dim = dim;
+  L.ngl = ngl;
   L.EX = (int)EX;
   L.EY = (int)EY;
   L.EZ = (int)EZ;
@@ -677,24 +809,26 @@ int pyn_ho3_detect(pyn_ctx* c, const int32_t* conn) {
   return PYN_OK;
 }
 
-// Reference matrices of the ngl = 3 element from one uploaded rule (pyn_elem_tables_set), in tensor order
+// Reference matrices of the element from one uploaded rule (pyn_elem_tables_set), in tensor order:
+// [Tf | Tr][r][s][a][b] = sum_g w Hrs_r[a] Hrs_s[b] (full | reduced), [Uf | Ur | Un][r][a][b] = sum_g w H[a] Hrs_r[b] (full | reduced | nodal)
 int pyn_ho3_tables(pyn_ctx* c, int which, int ngp, const double* w, const double* H, const double* Hrs) {
   const int dim = c->dim, nn = c->nn;
-  if (which != PYN_Q_FULL && which != PYN_Q_RED) return PYN_OK;
-  if (!((dim == 2 && nn == 9) || (dim == 3 && nn == 27))) return PYN_OK;
+  if (which < 0 || which > 2) return PYN_OK;
+  if (!((dim == 2 && (nn == 9 || nn == 4)) || (dim == 3 && (nn == 27 || nn == 8)))) return PYN_OK;
+  const int ngl = (nn == 9 || nn == 27) ? 3 : 2;
   const int dd = dim * dim, n2 = nn * nn;
-  const size_t total = (size_t)(2 * dd + 2 * dim) * n2;
+  const size_t total = (size_t)(2 * dd + 3 * dim) * n2;
   if (c->ho3_tabs_nn != nn) {
     (void)hipFree(c->d_ho3_tabs);
     c->d_ho3_tabs = nullptr;
-    c->ho3_tabs_ok[0] = c->ho3_tabs_ok[1] = false;
+    c->ho3_tabs_ok[0] = c->ho3_tabs_ok[1] = c->ho3_tabs_ok[2] = false;
     PYN_HIP(hipMalloc((void**)&c->d_ho3_tabs, total * sizeof(double)));
     c->ho3_tabs_nn = nn;
   }
   std::vector<double> T((size_t)dd * n2), U((size_t)dim * n2);
   for (int a = 0; a < nn; ++a)
     for (int b = 0; b < nn; ++b) {
-      const int ta = tens_of(dim, a), tb = tens_of(dim, b);
+      const int ta = tens_of(dim, ngl, a), tb = tens_of(dim, ngl, b);
       for (int r = 0; r < dim; ++r) {
         for (int s = 0; s < dim; ++s) {
           double acc = 0.0;
@@ -706,9 +840,11 @@ int pyn_ho3_tables(pyn_ctx* c, int which, int ngp, const double* w, const double
         U[(size_t)r * n2 + ta * nn + tb] = acc;
       }
     }
-  const size_t offT = which == PYN_Q_FULL ? 0 : (size_t)dd * n2;
-  const size_t offU = (size_t)2 * dd * n2 + (which == PYN_Q_FULL ? 0 : (size_t)dim * n2);
-  PYN_HIP(hipMemcpyAsync(c->d_ho3_tabs + offT, T.data(), T.size() * sizeof(double), hipMemcpyHostToDevice, c->stream));
+  if (which != PYN_Q_NODAL) {
+    const size_t offT = which == PYN_Q_FULL ? 0 : (size_t)dd * n2;
+    PYN_HIP(hipMemcpyAsync(c->d_ho3_tabs + offT, T.data(), T.size() * sizeof(double), hipMemcpyHostToDevice, c->stream));
+  }
+  const size_t offU = (size_t)2 * dd * n2 + (size_t)which * dim * n2;
   PYN_HIP(hipMemcpyAsync(c->d_ho3_tabs + offU, U.data(), U.size() * sizeof(double), hipMemcpyHostToDevice, c->stream));
   PYN_HIP(hipStreamSynchronize(c->stream));
   c->ho3_tabs_ok[which] = true;
@@ -732,9 +868,10 @@ int pyn_ho3_symbolic(pyn_ctx* c, bool* done) {
   c->nnzb = 0;
   PYN_HIP(hipMalloc((void**)&c->d_rowptr, (n + 1) * sizeof(int32_t)));
   const int grid = (int)((n + 1 + 255) / 256);
-  ho3_rowlen_kernel<<<grid, 256, 0, s>>>(T, L.dim, n, tlen.as<int32_t>());
+  ho3_rowlen_kernel<<<grid, 256, 0, s>>>(T, L.dim, L.ngl, n, tlen.as<int32_t>());
   // the total must fit the int32 CSR before the scan wraps: the interior count bounds it
-  const double est = (double)c->n_elem * (L.dim == 3 ? 512.0 : 64.0);
+  const double per_elem = L.ngl == 3 ? (L.dim == 3 ? 512.0 : 64.0) : (L.dim == 3 ? 27.0 : 9.0);
+  const double est = (double)c->n_elem * per_elem;
   PYN_CHECK(est < 2.0e9, "pattern has about %.3g entries (int32 CSR limit)", est);
   size_t tb = 0;
   PYN_HIP(hipcub::DeviceScan::ExclusiveSum(nullptr, tb, tlen.as<int32_t>(), c->d_rowptr, (int)(n + 1), s));
@@ -745,45 +882,27 @@ int pyn_ho3_symbolic(pyn_ctx* c, bool* done) {
   PYN_HIP(hipStreamSynchronize(s));
   PYN_CHECK(nnz > 0, "empty pattern");
   PYN_HIP(hipMalloc((void**)&c->d_colidx, (size_t)nnz * sizeof(int32_t)));
-  ho3_columns_kernel<<<(int)((n + 255) / 256), 256, 0, s>>>(T, L.dim, n, c->d_rowptr, c->d_colidx);
+  ho3_columns_kernel<<<(int)((n + 255) / 256), 256, 0, s>>>(T, L.dim, L.ngl, n, c->d_rowptr, c->d_colidx);
   PYN_HIP(hipGetLastError());
   c->nnzb = nnz;
   *done = true;
   return PYN_OK;
 }
 
-// K (+ Krhs), Rw of pyn_assemble_kle and the scalar Laplacian of pyn_assemble_scalar on a structured ngl = 3 mesh of
-// parallelograms / parallelepipeds.  *handled stays false when the mesh or the tables do not fit (the caller falls back).
+// K (+ Krhs), Rw of pyn_assemble_kle and the scalar Laplacian of pyn_assemble_scalar on a structured mesh of parallelograms /
+// parallelepipeds: second-order cells (ngl 3) in 2-D and 3-D, first-order quadrilaterals (3-D first-order cells have kernels of their
+// own, pyn_assemble_lattice.hip).  *handled stays false when the mesh or the tables do not fit (the caller falls back).
 int pyn_assemble_ho3_lattice(pyn_ctx* c, int form, double alpha_d, double alpha_w, double* K, double* Krhs, double* Rw, bool* handled) {
   *handled = false;
   Ho3Lattice& L = c->ho3;
   if (!L.valid || c->ho3_tabs_nn != c->nn || !c->ho3_tabs_ok[0] || c->quad[0].ngp < 1) return PYN_OK;
+  if (L.ngl == 2 && L.dim == 3) return PYN_OK;
   if (form == PYN_FORM_KLE && !c->ho3_tabs_ok[1]) return PYN_OK;
   if (form != PYN_FORM_KLE && form != PYN_FORM_LAPLACE) return PYN_OK;
   hipStream_t s = c->stream;
-  const int gs = L.dim == 3 ? 10 : 6;
-  if (!L.d_geom) PYN_HIP(hipMalloc((void**)&L.d_geom, (size_t)c->n_elem * gs * sizeof(double)));
-  const int ge = (int)((c->n_elem + 255) / 256);
-  DevTmp flag;
-  int* d_flag = nullptr;
-  if (L.affine < 0) {   // once per mesh
-    PYN_HIP(flag.alloc(sizeof(int)));
-    PYN_HIP(hipMemsetAsync(flag.p, 0, sizeof(int), s));
-    d_flag = flag.as<int>();
-  }
-  // J^-1, detJ of every element (part of the numeric phase: runs inside the timed region of every assembly)
-  if (L.dim == 3)
-    ho3_geom_kernel<3><<<ge, 256, 0, s>>>(c->d_conn, c->d_xyz, c->n_elem, c->quad[0].HrsCoo, L.d_geom, d_flag);
-  else
-    ho3_geom_kernel<2><<<ge, 256, 0, s>>>(c->d_conn, c->d_xyz, c->n_elem, c->quad[0].HrsCoo, L.d_geom, d_flag);
-  PYN_HIP(hipGetLastError());
-  if (d_flag) {
-    int h = 1;
-    PYN_HIP(hipMemcpyAsync(&h, d_flag, sizeof(int), hipMemcpyDeviceToHost, s));
-    PYN_HIP(hipStreamSynchronize(s));
-    L.affine = h ? 0 : 1;
-  }
-  if (!L.affine || getenv("PYNAMA_NO_HO3_LATTICE")) return PYN_OK;
+  bool ok = false;
+  PYN_TRY(ho3_prepare(c, &ok));
+  if (!ok) return PYN_OK;
   Ho3Args T;
   fill_lattice_args(c, T);
   if (c->d_bcmask) {
@@ -829,6 +948,38 @@ int pyn_assemble_ho3_lattice(pyn_ctx* c, int form, double alpha_d, double alpha_
     else
       PYN_TRY((launch_ho3_r<2, M_RW>(c, T)));
   }
+  *handled = true;
+  return PYN_OK;
+}
+
+// The first-order operators SrT / DivSrT / Curl (pyn_assemble_operator at the nodal rule) on any structured mesh the row-run kernels
+// know: ngl 2 / 3, 2-D / 3-D, parallelograms / parallelepipeds.
+int pyn_assemble_ho3_operator(pyn_ctx* c, int rule, int br, int bc, int nterms, const int32_t* terms, const double* coef, double* M,
+                              bool* handled) {
+  *handled = false;
+  Ho3Lattice& L = c->ho3;
+  if (!L.valid || rule != PYN_Q_NODAL || c->ho3_tabs_nn != c->nn || !c->ho3_tabs_ok[2] || c->quad[0].ngp < 1 || nterms > MAX_TERMS ||
+      getenv("PYNAMA_NO_HO3_OPERATOR"))
+    return PYN_OK;
+  bool ok = false;
+  PYN_TRY(ho3_prepare(c, &ok));
+  if (!ok) return PYN_OK;
+  Ho3Args T;
+  fill_lattice_args(c, T);
+  T.A = M;
+  T.obr = br;
+  T.obc = bc;
+  T.nterms = nterms;
+  for (int t = 0; t < nterms; ++t) {
+    T.t_row[t] = terms[3 * t];
+    T.t_col[t] = terms[3 * t + 1];
+    T.t_der[t] = terms[3 * t + 2];
+    T.t_coef[t] = coef[t];
+  }
+  if (L.dim == 3)
+    PYN_TRY((launch_ho3_r<3, M_OP>(c, T)));
+  else
+    PYN_TRY((launch_ho3_r<2, M_OP>(c, T)));
   *handled = true;
   return PYN_OK;
 }

@@ -571,8 +571,9 @@ extern "C" int pyn_mesh_set(pyn_ctx* c, int dim, int nn, int64_t n_elem, int64_t
 
 extern "C" int pyn_mesh_topology(pyn_ctx* c, int* kind, int* nx, int* ny, int* nz) {
   PYN_CHECK(c && c->n_elem > 0, "pyn_mesh_set first");
-  if (c->ho3.valid) {   // second-order lattice: nodes per x-line, x-lines per plane, planes (2-D: ny = x-lines, nz = 1)
-    if (kind) *kind = 2;
+  if (c->ho3.valid && (c->ho3.ngl == 3 || c->ho3.dim == 2)) {   // second-order lattice (kind 2) / first-order quadrilaterals (kind 3):
+                                                                // nodes per x-line, x-lines per plane, planes (2-D: ny = x-lines, nz = 1)
+    if (kind) *kind = c->ho3.ngl == 3 ? 2 : 3;
     if (nx) *nx = c->ho3.NX;
     if (ny) *ny = c->ho3.dim == 3 ? c->ho3.NY : c->ho3.npl;
     if (nz) *nz = c->ho3.dim == 3 ? c->ho3.npl : 1;

@@ -145,7 +145,7 @@ struct Lattice {
 // ids are P[j], so that a rank's slab with its ghost planes fits the same arithmetic: id = P[c_slow] + c_y NX + c_x (3-D).
 struct Ho3Lattice {
   bool valid = false;
-  int dim = 0;
+  int dim = 0, ngl = 0;         // ngl 3 (second order) or 2 (first order: the row-run kernels serve 2-D Q1 cells and the operators there)
   int EX = 0, EY = 0, EZ = 0;   // local elements per axis (2-D: EY = local element rows, EZ = 0)
   int NX = 0, NY = 0;           // nodes per x-line; x-lines per plane (3-D)
   int npl = 0, p_own0 = 0, n_own = 0;   // planes of the local mesh, owned ones = [p_own0, p_own0 + n_own) with ids 0 .. n_owned-1
@@ -235,7 +235,7 @@ struct pyn_ctx {
   // reference matrices of the ngl = 3 element in tensor (lattice) order, from the uploaded tables (pyn_elem_tables_set):
   // Tf / Tr[r][s][a][b] = sum_g w Hrs_r[a] Hrs_s[b] (full / reduced rule), Uf / Ur[r][a][b] = sum_g w H[a] Hrs_r[b]
   double* d_ho3_tabs = nullptr;
-  bool ho3_tabs_ok[2] = {false, false};
+  bool ho3_tabs_ok[3] = {false, false, false};   // full, reduced, nodal rule
   int ho3_tabs_nn = 0;
 
   // SELL-64 structures, one per block shape, + the node-level column-pattern dictionary (pyn_sell.hip)
@@ -326,3 +326,4 @@ void pyn_ho3_release(pyn_ctx* c);
 int pyn_ho3_tables(pyn_ctx* c, int which, int ngp, const double* w, const double* H, const double* Hrs);
 int pyn_ho3_symbolic(pyn_ctx* c, bool* done);
 int pyn_assemble_ho3_lattice(pyn_ctx* c, int form, double alpha_d, double alpha_w, double* K, double* Krhs, double* Rw, bool* handled);
+int pyn_assemble_ho3_operator(pyn_ctx* c, int rule, int br, int bc, int nterms, const int32_t* terms, const double* coef, double* M, bool* handled);

@@ -358,8 +358,10 @@ class DMPlexDom(object):
         eidx[-1] += k0
         base = sum(eidx[d] * m * self.strides[d] for d in range(dim))
         off = sum(loc[:, d] * self.strides[d] for d in range(dim))
-        conn_global = base[:, None] + off[None, :]
-        self.conn = self._global2local(conn_global).astype(np.int32)
+        if self.comm.size == 1 and self.nNodesGlobal < 2 ** 31:      # one rank: local == lattice ids, built in int32 at once
+            self.conn = base.astype(np.int32)[:, None] + off.astype(np.int32)[None, :]
+        else:
+            self.conn = self._global2local(base[:, None] + off[None, :]).astype(np.int32)
         # coordinates of the local nodes (GLL spaced inside each element)
         self.xyz = self._lattice_coordinates()
         # ---- device: created lazily (first use of .ctx) so that the host logic runs without a GPU
@@ -488,6 +490,8 @@ class DMPlexDom(object):
                 gh = (~own) & (self._ghost_gids[pos] == g)
                 out[gh] = self.nOwned + pos[gh]
             return out
+        if self.comm.size == 1:          # one rank: local ids ARE the lattice ids
+            return g
         plane = self.strides[-1]
         a, b = self.part.owned(self.comm.rank)
         lo, hi = self._ghost_lo[0], self._ghost_hi[1]
@@ -509,6 +513,8 @@ class DMPlexDom(object):
             gh = l >= self.nOwned
             out[gh] = self._ghost_gids[l[gh] - self.nOwned]
             return out
+        if self.comm.size == 1:
+            return l
         plane = self.strides[-1]
         a, b = self.part.owned(self.comm.rank)
         lo = self._ghost_lo[0]

@@ -359,3 +359,86 @@ def test_block_csr_product(lib, nelem, lanes):
     finally:
         os.environ.pop("PYNAMA_BCSR_LANES", None)
     ctx.close()
+
+
+# ---- the same row-run kernels on first-order lattices and for the first-order operators -----------------------------------------------
+@pytest.mark.parametrize("nelem", [[9, 7], [70, 3], [1, 1], [33, 40]])
+def test_q1_quadrilaterals_take_the_row_run_kernels(lib, nelem):
+    """2-D Q1 box meshes (the reference's `ngl: 2` runs, BASELINE configs[0]): closed-form graph, K, Krhs (compact and full), Rw and the
+    scalar Laplacian by the row-run kernels == oracle == generic kernel"""
+    from pynama_amd.elements.spectral import Spectral
+    mesh = fo.box_mesh(nelem, [0.0, 0.0], [1.0, 0.7], 2)
+    mask = boundary_mask(mesh)
+    ctx = lib.Context(0)
+    ctx.mesh_set(2, mesh.conn, mesh.xyz)
+    for t in Spectral(2, 2).deviceTables():
+        ctx.tables_set(*t)
+    ctx.bc_set(2, mask)
+    ctx.csr_symbolic()
+    assert ctx.mesh_topology() == ("lattice-q1-2d", nelem[0] + 1, nelem[1] + 1, 1)
+    rp, ci = ctx.csr_get()
+    rp_o, ci_o = fo.node_graph(mesh)
+    assert np.array_equal(rp, rp_o) and np.array_equal(ci, ci_o)
+    K, Kr, Krc, Rw = ctx.mat_create(2, 2), ctx.mat_create(2, 2), ctx.mat_create_rhs(2, 2), ctx.mat_create(2, 1)
+    os.environ["PYNAMA_HO3_REQUIRE"] = "1"
+    try:
+        ctx.assemble_kle(1e3, 1e2, K, Kr, Rw, -1)
+        ctx.assemble_kle(1e3, 1e2, K, Krc, -1, -1)
+    finally:
+        del os.environ["PYNAMA_HO3_REQUIRE"]
+    ref = fo.assemble_kle_freeslip(mesh, fo.Tables(2, 2))
+    assert sp_rel_err(mat_to_scipy(ctx, K, 2, 2), ref["K"]) < FP_TOL
+    assert sp_rel_err(mat_to_scipy(ctx, Kr, 2, 2), ref["Krhs"]) < FP_TOL
+    assert sp_rel_err(mat_to_scipy(ctx, Krc, 2, 2), ref["Krhs"]) < FP_TOL
+    assert sp_rel_err(mat_to_scipy(ctx, Rw, 2, 1), ref["Rw"]) < FP_TOL
+    K0 = ctx.mat_create(2, 2)
+    ctx.assemble_kle(1e3, 1e2, K0, -1, -1, -1, variant=0)
+    assert rel_err(ctx.mat_values(K, 2, 2), ctx.mat_values(K0, 2, 2)) < FP_TOL
+    ctx.bc_set(1, mask[:, 0].copy())
+    A, Ar = ctx.mat_create(1, 1), ctx.mat_create(1, 1)
+    ctx.assemble_scalar(lib.FORM_LAPLACE, A, Ar)
+    refs = fo.assemble_scalar(mesh, fo.Tables(2, 2), "laplace", dirichlet=mesh.boundary)
+    assert sp_rel_err(mat_to_scipy(ctx, A, 1, 1), refs["A"]) < FP_TOL
+    assert sp_rel_err(mat_to_scipy(ctx, Ar, 1, 1), refs["Arhs"]) < FP_TOL
+    ctx.close()
+
+
+@pytest.mark.parametrize("nelem,ngl", [([9, 7], 2), ([6, 5, 4], 2), ([9, 7], 3), ([3, 2, 3], 3), ([1, 1], 3), ([1, 1, 1], 2), ([40, 3], 3)])
+def test_operators_on_lattices(lib, nelem, ngl):
+    """SrT / DivSrT / Curl of Spectral.getElemKLEOperators + Operators.setValues (spectral.py:159-218, mat_generator.py:157-190) by the
+    row-run kernels on a sheared box (full J^-1): == oracle (after the lumped-weight row scaling) == generic kernel entry by entry"""
+    from pynama_amd.elements.spectral import Spectral
+    dim = len(nelem)
+    mesh = fo.box_mesh(nelem, [0.0] * dim, [1.0, 0.8, 1.2][:dim], ngl)
+    Aff = np.eye(dim) + 0.2 * np.random.default_rng(8).standard_normal((dim, dim))
+    assert np.linalg.det(Aff) > 0
+    mesh.xyz = mesh.xyz @ Aff.T
+    ref = fo.assemble_operators(mesh, fo.Tables(ngl, dim))
+    ctx = lib.Context(0)
+    ctx.mesh_set(dim, mesh.conn, mesh.xyz)
+    sp = Spectral(ngl, dim)
+    for t in sp.deviceTables():
+        ctx.tables_set(*t)
+    ctx.csr_symbolic()
+    ops = sp.operatorTerms()
+    mass = ctx.mat_create(1, 1)
+    ctx.assemble_scalar(lib.FORM_MASS_NODAL, mass, -1, 0)
+    vw = ctx.vec_create(1)
+    ctx.mat_diagonal(mass, vw)
+    w = ctx.vec_get(vw, 1)
+    for name in ("SrT", "DivSrT", "Curl"):
+        br, bc, terms, coef = ops[name]
+        m, m0 = ctx.mat_create(br, bc), ctx.mat_create(br, bc)
+        ctx.assemble_operator(lib.Q_NODAL, terms, coef, m)
+        t_fast = ctx.timers()["assemble_ms"]
+        os.environ["PYNAMA_NO_HO3_OPERATOR"] = "1"
+        try:
+            ctx.assemble_operator(lib.Q_NODAL, terms, coef, m0)
+        finally:
+            del os.environ["PYNAMA_NO_HO3_OPERATOR"]
+        assert rel_err(ctx.mat_values(m, br, bc), ctx.mat_values(m0, br, bc)) < FP_TOL, (name, t_fast)
+        vs = ctx.vec_create(br)
+        ctx.vec_set(vs, np.repeat(1.0 / w, br))
+        ctx.mat_row_scale(m, vs)
+        assert sp_rel_err(mat_to_scipy(ctx, m, br, bc), ref[name]) < FP_TOL, name
+    ctx.close()
