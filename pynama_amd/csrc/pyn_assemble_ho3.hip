@@ -29,6 +29,7 @@
 #include <hipcub/hipcub.hpp>
 
 #include <algorithm>
+#include <cmath>
 
 #include "pyn_internal.h"
 
@@ -64,6 +65,7 @@ struct Ho3Args {
   const uint8_t* nbits;   // per local node: bit p = DOF p imposed; null = nothing imposed
   const double* geom;     // [n_elem][GS]
   const double* tabs;
+  const double* tabs1d;   // [8][NGL][NGL] 1-D factors (Mf Df Sf Mr Dr Sr Mn Dn) when the records are verified tensor products, else null
   double alpha_d, alpha_w;
   double* A;
   double* Arhs;
@@ -73,6 +75,7 @@ struct Ho3Args {
   int nruns, nly;         // runs per x-line, lines of this class per plane (3-D)
   int so0;                // first owned plane (3-D) / line (2-D), as an owned index, whose local index has the parity of the class
   int img_len;            // doubles of LDS behind the kernel
+  int ablate;             // diagnostics (PYNAMA_HO3_ABLATE): 1 no unit loop (zero + copy out only), 2 no copy out, 4 no LDS adds
   int step;               // distance (owned index) between two lines of a class along the slow axis: 2 (ngl 3), 1 (ngl 2)
   // first-order operator form (M_OP): block shape and the (row component, column component, derivative axis, coefficient) terms
   int obr, obc, nterms;
@@ -200,11 +203,91 @@ __global__ void ho3_pack_bits_kernel(const uint8_t* __restrict__ mask, int64_t n
   bits[i] = (uint8_t)m;
 }
 
-// one block of the element matrix of element `g` (J^-1, detJ) for the local node pair (a, b) in tensor order; NN = nodes per element
-template <int DIM, int NN, int MAT>
-__device__ __forceinline__ void ho3_block(const double* __restrict__ g, const double* __restrict__ tabs, int a, int b, double alpha_d,
-                                          double alpha_w, double (&v)[3][3]) {
-  constexpr int N2 = NN * NN, DD = DIM * DIM;
+// Reference matrices, one contiguous RECORD per node pair (a, b) in tensor order (TS doubles, 16-byte aligned):
+//   [0, DD)           Tf_rs[a][b] = sum_g w Hrs_r[a] Hrs_s[b]   (full rule)
+//   [DD, 2 DD)        Tr_rs[a][b]                                (reduced rule)
+//   [2 DD, +DIM)      Uf_x[a][b]  = sum_g w H[a] Hrs_x[b]        (full rule)
+//   [.., +DIM)        Ur_x[b][a]                                 (reduced rule, transposed: what Rw's (a, b) block reads)
+//   [.., +DIM)        Un_x[a][b]                                 (nodal rule: the first-order operators)
+// A lane reads its pair's record with one base address and immediate offsets (vector loads), lanes of a group (consecutive b) read
+// consecutive records.
+template <int DIM>
+struct TabRec {
+  static constexpr int DD = DIM * DIM;
+  static constexpr int TS = (2 * DD + 3 * DIM + 1) & ~1;
+  static constexpr int TF = 0, TR = DD, UF = 2 * DD, URT = 2 * DD + DIM, UN = 2 * DD + 2 * DIM;
+};
+
+// The record of node pair (a, b) rebuilt from the 1-D factors of a tensor-product element (LDS, no global load in the unit loop):
+// with m_d = M[a_d][b_d], dab_d = D[a_d][b_d] = sum w h'_a h_b, dba_d = D[b_d][a_d], s_d = S[a_d][b_d] per axis d,
+//   T_rs = prod_d ( d == r == s ? s_d : d == r ? dab_d : d == s ? dba_d : m_d ),   U_x[a][b] = dba_x prod_{d != x} m_d,
+//   U_x[b][a] = dab_x prod_{d != x} m_d (M symmetric)
+template <int DIM, int NGL, int MAT>
+__device__ __forceinline__ void ho3_record_1d(const double* __restrict__ t1, const int (&la)[3], const int (&lb)[3], double* __restrict__ rec) {
+  using TR_ = TabRec<DIM>;
+  constexpr int N1 = NGL * NGL;
+  auto fac = [&](int tab, int d, bool tr) { return t1[tab * N1 + (tr ? lb[d] * NGL + la[d] : la[d] * NGL + lb[d])]; };
+  if (MAT == M_K || MAT == M_LAP) {
+#pragma unroll
+    for (int rule = 0; rule < (MAT == M_K ? 2 : 1); ++rule) {
+      double m[DIM], dab[DIM], dba[DIM], sd[DIM];
+#pragma unroll
+      for (int d = 0; d < DIM; ++d) {
+        m[d] = fac(3 * rule + 0, d, false);
+        dab[d] = fac(3 * rule + 1, d, false);
+        dba[d] = fac(3 * rule + 1, d, true);
+        sd[d] = fac(3 * rule + 2, d, false);
+      }
+#pragma unroll
+      for (int r = 0; r < DIM; ++r)
+#pragma unroll
+        for (int s2 = 0; s2 < DIM; ++s2) {
+          double p = 1.0;
+#pragma unroll
+          for (int d = 0; d < DIM; ++d) p *= (d == r && d == s2) ? sd[d] : (d == r ? dab[d] : (d == s2 ? dba[d] : m[d]));
+          rec[(rule == 0 ? TR_::TF : TR_::TR) + r * DIM + s2] = p;
+        }
+    }
+  } else if (MAT == M_RW) {
+    double mf[DIM], mr[DIM];
+#pragma unroll
+    for (int d = 0; d < DIM; ++d) {
+      mf[d] = fac(0, d, false);
+      mr[d] = fac(3, d, false);
+    }
+#pragma unroll
+    for (int x = 0; x < DIM; ++x) {
+      double pf = fac(1, x, true), pr = fac(4, x, false);
+#pragma unroll
+      for (int d = 0; d < DIM; ++d)
+        if (d != x) {
+          pf *= mf[d];
+          pr *= mr[d];
+        }
+      rec[TR_::UF + x] = pf;
+      rec[TR_::URT + x] = pr;
+    }
+  } else {
+    double mn[DIM];
+#pragma unroll
+    for (int d = 0; d < DIM; ++d) mn[d] = fac(6, d, false);
+#pragma unroll
+    for (int x = 0; x < DIM; ++x) {
+      double pn = fac(7, x, true);
+#pragma unroll
+      for (int d = 0; d < DIM; ++d)
+        if (d != x) pn *= mn[d];
+      rec[TR_::UN + x] = pn;
+    }
+  }
+}
+
+// one block of the element matrix of element `g` (J^-1, detJ) for the node pair whose table record is `tb`
+template <int DIM, int MAT>
+__device__ __forceinline__ void ho3_block(const double* __restrict__ g, const double* __restrict__ tb, double alpha_d, double alpha_w,
+                                          double (&v)[3][3]) {
+  using TR_ = TabRec<DIM>;
+  constexpr int DD = DIM * DIM;
   double Ji[DIM][DIM];
 #pragma unroll
   for (int x = 0; x < DIM; ++x)
@@ -215,11 +298,10 @@ __device__ __forceinline__ void ho3_block(const double* __restrict__ g, const do
   for (int p = 0; p < 3; ++p)
 #pragma unroll
     for (int q = 0; q < 3; ++q) v[p][q] = 0.0;
-  const int ab = a * NN + b;
   if (MAT == M_OP) {   // v[0][d] = detJ sum_x Ji[d][x] Un_x[a][b]: H_a grad_d N_b at the nodal rule; the caller places the terms
     double un[DIM];
 #pragma unroll
-    for (int x = 0; x < DIM; ++x) un[x] = tabs[(2 * DD + 2 * DIM + x) * N2 + ab];
+    for (int x = 0; x < DIM; ++x) un[x] = tb[TR_::UN + x];
 #pragma unroll
     for (int d = 0; d < DIM; ++d) {
       double s0 = 0.0;
@@ -234,7 +316,7 @@ __device__ __forceinline__ void ho3_block(const double* __restrict__ g, const do
 #pragma unroll
     for (int r = 0; r < DIM; ++r)
 #pragma unroll
-      for (int s = 0; s < DIM; ++s) tf[r][s] = tabs[(r * DIM + s) * N2 + ab];
+      for (int s = 0; s < DIM; ++s) tf[r][s] = tb[TR_::TF + r * DIM + s];
     double lap = 0.0;   // sum_rs Q_rs Tf_rs, Q = Ji^T Ji
 #pragma unroll
     for (int x = 0; x < DIM; ++x)
@@ -253,7 +335,7 @@ __device__ __forceinline__ void ho3_block(const double* __restrict__ g, const do
 #pragma unroll
     for (int r = 0; r < DIM; ++r)
 #pragma unroll
-      for (int s = 0; s < DIM; ++s) tr[r][s] = tabs[(DD + r * DIM + s) * N2 + ab];
+      for (int s = 0; s < DIM; ++s) tr[r][s] = tb[TR_::TR + r * DIM + s];
     double X[DIM][DIM], Y[DIM][DIM];
 #pragma unroll
     for (int p = 0; p < DIM; ++p)
@@ -283,12 +365,11 @@ __device__ __forceinline__ void ho3_block(const double* __restrict__ g, const do
   } else {
     // Rw: gU[d] = sum_x Ji[d][x] Uf_x[a][b] (H_a grad_d N_b, full rule), gR[d] = sum_x Ji[d][x] Ur_x[b][a] (grad_d N_a H_b, reduced rule)
     double gU[DIM], gR[DIM];
-    const int ba = b * NN + a;
     double uf[DIM], ur[DIM];
 #pragma unroll
     for (int x = 0; x < DIM; ++x) {
-      uf[x] = tabs[(2 * DD + x) * N2 + ab];
-      ur[x] = tabs[(2 * DD + DIM + x) * N2 + ba];
+      uf[x] = tb[TR_::UF + x];
+      ur[x] = tb[TR_::URT + x];
     }
 #pragma unroll
     for (int d = 0; d < DIM; ++d) {
@@ -340,7 +421,14 @@ __global__ void __launch_bounds__(256) assemble_ho3_lattice_kernel(Ho3Args T) {
   __shared__ int rowoff[R + 1];
   __shared__ int srank[5], splane[5];   // slow axis: sorted position of neighbour plane j, and its inverse
   __shared__ unsigned char nb[BXW * BYW * BZW];
+  __shared__ double t1d[8 * NGL * NGL];
+  // J^-1, detJ of the elements the run touches, requested in the prologue with the row offsets (one memory latency for both): the
+  // triple loop then makes no global load at all when the table records come from the 1-D factors
+  constexpr int GEX = NGL == 3 ? R / 2 + 1 : R + 1, GEL = GEX * (DIM == 3 ? 4 : 2);
+  __shared__ double gl[GEL * GS];
   const int tid = threadIdx.x;
+  const bool tens = T.tabs1d != nullptr;
+  if (tens && tid < 8 * NGL * NGL) t1d[tid] = T.tabs1d[tid];
   int bid = blockIdx.x;
   const int run = bid % T.nruns;
   bid /= T.nruns;
@@ -386,17 +474,33 @@ __global__ void __launch_bounds__(256) assemble_ho3_lattice_kernel(Ho3Args T) {
       any |= m;
     }
   }
+  const int ny_e = (NGL == 2 || !(cy & 1)) ? 2 : 1, nz_e = DIM == 3 ? ((NGL == 2 || !(cz & 1)) ? 2 : 1) : 1;
+  const int ex0 = NGL == 3 ? (x0 >> 1) - 1 : x0 - 1;             // first element column the run can touch
+  for (int i = tid; i < GEX * ny_e * nz_e * GS && !(T.ablate & 1); i += 256) {
+    const int ge = i / GS, w = i - ge * GS;
+    const int gx = ge % GEX, gyz = ge / GEX, ys = gyz % ny_e, zs = gyz / ny_e;
+    const int ex = ex0 + gx;
+    const int ey = NGL == 2 ? cy - 1 + ys : ((cy & 1) ? (cy >> 1) : (cy >> 1) - 1 + ys);
+    const int ez = DIM == 3 ? (NGL == 2 ? cz - 1 + zs : ((cz & 1) ? (cz >> 1) : (cz >> 1) - 1 + zs)) : 0;
+    double v = 0.0;
+    if (ex >= 0 && ex < T.EX && ey >= 0 && ey < T.EY && (DIM == 2 || (ez >= 0 && ez < T.EZ)))
+      v = T.geom[(ex + (int64_t)T.EX * (ey + (int64_t)T.EY * ez)) * GS + w];
+    gl[i] = v;
+  }
   for (int i = tid; i < T.img_len; i += 256) img[i] = 0.0;
   const int routed = __syncthreads_or(any);
 
   // ---- the (row, element, column node) triples of the run.  ngl 3: rows alternate vertex-like (two elements along x) / mid-node
   //      (one), enumerated per row pair with three x-slots; ngl 2: every row has two elements along x
-  const int ny_e = (NGL == 2 || !(cy & 1)) ? 2 : 1, nz_e = DIM == 3 ? ((NGL == 2 || !(cz & 1)) ? 2 : 1) : 1;
   const int nyz = ny_e * nz_e, sh = nyz == 4 ? 2 : (nyz == 2 ? 1 : 0);
-  const int nu = (NGL == 3 ? ((nrows + 1) >> 1) * 3 : nrows * 2) * nyz * NN;
+  // a lane keeps ONE column node b of the element (its lattice offsets are loop invariants); the 256 / NN groups of NN lanes walk the
+  // (row, element) slots of the run
+  const int nslot = (NGL == 3 ? ((nrows + 1) >> 1) * 3 : nrows * 2) * nyz;
+  constexpr int NG = 256 / NN;
+  const int grp = tid / NN, b = tid - grp * NN;
+  const int lbx = b % NGL, lby = (b / NGL) % NGL, lbz = b / (NGL * NGL);
   const int EYL = T.EY;
-  for (int u = tid; u < nu; u += 256) {
-    const int t0 = u / NN, b = u - t0 * NN;
+  for (int t0 = grp; t0 < nslot && grp < NG && !(T.ablate & 1); t0 += NG) {
     const int yz = t0 & (nyz - 1), t1 = t0 >> sh;
     int cx, ex, la_x;
     if (NGL == 3) {
@@ -437,9 +541,8 @@ __global__ void __launch_bounds__(256) assemble_ho3_lattice_kernel(Ho3Args T) {
       }
       if (ez < 0 || ez >= T.EZ) continue;
     }
-    const int64_t e = ex + (int64_t)T.EX * (ey + (int64_t)EYL * ez);
+    const double* __restrict__ ge = gl + ((zs * ny_e + ys) * GEX + (ex - ex0)) * GS;
     const int a = (la_z * NGL + la_y) * NGL + la_x;
-    const int lbx = b % NGL, lby = (b / NGL) % NGL, lbz = b / (NGL * NGL);
     int xlo, n_x;
     axis_range<NGL>(cx, NX, xlo, n_x);
     const int kx = M * ex + lbx - xlo, ky = M * ey + lby - ylo;
@@ -451,7 +554,18 @@ __global__ void __launch_bounds__(256) assemble_ho3_lattice_kernel(Ho3Args T) {
     const int r = cx - x0;
     const int base = rowoff[r] * BB, len = rowoff[r + 1] - rowoff[r];
     double v[3][3];
-    ho3_block<DIM, NN, MAT>(T.geom + e * GS, T.tabs, a, b, T.alpha_d, T.alpha_w, v);
+    if (tens) {   // the record from the 1-D factors in LDS: the loop's only global loads are the element's J^-1, detJ
+      double rec[TabRec<DIM>::TS];
+      const int la[3] = {la_x, la_y, la_z}, lb[3] = {lbx, lby, lbz};
+      ho3_record_1d<DIM, NGL, MAT>(t1d, la, lb, rec);
+      ho3_block<DIM, MAT>(ge, rec, T.alpha_d, T.alpha_w, v);
+    } else {
+      ho3_block<DIM, MAT>(ge, T.tabs + (a * NN + b) * TabRec<DIM>::TS, T.alpha_d, T.alpha_w, v);
+    }
+    if (T.ablate & 4) {
+      if (v[0][0] == 1.2345e-300) img[0] = v[1][1] + v[2][2] + v[0][1] + v[1][0] + v[0][2] + v[2][0] + v[1][2] + v[2][1];
+      continue;
+    }
     if (MAT == M_OP) {
       for (int t = 0; t < T.nterms; ++t) {
         const int d = T.t_der[t];
@@ -468,15 +582,36 @@ __global__ void __launch_bounds__(256) assemble_ho3_lattice_kernel(Ho3Args T) {
   __syncthreads();
 
   // ---- the piece of the value array(s) this run owns
+  if (T.ablate & 2) return;
   const int64_t gbase = (int64_t)rp0 * BB;
   double* __restrict__ outA = T.A;
   double* __restrict__ outR = T.Arhs;
   if (!routed) {
     const int total = rowoff[nrows] * BB;
     const bool zr = outR && !T.rhs_clean && !T.rcrow;   // (a compact matrix stores no row of a run without imposed DOFs)
-    for (int i = tid; i < total; i += 256) {
-      outA[gbase + i] = img[i];
-      if (zr) outR[gbase + i] = 0.0;
+    if (T.ablate & 8) {   // A/B: one double per lane and store
+      for (int i = tid; i < total; i += 256) {
+        outA[gbase + i] = img[i];
+        if (zr) outR[gbase + i] = 0.0;
+      }
+      return;
+    }
+    // two doubles per lane and store (1 KiB per wave instruction; the piece starts on any double: 8-byte aligned pairs)
+    typedef double __attribute__((ext_vector_type(2), aligned(8))) d2u;
+    for (int i = 2 * tid; i + 1 < total; i += 512) {
+      d2u v2;
+      v2.x = img[i];
+      v2.y = img[i + 1];
+      *reinterpret_cast<d2u*>(outA + gbase + i) = v2;
+      if (zr) {
+        d2u z2;
+        z2.x = z2.y = 0.0;
+        *reinterpret_cast<d2u*>(outR + gbase + i) = z2;
+      }
+    }
+    if ((total & 1) && tid == 0) {
+      outA[gbase + total - 1] = img[total - 1];
+      if (zr) outR[gbase + total - 1] = 0.0;
     }
     return;
   }
@@ -604,6 +739,7 @@ void fill_lattice_args(const pyn_ctx* c, Ho3Args& T) {
   T.nbits = nullptr;
   T.geom = L.d_geom;
   T.tabs = c->d_ho3_tabs;
+  T.tabs1d = c->ho3_tens_ok ? c->d_ho3_t1d : nullptr;
   T.alpha_d = T.alpha_w = 0.0;
   T.A = T.Arhs = nullptr;
   T.rhs_clean = 0;
@@ -613,6 +749,10 @@ void fill_lattice_args(const pyn_ctx* c, Ho3Args& T) {
   T.so0 = 0;
   T.img_len = 0;
   T.step = L.ngl == 3 ? 2 : 1;
+  {
+    const char* ab = getenv("PYNAMA_HO3_ABLATE");
+    T.ablate = ab ? atoi(ab) : 0;
+  }
   T.obr = T.obc = 1;
   T.nterms = 0;
 }
@@ -809,45 +949,118 @@ int pyn_ho3_detect(pyn_ctx* c, const int32_t* conn) {
   return PYN_OK;
 }
 
-// Reference matrices of the element from one uploaded rule (pyn_elem_tables_set), in tensor order:
-// [Tf | Tr][r][s][a][b] = sum_g w Hrs_r[a] Hrs_s[b] (full | reduced), [Uf | Ur | Un][r][a][b] = sum_g w H[a] Hrs_r[b] (full | reduced | nodal)
+// Reference matrices of the element from one uploaded rule (pyn_elem_tables_set): the part of every node pair's record (TabRec) that
+// rule supplies -- Tf / Uf (full), Tr / Ur (reduced), Un (nodal) -- in tensor order
 int pyn_ho3_tables(pyn_ctx* c, int which, int ngp, const double* w, const double* H, const double* Hrs) {
   const int dim = c->dim, nn = c->nn;
   if (which < 0 || which > 2) return PYN_OK;
   if (!((dim == 2 && (nn == 9 || nn == 4)) || (dim == 3 && (nn == 27 || nn == 8)))) return PYN_OK;
   const int ngl = (nn == 9 || nn == 27) ? 3 : 2;
   const int dd = dim * dim, n2 = nn * nn;
-  const size_t total = (size_t)(2 * dd + 3 * dim) * n2;
+  const int ts = (2 * dd + 3 * dim + 1) & ~1;        // record per node pair (TabRec)
+  const size_t total = (size_t)ts * n2;
   if (c->ho3_tabs_nn != nn) {
     (void)hipFree(c->d_ho3_tabs);
     c->d_ho3_tabs = nullptr;
     c->ho3_tabs_ok[0] = c->ho3_tabs_ok[1] = c->ho3_tabs_ok[2] = false;
     PYN_HIP(hipMalloc((void**)&c->d_ho3_tabs, total * sizeof(double)));
+    PYN_HIP(hipMemsetAsync(c->d_ho3_tabs, 0, total * sizeof(double), c->stream));
+    c->ho3_tabs_host.assign(total, 0.0);
     c->ho3_tabs_nn = nn;
   }
-  std::vector<double> T((size_t)dd * n2), U((size_t)dim * n2);
+  std::vector<double>& R = c->ho3_tabs_host;
   for (int a = 0; a < nn; ++a)
     for (int b = 0; b < nn; ++b) {
       const int ta = tens_of(dim, ngl, a), tb = tens_of(dim, ngl, b);
+      double* rec = R.data() + (size_t)(ta * nn + tb) * ts;
+      double* recT = R.data() + (size_t)(tb * nn + ta) * ts;      // Ur is read transposed
       for (int r = 0; r < dim; ++r) {
-        for (int s = 0; s < dim; ++s) {
-          double acc = 0.0;
-          for (int g = 0; g < ngp; ++g) acc += w[g] * Hrs[((size_t)g * dim + r) * nn + a] * Hrs[((size_t)g * dim + s) * nn + b];
-          T[(size_t)(r * dim + s) * n2 + ta * nn + tb] = acc;
-        }
+        if (which != PYN_Q_NODAL)
+          for (int s = 0; s < dim; ++s) {
+            double acc = 0.0;
+            for (int g = 0; g < ngp; ++g) acc += w[g] * Hrs[((size_t)g * dim + r) * nn + a] * Hrs[((size_t)g * dim + s) * nn + b];
+            rec[(which == PYN_Q_FULL ? 0 : dd) + r * dim + s] = acc;
+          }
         double acc = 0.0;
         for (int g = 0; g < ngp; ++g) acc += w[g] * H[(size_t)g * nn + a] * Hrs[((size_t)g * dim + r) * nn + b];
-        U[(size_t)r * n2 + ta * nn + tb] = acc;
+        if (which == PYN_Q_FULL) rec[2 * dd + r] = acc;
+        if (which == PYN_Q_RED) recT[2 * dd + dim + r] = acc;
+        if (which == PYN_Q_NODAL) rec[2 * dd + 2 * dim + r] = acc;
       }
     }
-  if (which != PYN_Q_NODAL) {
-    const size_t offT = which == PYN_Q_FULL ? 0 : (size_t)dd * n2;
-    PYN_HIP(hipMemcpyAsync(c->d_ho3_tabs + offT, T.data(), T.size() * sizeof(double), hipMemcpyHostToDevice, c->stream));
+  PYN_HIP(hipMemcpyAsync(c->d_ho3_tabs, R.data(), total * sizeof(double), hipMemcpyHostToDevice, c->stream));
+  // 1-D factors of this rule: M[i][j] = sum w h_i h_j, D[i][j] = sum w h'_i h_j, S[i][j] = sum w h'_i h'_j, recovered from the uploaded
+  // tensor tables by summing out the other axes (sum_ij M_ij = sum w = 2 on [-1, 1]); the records rebuilt from them are checked below
+  {
+    const int n1 = ngl * ngl;
+    if ((int)c->ho3_t1d_host.size() != 8 * n1) c->ho3_t1d_host.assign((size_t)8 * n1, 0.0);
+    double* M1 = c->ho3_t1d_host.data() + (size_t)(which == PYN_Q_NODAL ? 6 : 3 * which) * n1;
+    double* D1 = M1 + n1;
+    double* S1 = which == PYN_Q_NODAL ? nullptr : M1 + 2 * n1;
+    for (int k = 0; k < n1; ++k) {
+      M1[k] = D1[k] = 0.0;
+      if (S1) S1[k] = 0.0;
+    }
+    double norm = 1.0;
+    for (int d = 1; d < dim; ++d) norm *= 2.0;
+    for (int a = 0; a < nn; ++a)
+      for (int b = 0; b < nn; ++b) {
+        const int i = loc_of(dim, ngl, a, 0), j = loc_of(dim, ngl, b, 0);
+        double mass = 0.0, u0 = 0.0, t00 = 0.0;
+        for (int g = 0; g < ngp; ++g) {
+          mass += w[g] * H[(size_t)g * nn + a] * H[(size_t)g * nn + b];
+          u0 += w[g] * Hrs[((size_t)g * dim + 0) * nn + a] * H[(size_t)g * nn + b];                       // h'_a h_b along x
+          t00 += w[g] * Hrs[((size_t)g * dim + 0) * nn + a] * Hrs[((size_t)g * dim + 0) * nn + b];
+        }
+        M1[i * ngl + j] += mass / norm;
+        D1[i * ngl + j] += u0 / norm;
+        if (S1) S1[i * ngl + j] += t00 / norm;
+      }
   }
-  const size_t offU = (size_t)2 * dd * n2 + (size_t)which * dim * n2;
-  PYN_HIP(hipMemcpyAsync(c->d_ho3_tabs + offU, U.data(), U.size() * sizeof(double), hipMemcpyHostToDevice, c->stream));
-  PYN_HIP(hipStreamSynchronize(c->stream));
   c->ho3_tabs_ok[which] = true;
+  c->ho3_tens_ok = false;
+  if (c->ho3_tabs_ok[0] && c->ho3_tabs_ok[1] && c->ho3_tabs_ok[2] && !getenv("PYNAMA_HO3_DENSE_TABLES")) {
+    // every record entry against the product of the 1-D factors
+    const int n1 = ngl * ngl;
+    const double* t1 = c->ho3_t1d_host.data();
+    double worst = 0.0, scale = 0.0;
+    for (int ta = 0; ta < nn; ++ta)
+      for (int tb = 0; tb < nn; ++tb) {
+        int la[3] = {0, 0, 0}, lb[3] = {0, 0, 0};
+        for (int d = 0, x = ta, y = tb; d < dim; ++d, x /= ngl, y /= ngl) {
+          la[d] = x % ngl;
+          lb[d] = y % ngl;
+        }
+        auto fac = [&](int tab, int d, bool tr) { return t1[tab * n1 + (tr ? lb[d] * ngl + la[d] : la[d] * ngl + lb[d])]; };
+        const double* rec = R.data() + (size_t)(ta * nn + tb) * ts;
+        for (int rule = 0; rule < 2; ++rule)
+          for (int r = 0; r < dim; ++r)
+            for (int s2 = 0; s2 < dim; ++s2) {
+              double p = 1.0;
+              for (int d = 0; d < dim; ++d)
+                p *= (d == r && d == s2) ? fac(3 * rule + 2, d, false) : (d == r ? fac(3 * rule + 1, d, false) : (d == s2 ? fac(3 * rule + 1, d, true) : fac(3 * rule, d, false)));
+              const double ref = rec[rule * dd + r * dim + s2];
+              worst = std::max(worst, std::fabs(p - ref));
+              scale = std::max(scale, std::fabs(ref));
+            }
+        for (int x = 0; x < dim; ++x) {
+          double pf = fac(1, x, true), pr = fac(4, x, false), pn = fac(7, x, true);
+          for (int d = 0; d < dim; ++d)
+            if (d != x) {
+              pf *= fac(0, d, false);
+              pr *= fac(3, d, false);
+              pn *= fac(6, d, false);
+            }
+          worst = std::max(worst, std::max(std::fabs(pf - rec[2 * dd + x]), std::max(std::fabs(pr - rec[2 * dd + dim + x]), std::fabs(pn - rec[2 * dd + 2 * dim + x]))));
+        }
+      }
+    if (worst <= 1e-13 * scale) {
+      if (!c->d_ho3_t1d) PYN_HIP(hipMalloc((void**)&c->d_ho3_t1d, 8 * 9 * sizeof(double)));
+      PYN_HIP(hipMemcpyAsync(c->d_ho3_t1d, t1, (size_t)8 * n1 * sizeof(double), hipMemcpyHostToDevice, c->stream));
+      c->ho3_tens_ok = true;
+    }
+  }
+  PYN_HIP(hipStreamSynchronize(c->stream));
   return PYN_OK;
 }
 

@@ -159,6 +159,7 @@ extern "C" int pyn_ctx_destroy(pyn_ctx* c) {
   (void)hipFree(c->lat.d_zord);
   pyn_ho3_release(c);
   (void)hipFree(c->d_ho3_tabs);
+  (void)hipFree(c->d_ho3_t1d);
   (void)hipFree(c->d_bcmask);
   (void)hipFree(c->d_rowptr);
   (void)hipFree(c->d_colidx);

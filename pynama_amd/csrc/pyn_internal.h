@@ -235,6 +235,10 @@ struct pyn_ctx {
   // reference matrices of the ngl = 3 element in tensor (lattice) order, from the uploaded tables (pyn_elem_tables_set):
   // Tf / Tr[r][s][a][b] = sum_g w Hrs_r[a] Hrs_s[b] (full / reduced rule), Uf / Ur[r][a][b] = sum_g w H[a] Hrs_r[b]
   double* d_ho3_tabs = nullptr;
+  std::vector<double> ho3_t1d_host;    // 1-D factors M, D, S of the three rules; the records are their tensor products when ho3_tens_ok
+  double* d_ho3_t1d = nullptr;
+  bool ho3_tens_ok = false;
+  std::vector<double> ho3_tabs_host;   // host image of the records (the three rules arrive in separate pyn_elem_tables_set calls)
   bool ho3_tabs_ok[3] = {false, false, false};   // full, reduced, nodal rule
   int ho3_tabs_nn = 0;
 

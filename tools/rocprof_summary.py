@@ -2,7 +2,7 @@
 """Turn rocprofv3 result databases (rocpd sqlite, the default output of this ROCm) into the small text files
 committed under profiles/.
   rocprof_summary.py stats  <results.db> <out.csv> [out.md]     --kernel-trace --stats run
-  rocprof_summary.py pmc    <fetch.db> <write.db> <out.json>    --pmc FETCH_SIZE / --pmc WRITE_SIZE runs
+  rocprof_summary.py pmc    <fetch.db> <write.db> <out.json> [per]   --pmc FETCH_SIZE / --pmc WRITE_SIZE runs (per: launches per logical launch)
   rocprof_summary.py counters <results.db> <out.json> [kernel-substring]   any --pmc run: per-kernel mean of every counter
   rocprof_summary.py timeline <results.db> <out.txt> [n]        last n dispatches of a --kernel-trace run: start, duration, gap"""
 import json
@@ -30,7 +30,10 @@ def stats(db, out_csv, out_md=None):
                 f.write("| `%s` | %d | %.2f | %.1f | %.2f |\n" % (short(name, 90), calls, tot / 1e3, avg, pct))
 
 
-def pmc(fetch_db, write_db, out_json):
+def pmc(fetch_db, write_db, out_json, per=1):
+    """per: launches that make up ONE logical launch (the row-run kernels run once per class of x-lines: 2 launches per matrix in 2-D,
+    4 in 3-D) -- `hbm_bytes_per_launch` is then the sum over such a group"""
+    per = int(per)
     res = {}
     for db, counter in ((fetch_db, "FETCH_SIZE"), (write_db, "WRITE_SIZE")):
         con = sqlite3.connect(db)
@@ -44,7 +47,9 @@ def pmc(fetch_db, write_db, out_json):
     for k, v in res.items():
         if "FETCH_SIZE_KB" in v and "WRITE_SIZE_KB" in v:
             # gfx950: FETCH_SIZE counts 64 B per 128-B request (MI355X_MICROARCH.md, HBM section) -> x2
-            v["hbm_bytes_per_launch"] = (2.0 * v["FETCH_SIZE_KB"] + v["WRITE_SIZE_KB"]) * 1024.0
+            v["hbm_bytes_per_launch"] = (2.0 * v["FETCH_SIZE_KB"] + v["WRITE_SIZE_KB"]) * 1024.0 * per
+            if per > 1:
+                v["launches_per_logical_launch"] = per
     with open(out_json, "w") as f:
         json.dump({"correction": "(2*FETCH_SIZE + WRITE_SIZE)*1024 bytes per launch (gfx950 FETCH_SIZE counts 64 B per "
                                  "128-B request; separate --pmc passes)",
@@ -95,4 +100,4 @@ if __name__ == "__main__":
     elif sys.argv[1] == "stats":
         stats(*sys.argv[2:5])
     else:
-        pmc(*sys.argv[2:5])
+        pmc(*sys.argv[2:6])
