@@ -442,3 +442,43 @@ def test_operators_on_lattices(lib, nelem, ngl):
         ctx.mat_row_scale(m, vs)
         assert sp_rel_err(mat_to_scipy(ctx, m, br, bc), ref[name]) < FP_TOL, name
     ctx.close()
+
+
+@pytest.mark.parametrize("nelem,ngl", [([7, 6, 5], 2), ([2, 2, 2], 2), ([9, 7], 2), ([9, 7], 3), ([1, 1], 3), ([1, 3, 2], 2)])
+def test_closed_form_pattern_dictionary(lib, nelem, ngl):
+    """the column-pattern dictionary of a single-rank lattice written in closed form (27 / 9 / 16 patterns) gives the products of the
+    hash-based construction (PYNAMA_NO_LATTICE_PATTERNS=1) and of scipy, for the scalar and the block matrices that use it"""
+    from pynama_amd.elements.spectral import Spectral
+    dim = len(nelem)
+    mesh = fo.box_mesh(nelem, [0.0] * dim, [1.0] * dim, ngl)
+    x1 = np.random.default_rng(3).standard_normal(mesh.n_node)
+    xd = np.random.default_rng(4).standard_normal(mesh.n_node * dim)
+    res = {}
+    for mode in ("closed", "hash"):
+        if mode == "hash":
+            os.environ["PYNAMA_NO_LATTICE_PATTERNS"] = "1"
+        try:
+            ctx = lib.Context(0)
+            ctx.mesh_set(dim, mesh.conn, mesh.xyz)
+            for t in Spectral(ngl, dim).deviceTables():
+                ctx.tables_set(*t)
+            ctx.csr_symbolic()
+            A, K = ctx.mat_create(1, 1), ctx.mat_create(dim, dim)
+            ctx.assemble_scalar(lib.FORM_LAPLACE, A, -1)
+            ctx.assemble_kle(1e3, 1e2, K, -1, -1, -1)
+            v1, w1, vd, wd = ctx.vec_create(1), ctx.vec_create(1), ctx.vec_create(dim), ctx.vec_create(dim)
+            ctx.vec_set(v1, x1)
+            ctx.vec_set(vd, xd)
+            ctx.spmv(A, v1, w1)
+            ctx.spmv(K, vd, wd)
+            info = ctx.solve(K, vd, wd, fixed_iters=3)          # the solver's product kernels (image / LDS-staged runs)
+            res[mode] = (ctx.vec_get(w1, 1), ctx.vec_get(wd, dim), info.rnorm)
+            if mode == "closed":
+                SA, SK = mat_to_scipy(ctx, A, 1, 1), mat_to_scipy(ctx, K, dim, dim)
+                assert rel_err(res[mode][0], SA @ x1) < 1e-13
+            ctx.close()
+        finally:
+            os.environ.pop("PYNAMA_NO_LATTICE_PATTERNS", None)
+    assert rel_err(res["closed"][0], res["hash"][0]) < 1e-14
+    assert rel_err(res["closed"][1], res["hash"][1]) < 1e-13
+    assert abs(res["closed"][2] - res["hash"][2]) <= 1e-12 * abs(res["hash"][2])
