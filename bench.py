@@ -76,9 +76,12 @@ class Traffic:
     run), committed under profiles/ together with the hash of the kernel sources they were taken on.  Quoted only when that
     hash is the one embedded in the library that just ran."""
 
-    def __init__(self, lib_hash):
+    def __init__(self, lib_hash, passes=("traffic", "assembly", "assembly_general")):
+        # `passes`: the headline workload's counter passes (tools/profile_pass_r03.sh part a); the other configurations' passes hold
+        # kernels of the same names at other sizes and are not mixed in
         self.lib_hash, self.k, self.why = lib_hash, {}, "no PMC summary under profiles/ was taken on these kernel sources"
-        for fn in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_*.json"))):
+        files = [fn for p in passes for fn in sorted(glob.glob(os.path.join(ROOT, "profiles", f"r*_pmc_{p}.json")))]
+        for fn in files:
             try:
                 with open(fn) as fh:
                     d = json.load(fh)
@@ -688,6 +691,13 @@ def main():
         tr_spmv, src_spmv = traffic.get(spmv_kernel)
         tr_asm, src_asm = traffic.get(asm_kernel)
         other = wall / args.steps * 1e3 - asm_mean - cg_mean
+        cg_traffic = None
+        if world_size == 1:
+            parts = [traffic.get(k)[0] for k in (spmv_kernel, "cg_update_selfred_kernel", "cg_p_selfred_kernel")]
+            if all(p is not None for p in parts):
+                gbs = sum(parts) / (cg_mean / args.cg_iters * 1e-3) / 1e9
+                cg_traffic = {"bytes_per_iteration": sum(parts), "GBs": gbs, "frac": gbs / HBM_PEAK_GBS, "source": src_spmv,
+                              "kernels": [spmv_kernel, "cg_update_selfred_kernel", "cg_p_selfred_kernel"]}
         out = {
             "metric": "assembled element-DOFs/sec + CG iterations/sec, 10M-DOF Poisson, 1/2/4/8 MI355X",
             "value": elem_dofs_per_step / (asm_mean * 1e-3),
@@ -727,7 +737,11 @@ def main():
                                                        "lattice kernels read neither rowptr nor colidx (4 nnz + 4 N of the algorithmic count)"}),
             "roofline_assembly_general": general,
             "roofline_cg_iteration": {"bound": "hbm", "achieved": cg_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                                      "frac": cg_gbs / HBM_PEAK_GBS, "algorithmic_bytes_per_iteration": B_cg * share},
+                                      "frac": cg_gbs / HBM_PEAK_GBS, "algorithmic_bytes_per_iteration": B_cg * share,
+                                      # the same iteration time priced on the bytes the PMC counters saw its three kernels move
+                                      # (product + the two fused vector kernels): the CSR model above charges 4 B of column index
+                                      # per entry that the dictionary product never streams, so this is the fraction to steer by
+                                      "on_measured_traffic": cg_traffic},
             "check": check,
             "selftest": selftest,
             "matrix_free": mfree,

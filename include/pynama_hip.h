@@ -112,9 +112,29 @@ int pyn_halo_set(pyn_ctx* ctx, int64_t n_owned, int64_t n_ghost, int n_neigh, co
  * HrsCoo has dim+1 columns, and every entry point below works unchanged. */
 int pyn_mesh_set(pyn_ctx* ctx, int dim, int nn, int64_t n_elem, int64_t n_node,
                  const int32_t* conn, const double* xyz);
+/* The reference's box mesh built where it is used: replaces PETSc.DMPlex().createBoxMesh(faces, lower, upper)
+ * (src/domain/dmplex.py:16-21) + the per-cell closure / coordinate interpolation of setFemIndexing / computeFullCoordinates
+ * (dmplex.py:42-95) for this rank's block of a structured mesh of ngl^dim-node cells, without a host copy of either array:
+ *   nel_local[dim]  elements per axis of the block (only the slowest axis -- y in 2-D, z in 3-D -- may be cut),
+ *   layer0          first global element layer of the block along the slowest axis,
+ *   lattice[dim]    nodes per axis of the WHOLE mesh ((ngl-1) * elements + 1),
+ *   loc[nn*dim]     lattice offset in 0..ngl-1 of local node a along axis d (the reference's local order),
+ *   planes[n_planes] global slowest-axis index of local plane k: local node id = k * (nodes per plane) + in-plane id, owned planes
+ *                   first (pyn_halo_set's numbering); n_planes = (ngl-1) * nel_local[slow] + 1,
+ *   axes            coordinate of lattice line i of axis d, the axes one after the other (lattice[0] + lattice[1] (+ lattice[2]) doubles).
+ * Everything pyn_mesh_set does afterwards (topology detection, verified against the generated connectivity) is the same. */
+int pyn_mesh_box(pyn_ctx* ctx, int dim, int ngl, const int64_t* nel_local, int64_t layer0, const int64_t* lattice,
+                 const int32_t* loc, int64_t n_planes, const int64_t* planes, const double* axes);
+/* Host copies of the local mesh as the device holds it (either pointer may be NULL): conn[n_elem*nn], xyz[n_node*dim].
+ * DMPlexDom.getCellCornersCoords / getNodesCoordinates (dmplex.py:97-104, 230-244) for a caller that wants them all. */
+int pyn_mesh_get(pyn_ctx* ctx, int32_t* conn, double* xyz);
 /* Topology recognised by pyn_mesh_set: kind 0 = general connectivity, 1 = structured lattice of Q1
  * hexahedra (the reference's box mesh, src/domain/dmplex.py:8-21, or a rank's z-slab of one): nx, ny =
- * nodes per x / y line, nz = node planes of the local mesh.  Lattices are assembled by a plan-free kernel. */
+ * nodes per x / y line, nz = node planes of the local mesh.  Lattices are assembled by a plan-free kernel.
+ * kind 2 = structured mesh of SECOND-order cells (ngl = 3: 9-node quadrilaterals / 27-node hexahedra in the
+ * reference's local order, src/elements/spectral.py:346-431 -- the order of every yaml file under src/cases),
+ * kind 3 = structured mesh of Q1 quadrilaterals; for both nx, ny, nz count the NODES per x-line, x-lines per
+ * plane and planes (2-D: nz = 1) and the atomics-free row-run kernels assemble them (pyn_assemble_ho3.hip). */
 int pyn_mesh_topology(pyn_ctx* ctx, int* kind, int* nx, int* ny, int* nz);
 /* One quadrature's tables -- Spectral.computeMats2D/3D output (spectral.py:220-344):
  * w[ngp], H[ngp*nn], Hrs[ngp*dim*nn], HrsCoo[ngp*dim*2^dim] (geometry basis, spectral.py:54-61). */
@@ -145,6 +165,10 @@ int pyn_patch_plan_set(pyn_ctx* ctx, int n_patch, const int32_t* patch_ptr, cons
 /* kind 0: the plan of the scalar forms (<= 352 rows per patch); kind 1: the plan of the tiled KLE
  * assembly (3x3 blocks: <= 36 rows per patch, e.g. 4x3x3 node tiles).  Both may coexist. */
 int pyn_patch_plan_set_kind(pyn_ctx* ctx, int kind, int n_patch, const int32_t* patch_ptr, const int32_t* patch_rows);
+/* The plan in use (the caller's, or the automatic one an assembly built): info[4] = patches, longest patch (rows), longest
+ * element list of a patch, (patch, element) pairs -- pairs / elements is the factor by which elements on patch borders are
+ * integrated more than once (diagnostics; no counterpart in the reference). */
+int pyn_patch_plan_info(pyn_ctx* ctx, int kind, int64_t* info);
 
 /* ---- matrices and vectors (device resident) ---------------------------------------------
  * Handles are small non-negative ints.  A vector with block size b has (n_owned+n_ghost)*b
@@ -170,7 +194,8 @@ int pyn_mat_add_values(pyn_ctx* ctx, int mat_id, int nrows, const int32_t* rows,
 int pyn_mat_get_values(pyn_ctx* ctx, int mat_id, double* val);      /* layout above */
 int pyn_mat_get_diagonal(pyn_ctx* ctx, int mat_id, int vec_id);
 int pyn_mat_axpy(pyn_ctx* ctx, int y_mat, double a, int x_mat);     /* Y += a X (base_problem.py:318) */
-int pyn_mat_row_scale(pyn_ctx* ctx, int mat_id, int vec_id);        /* diagonalScale(L=) mat_generator.py:176 */
+int pyn_mat_row_scale(pyn_ctx* ctx, int mat_id, int vec_id);        /* diagonalScale(L=) mat_generator.py:176; a vector of block size 1
+                                                                      * holds one factor per NODE for all of its rows (the lumped weights) */
 int pyn_vec_create(pyn_ctx* ctx, int bs, int* vec_id);
 int pyn_vec_destroy(pyn_ctx* ctx, int vec_id);
 int pyn_vec_set_host(pyn_ctx* ctx, int vec_id, const double* src);  /* owned part, n_owned*bs */

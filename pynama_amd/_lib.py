@@ -72,6 +72,9 @@ SIGNATURES = {
     "pyn_csr_get": [_P, C.c_void_p, C.c_void_p],
     "pyn_patch_plan_set": [_P, _I, _P, _P],
     "pyn_patch_plan_set_kind": [_P, _I, _I, _P, _P],
+    "pyn_patch_plan_info": [_P, _I, _P],
+    "pyn_mesh_box": [_P, _I, _I, _P, _L, _P, _P, _L, _P, _P],
+    "pyn_mesh_get": [_P, _P, _P],
     "pyn_mat_create": [_P, _I, _I, C.POINTER(_I)],
     "pyn_mat_create_rhs": [_P, _I, _I, C.POINTER(_I)],
     "pyn_mat_stored_blocks": [_P, _I, C.POINTER(_L), C.POINTER(_L)],
@@ -284,6 +287,35 @@ class Context:
         self._bc_last = None
         if not getattr(self, "_halo", False):
             self.n_owned, self.n_ghost = n_node, 0
+
+    def mesh_box(self, dim, ngl, nel_local, layer0, lattice, loc, planes, axes):
+        """this rank's block of a structured box mesh, generated on the device (pyn_mesh_box): no host conn / xyz"""
+        nel = np.ascontiguousarray(nel_local, dtype=np.int64)
+        lat = np.ascontiguousarray(lattice, dtype=np.int64)
+        loc = _i32(loc)
+        planes = np.ascontiguousarray(planes, dtype=np.int64)
+        axes = _f64(np.concatenate([np.asarray(a, dtype=np.float64) for a in axes]))
+        assert loc.shape == (ngl ** dim, dim) and nel.size == dim and lat.size == dim and axes.size == int(lat.sum())
+        _check(self.lib.pyn_mesh_box(self.h, dim, ngl, nel.ctypes.data_as(_P), int(layer0), lat.ctypes.data_as(_P),
+                                     loc.ctypes.data_as(_P), planes.size, planes.ctypes.data_as(_P), axes.ctypes.data_as(_P)))
+        per = int(np.prod(lat[:-1]))
+        self.dim, self.nn, self.n_elem, self.n_node = dim, ngl ** dim, int(np.prod(nel)), per * planes.size
+        self._bc_last = None
+        if not getattr(self, "_halo", False):
+            self.n_owned, self.n_ghost = self.n_node, 0
+
+    def mesh_get(self, conn=True, xyz=True):
+        """host copies of the local mesh as the device holds it"""
+        cn = np.empty((self.n_elem, self.nn), np.int32) if conn else None
+        xy = np.empty((self.n_node, self.dim), np.float64) if xyz else None
+        _check(self.lib.pyn_mesh_get(self.h, cn.ctypes.data_as(_P) if conn else None, xy.ctypes.data_as(_P) if xyz else None))
+        return cn, xy
+
+    def patch_plan_info(self, kind=0):
+        """(patches, longest patch, longest element list, patch-element pairs) of the plan in use"""
+        info = np.zeros(4, np.int64)
+        _check(self.lib.pyn_patch_plan_info(self.h, kind, info.ctypes.data_as(_P)))
+        return tuple(int(v) for v in info)
 
     def mesh_topology(self):
         """('lattice', nx, ny, nz) for structured Q1 hex meshes, ('general', 0, 0, 0) otherwise"""

@@ -868,7 +868,29 @@ void pyn_ho3_release(pyn_ctx* c) {
 // Is the connectivity that of a structured mesh of tensor-product cells of order 1 or 2 (ngl 2 / 3: the reference's box mesh,
 // src/domain/dmplex.py:8-21, 42-61, or a rank's slab of one)?  Host, once per pyn_mesh_set; every entry of `conn` is checked against
 // the closed form the kernels use.
-int pyn_ho3_detect(pyn_ctx* c, const int32_t* conn) {
+// every element of a structured block against its closed form (one thread per entry of the connectivity)
+struct LocTab {
+  signed char v[27][3];
+};
+__global__ void ho3_conn_verify_kernel(const int32_t* __restrict__ conn, const int32_t* __restrict__ P, LocTab loc, int dim, int nn, int m,
+                                       int64_t ne, int EX, int EY, int NX, int64_t per_layer, int* __restrict__ bad) {
+  const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= ne * nn) return;
+  const int64_t e = t / nn;
+  const int a = (int)(t - e * nn);
+  const int ex = (int)(e % EX), ey = dim == 3 ? (int)((e / EX) % EY) : 0;
+  const int64_t el = e / per_layer;
+  int64_t id;
+  if (dim == 3)
+    id = (int64_t)P[m * el + loc.v[a][2]] + (int64_t)(m * ey + loc.v[a][1]) * NX + m * ex + loc.v[a][0];
+  else
+    id = (int64_t)P[m * el + loc.v[a][1]] + m * ex + loc.v[a][0];
+  if (conn[t] != id) atomicAdd(bad, 1);
+}
+
+// `at(i)`: entry i of the local connectivity as the host sees it; the shape guessed from O(element rows + layers) entries is checked
+// against all of c->d_conn on the device
+int pyn_ho3_detect(pyn_ctx* c, const ConnAt& at) {
   pyn_ho3_release(c);
   const int dim = c->dim, nn = c->nn;
   const int ngl = (nn == 9 || nn == 27) ? 3 : 2;
@@ -878,14 +900,15 @@ int pyn_ho3_detect(pyn_ctx* c, const int32_t* conn) {
   for (int a = 0; a < nn; ++a) a_of[tens_of(dim, ngl, a)] = a;
   const int a0 = a_of[0];
   const int64_t ne = c->n_elem;
+  const int32_t c0 = at(a0);
   int64_t EX = 1;
-  while (EX < ne && conn[EX * nn + a0] == conn[a0] + m * EX) ++EX;
+  while (EX < ne && at(EX * nn + a0) == c0 + m * EX) ++EX;
   if (ne % EX) return PYN_OK;
   const int64_t NX = m * EX + 1;
   int64_t EY, EZ = 0, NY = 0, PS, EL;   // EL: element layers along the slow axis
   if (dim == 3) {
     EY = 1;
-    while (EY * EX < ne && conn[EY * EX * nn + a0] == conn[a0] + m * EY * NX) ++EY;
+    while (EY * EX < ne && at(EY * EX * nn + a0) == c0 + m * EY * NX) ++EY;
     if ((ne / EX) % EY) return PYN_OK;
     EZ = ne / (EX * EY);
     NY = m * EY + 1;
@@ -903,22 +926,10 @@ int pyn_ho3_detect(pyn_ctx* c, const int32_t* conn) {
   const int stride_s = dim == 3 ? ngl * ngl : ngl;     // tensor stride of the slow axis
   for (int64_t l = 0; l < EL; ++l)
     for (int j = 0; j < ngl; ++j) {
-      const int32_t base = conn[l * per_layer * nn + a_of[j * stride_s]];
+      const int32_t base = at(l * per_layer * nn + a_of[j * stride_s]);
       if (P[m * l + j] >= 0 && P[m * l + j] != base) return PYN_OK;
       P[m * l + j] = base;
     }
-  for (int64_t e = 0; e < ne; ++e) {
-    const int64_t ex = e % EX, ey = dim == 3 ? (e / EX) % EY : 0, el = e / per_layer;
-    const int32_t* q = conn + e * nn;
-    for (int a = 0; a < nn; ++a) {
-      int64_t id;
-      if (dim == 3)
-        id = (int64_t)P[m * el + loc_of(3, ngl, a, 2)] + (m * ey + loc_of(3, ngl, a, 1)) * NX + m * ex + loc_of(3, ngl, a, 0);
-      else
-        id = (int64_t)P[m * el + loc_of(2, ngl, a, 1)] + m * ex + loc_of(2, ngl, a, 0);
-      if (q[a] != id) return PYN_OK;
-    }
-  }
   std::vector<int32_t> sorted(P);
   std::sort(sorted.begin(), sorted.end());
   for (int64_t j = 0; j < npl; ++j)
@@ -934,6 +945,26 @@ int pyn_ho3_detect(pyn_ctx* c, const int32_t* conn) {
   Ho3Lattice& L = c->ho3;
   PYN_HIP(hipMalloc((void**)&L.d_P, npl * sizeof(int32_t)));
   PYN_HIP(hipMemcpy(L.d_P, P.data(), npl * sizeof(int32_t), hipMemcpyHostToDevice));
+  {   // every element against the guessed shape
+    int* d_bad = nullptr;
+    int bad = 0;
+    PYN_HIP(hipMalloc((void**)&d_bad, sizeof(int)));
+    PYN_HIP(hipMemsetAsync(d_bad, 0, sizeof(int), c->stream));
+    const unsigned grid = (unsigned)((ne * nn + 255) / 256);
+    LocTab lt;
+    for (int a = 0; a < nn; ++a)
+      for (int d = 0; d < dim; ++d) lt.v[a][d] = (signed char)loc_of(dim, ngl, a, d);
+    ho3_conn_verify_kernel<<<grid, 256, 0, c->stream>>>(c->d_conn, L.d_P, lt, dim, nn, m, ne, (int)EX, (int)EY, (int)NX, per_layer, d_bad);
+    PYN_HIP(hipGetLastError());
+    PYN_HIP(hipMemcpyAsync(&bad, d_bad, sizeof(int), hipMemcpyDeviceToHost, c->stream));
+    PYN_HIP(hipStreamSynchronize(c->stream));
+    (void)hipFree(d_bad);
+    if (bad) {
+      (void)hipFree(L.d_P);
+      L.d_P = nullptr;
+      return PYN_OK;
+    }
+  }
   L.P = P;
   L.dim = dim;
   L.ngl = ngl;

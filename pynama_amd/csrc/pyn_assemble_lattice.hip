@@ -1483,21 +1483,38 @@ __global__ void lattice_symbolic_kernel(LatArgs T, int64_t n_rows, int32_t* __re
 }  // namespace
 
 // ---- structured topology: detection (host, once per pyn_mesh_set) and launch -------------------------
-int pyn_lattice_detect(pyn_ctx* c, const int32_t* conn) {
+// every element of a structured Q1 block against its closed form (one thread per element; `bad` counts the mismatches)
+__global__ void lattice_conn_verify_kernel(const int32_t* __restrict__ conn, const int32_t* __restrict__ P, int64_t ne, int ex, int ey, int nx,
+                                           int* __restrict__ bad) {
+  const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= ne) return;
+  const int ix = (int)(e % ex), iy = (int)((e / ex) % ey);
+  const int64_t l = e / ((int64_t)ex * ey);
+  const int32_t lo = P[l] + iy * nx + ix, hi = P[l + 1] + iy * nx + ix;
+  const int4 q0 = *reinterpret_cast<const int4*>(conn + e * 8), q1 = *reinterpret_cast<const int4*>(conn + e * 8 + 4);
+  if (q0.x != lo || q0.y != lo + nx || q0.z != lo + nx + 1 || q0.w != lo + 1 || q1.x != hi || q1.y != hi + 1 || q1.z != hi + nx + 1 ||
+      q1.w != hi + nx)
+    atomicAdd(bad, 1);
+}
+
+// `at(i)`: entry i of the local connectivity (the uploaded host array, or the closed form of pyn_mesh_box); it is asked for O(layers +
+// element rows) entries -- the shape guessed from them is then checked against ALL of c->d_conn on the device
+int pyn_lattice_detect(pyn_ctx* c, const ConnAt& at) {
   Lattice& L = c->lat;
   (void)hipFree(L.d_P);
   (void)hipFree(L.d_zord);
   L = Lattice();
   if (c->dim != 3 || c->nn != 8 || c->n_elem < 1 || getenv("PYNAMA_NO_LATTICE")) return PYN_OK;
   const int64_t ne = c->n_elem;
-  const int64_t nx = (int64_t)conn[1] - conn[0];
-  if (nx < 2 || conn[3] != conn[0] + 1) return PYN_OK;
+  const int64_t nx = (int64_t)at(1) - at(0);
+  if (nx < 2 || at(3) != at(0) + 1) return PYN_OK;
   const int64_t ex = nx - 1;
   if (ne % ex) return PYN_OK;
   // rows of elements per layer: the first element row that does not continue the bottom plane of layer 0
   int64_t ey = 0;
+  const int32_t c0 = at(0);
   for (int64_t j = 0; j * ex < ne; ++j) {
-    if (conn[j * ex * 8] != conn[0] + j * nx) break;
+    if (at(j * ex * 8) != c0 + j * nx) break;
     ey = j + 1;
   }
   if (ey < 1 || (ne / ex) % ey) return PYN_OK;
@@ -1505,20 +1522,11 @@ int pyn_lattice_detect(pyn_ctx* c, const int32_t* conn) {
   if (nxny * npl != c->n_node || nxny > INT32_MAX / 2) return PYN_OK;
   std::vector<int32_t> P((size_t)npl);
   for (int64_t l = 0; l < ezl; ++l) {
-    const int32_t* e0 = conn + l * ex * ey * 8;
-    P[l] = e0[0];
-    if (l + 1 == ezl) P[l + 1] = e0[4];
-    if (l > 0 && P[l] != conn[(l - 1) * ex * ey * 8 + 4]) return PYN_OK;
+    const int64_t e0 = l * ex * ey * 8;
+    P[l] = at(e0);
+    if (l + 1 == ezl) P[l + 1] = at(e0 + 4);
+    if (l > 0 && P[l] != at((l - 1) * ex * ey * 8 + 4)) return PYN_OK;
   }
-  for (int64_t l = 0; l < ezl; ++l)
-    for (int64_t iy = 0; iy < ey; ++iy)
-      for (int64_t ix = 0; ix < ex; ++ix) {
-        const int32_t* q = conn + ((l * ey + iy) * ex + ix) * 8;
-        const int32_t lo = (int32_t)(P[l] + iy * nx + ix), hi = (int32_t)(P[l + 1] + iy * nx + ix);
-        if (q[0] != lo || q[1] != lo + nx || q[2] != lo + nx + 1 || q[3] != lo + 1 || q[4] != hi || q[5] != hi + 1 ||
-            q[6] != hi + nx + 1 || q[7] != hi + nx)
-          return PYN_OK;
-      }
   // planes are disjoint blocks of nx*ny ids; the owned ones are consecutive in z and carry ids 0..n_owned-1
   std::vector<int32_t> sorted(P);
   std::sort(sorted.begin(), sorted.end());
@@ -1546,6 +1554,23 @@ int pyn_lattice_detect(pyn_ctx* c, const int32_t* conn) {
   PYN_HIP(hipMalloc((void**)&L.d_zord, npl * sizeof(int32_t)));
   PYN_HIP(hipMemcpy(L.d_P, P.data(), npl * sizeof(int32_t), hipMemcpyHostToDevice));
   PYN_HIP(hipMemcpy(L.d_zord, zord.data(), npl * sizeof(int32_t), hipMemcpyHostToDevice));
+  {   // every element against the guessed shape
+    int* d_bad = nullptr;
+    int bad = 0;
+    PYN_HIP(hipMalloc((void**)&d_bad, sizeof(int)));
+    PYN_HIP(hipMemsetAsync(d_bad, 0, sizeof(int), c->stream));
+    lattice_conn_verify_kernel<<<(unsigned)((ne + 255) / 256), 256, 0, c->stream>>>(c->d_conn, L.d_P, ne, (int)ex, (int)ey, (int)nx, d_bad);
+    PYN_HIP(hipGetLastError());
+    PYN_HIP(hipMemcpyAsync(&bad, d_bad, sizeof(int), hipMemcpyDeviceToHost, c->stream));
+    PYN_HIP(hipStreamSynchronize(c->stream));
+    (void)hipFree(d_bad);
+    if (bad) {
+      (void)hipFree(L.d_P);
+      (void)hipFree(L.d_zord);
+      L = Lattice();
+      return PYN_OK;
+    }
+  }
   L.nx = (int)nx;
   L.ny = (int)ny;
   L.npl = (int)npl;

@@ -1034,6 +1034,17 @@ extern "C" int pyn_patch_plan_set(pyn_ctx* c, int n_patch, const int32_t* patch_
   return pyn_patch_plan_set_kind(c, 0, n_patch, patch_ptr, patch_rows);
 }
 
+extern "C" int pyn_patch_plan_info(pyn_ctx* c, int kind, int64_t* info) {
+  PYN_CHECK(c && info, "NULL argument");
+  PYN_CHECK(kind == 0 || kind == 1, "plan kind must be 0 (scalar) or 1 (KLE)");
+  const PatchPlan& P = c->plan[kind];
+  info[0] = P.npatch;
+  info[1] = P.maxrows;
+  info[2] = P.maxlen;
+  info[3] = P.npe;
+  return PYN_OK;
+}
+
 static bool g_default_plan = false;  // pyn_patch_plan_set_kind called by ensure_default_plan
 
 extern "C" int pyn_patch_plan_set_kind(pyn_ctx* c, int kind, int n_patch, const int32_t* patch_ptr, const int32_t* patch_rows) {

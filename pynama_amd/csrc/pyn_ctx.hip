@@ -521,9 +521,96 @@ int pyn_halo_exchange_on(pyn_ctx* c, double* x, int bs, hipStream_t st) {
 
 // ---------------------------------------------------------------------------------------------
 // mesh / tables / bc
-extern "C" int pyn_mesh_set(pyn_ctx* c, int dim, int nn, int64_t n_elem, int64_t n_node, const int32_t* conn,
-                            const double* xyz) {
-  PYN_CHECK(c && conn && xyz, "NULL argument");
+// first connectivity entry outside [0, n_node) (INT64_MAX: none)
+__global__ void conn_range_kernel(const int32_t* __restrict__ conn, int64_t n, int32_t n_node, unsigned long long* __restrict__ first_bad) {
+  int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (; t < n; t += stride) {
+    const int32_t v = conn[t];
+    if (v < 0 || v >= n_node) atomicMin(first_bad, (unsigned long long)t);
+  }
+}
+
+// box mesh in closed form: element e = (ex, ey[, el]) of the local block, local node a -> local id of the lattice node
+struct BoxArgs {
+  int dim, nn, m;
+  int64_t n_elem, n_node, PS;          // PS: nodes per plane (3-D) / per x-line (2-D) = one step of the slow axis
+  int E[3], N[3];                      // elements per axis of the local block, global lattice per axis
+  int64_t layer0;                      // first global element layer of the block along the slow axis
+  const int32_t* loc;                  // [nn * dim] lattice offsets of the local nodes
+  const int32_t* lplane;               // [m * E[slow] + 1]: LOCAL plane index of plane j of the block (owned first, then ghosts)
+  const int64_t* planes;               // [n_node / PS]: global slow-axis index of local plane k
+  const double* axes;                  // coordinates of the lattice lines: N[0] + N[1] (+ N[2]) doubles
+};
+
+__global__ void box_conn_kernel(BoxArgs B, int32_t* __restrict__ conn) {
+  const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= B.n_elem * B.nn) return;
+  const int64_t e = t / B.nn;
+  const int a = (int)(t - e * B.nn);
+  const int ex = (int)(e % B.E[0]);
+  const int64_t r = e / B.E[0];
+  const int ey = B.dim == 3 ? (int)(r % B.E[1]) : 0;
+  const int64_t el = B.dim == 3 ? r / B.E[1] : r;
+  const int32_t* l = B.loc + a * B.dim;
+  int64_t id = (int64_t)B.lplane[B.m * el + l[B.dim - 1]] * B.PS + B.m * ex + l[0];
+  if (B.dim == 3) id += (int64_t)(B.m * ey + l[1]) * B.N[0];
+  conn[t] = (int32_t)id;
+}
+
+__global__ void box_xyz_kernel(BoxArgs B, double* __restrict__ xyz) {
+  const int64_t n = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (n >= B.n_node) return;
+  const int64_t k = n / B.PS, in = n - k * B.PS;
+  const int64_t g = B.planes[k];
+  if (B.dim == 3) {
+    const int iy = (int)(in / B.N[0]), ix = (int)(in - (int64_t)iy * B.N[0]);
+    xyz[n * 3] = B.axes[ix];
+    xyz[n * 3 + 1] = B.axes[B.N[0] + iy];
+    xyz[n * 3 + 2] = B.axes[B.N[0] + B.N[1] + g];
+  } else {
+    xyz[n * 2] = B.axes[in];
+    xyz[n * 2 + 1] = B.axes[B.N[0] + g];
+  }
+}
+
+// what pyn_mesh_set / pyn_mesh_box share once c->d_conn and c->d_xyz hold the local mesh
+static int mesh_installed(pyn_ctx* c, const ConnAt& at) {
+  {
+    unsigned long long* d_bad = nullptr;
+    unsigned long long bad = ~0ull;
+    const int64_t n = c->n_elem * c->nn;
+    PYN_HIP(hipMalloc((void**)&d_bad, sizeof(bad)));
+    PYN_HIP(hipMemcpyAsync(d_bad, &bad, sizeof(bad), hipMemcpyHostToDevice, c->stream));
+    conn_range_kernel<<<(unsigned)std::min<int64_t>((n + 255) / 256, 4096), 256, 0, c->stream>>>(c->d_conn, n, (int32_t)c->n_node, d_bad);
+    PYN_HIP(hipGetLastError());
+    PYN_HIP(hipMemcpyAsync(&bad, d_bad, sizeof(bad), hipMemcpyDeviceToHost, c->stream));
+    PYN_HIP(hipStreamSynchronize(c->stream));
+    (void)hipFree(d_bad);
+    if (bad != ~0ull) {
+      const long long i = (long long)bad;
+      c->n_elem = c->n_node = 0;
+      PYN_CHECK(false, "conn[%lld]=%d out of range", i, (int)at(i));
+    }
+  }
+  c->mesh_affine = -1;
+  for (int k = 0; k < 3; ++k) {   // matrix-free operators belong to the mesh
+    (void)hipFree(c->mf_mask[k]);
+    c->mf_mask[k] = nullptr;
+    c->mf_set[k] = false;
+  }
+  PYN_TRY(pyn_lattice_detect(c, at));
+  PYN_TRY(pyn_ho3_detect(c, at));
+  // graph + matrices depend on the mesh
+  (void)hipFree(c->d_rowptr);
+  (void)hipFree(c->d_colidx);
+  c->d_rowptr = nullptr;
+  c->d_colidx = nullptr;
+  c->nnzb = 0;
+  return PYN_OK;
+}
+
+static int mesh_sizes(pyn_ctx* c, int dim, int nn, int64_t n_elem, int64_t n_node) {
   PYN_CHECK(dim == 2 || dim == 3, "dim must be 2 or 3");
   int ngl = 0;
   for (int g = 2; g <= 32; ++g) {
@@ -535,14 +622,13 @@ extern "C" int pyn_mesh_set(pyn_ctx* c, int dim, int nn, int64_t n_elem, int64_t
   const bool simplex = nn == dim + 1;
   PYN_CHECK(ngl >= 2 || simplex, "nn=%d is neither ngl^dim nor a linear simplex (dim+1)", nn);
   PYN_CHECK(n_elem > 0 && n_node > 0 && n_node < (int64_t)INT32_MAX, "bad sizes");
+  PYN_CHECK(n_elem * nn < ((int64_t)1 << 40), "bad sizes");
   if (!c->halo_set) {
     c->n_owned = n_node;
     c->n_ghost = 0;
   }
   PYN_CHECK(c->n_owned + c->n_ghost == n_node, "n_node %lld != owned+ghost %lld", (long long)n_node,
             (long long)(c->n_owned + c->n_ghost));
-  for (int64_t i = 0; i < n_elem * nn; ++i)
-    PYN_CHECK(conn[i] >= 0 && conn[i] < n_node, "conn[%lld]=%d out of range", (long long)i, conn[i]);
   c->dim = dim;
   c->nn = nn;
   c->nc = simplex ? nn : 1 << dim;
@@ -550,23 +636,105 @@ extern "C" int pyn_mesh_set(pyn_ctx* c, int dim, int nn, int64_t n_elem, int64_t
   c->n_elem = n_elem;
   c->n_node = n_node;
   PYN_HIP(hipSetDevice(c->device));
+  return PYN_OK;
+}
+
+extern "C" int pyn_mesh_set(pyn_ctx* c, int dim, int nn, int64_t n_elem, int64_t n_node, const int32_t* conn,
+                            const double* xyz) {
+  PYN_CHECK(c && conn && xyz, "NULL argument");
+  PYN_TRY(mesh_sizes(c, dim, nn, n_elem, n_node));
   PYN_TRY(dev_upload(&c->d_conn, conn, (size_t)n_elem * nn, c->stream));
   PYN_TRY(dev_upload(&c->d_xyz, xyz, (size_t)n_node * dim, c->stream));
-  PYN_HIP(hipStreamSynchronize(c->stream));
-  c->mesh_affine = -1;
-  for (int k = 0; k < 3; ++k) {   // matrix-free operators belong to the mesh
-    (void)hipFree(c->mf_mask[k]);
-    c->mf_mask[k] = nullptr;
-    c->mf_set[k] = false;
+  return mesh_installed(c, [conn](int64_t i) { return conn[i]; });
+}
+
+extern "C" int pyn_mesh_box(pyn_ctx* c, int dim, int ngl, const int64_t* nel_local, int64_t layer0, const int64_t* lattice,
+                            const int32_t* loc, int64_t n_planes, const int64_t* planes, const double* axes) {
+  PYN_CHECK(c && nel_local && lattice && loc && planes && axes, "NULL argument");
+  PYN_CHECK(dim == 2 || dim == 3, "dim must be 2 or 3");
+  PYN_CHECK(ngl >= 2 && ngl <= 32, "ngl out of range");
+  const int m = ngl - 1, slow = dim - 1;
+  int nn = 1;
+  int64_t n_elem = 1, PS = 1;
+  for (int d = 0; d < dim; ++d) {
+    nn *= ngl;
+    PYN_CHECK(nel_local[d] >= 1 && lattice[d] >= 2 && lattice[d] < INT32_MAX && nel_local[d] < INT32_MAX, "bad box sizes");
+    PYN_CHECK(d == slow || lattice[d] == m * nel_local[d] + 1, "only the slowest axis may be cut into slabs");
+    n_elem *= nel_local[d];
+    if (d != slow) PS *= lattice[d];
   }
-  PYN_TRY(pyn_lattice_detect(c, conn));
-  PYN_TRY(pyn_ho3_detect(c, conn));
-  // graph + matrices depend on the mesh
-  (void)hipFree(c->d_rowptr);
-  (void)hipFree(c->d_colidx);
-  c->d_rowptr = nullptr;
-  c->d_colidx = nullptr;
-  c->nnzb = 0;
+  PYN_CHECK(layer0 >= 0 && m * (layer0 + nel_local[slow]) + 1 <= lattice[slow], "element layers outside the lattice");
+  PYN_CHECK(n_planes == m * nel_local[slow] + 1, "a block of %lld element layers has %lld planes, not %lld", (long long)nel_local[slow],
+            (long long)(m * nel_local[slow] + 1), (long long)n_planes);
+  for (int a = 0; a < nn; ++a)
+    for (int d = 0; d < dim; ++d) PYN_CHECK(loc[a * dim + d] >= 0 && loc[a * dim + d] <= m, "loc[%d][%d] outside the element", a, d);
+  // local plane index of every plane of the block
+  std::vector<int32_t> lplane((size_t)n_planes, -1);
+  const int64_t g0 = (int64_t)m * layer0;
+  for (int64_t k = 0; k < n_planes; ++k) {
+    const int64_t j = planes[k] - g0;
+    PYN_CHECK(j >= 0 && j < n_planes && lplane[j] < 0, "planes[] is not a permutation of the block's planes");
+    lplane[j] = (int32_t)k;
+  }
+  PYN_TRY(mesh_sizes(c, dim, nn, n_elem, PS * n_planes));
+  PYN_TRY(dev_upload(&c->d_conn, (const int32_t*)nullptr, (size_t)n_elem * nn, c->stream));
+  PYN_TRY(dev_upload(&c->d_xyz, (const double*)nullptr, (size_t)c->n_node * dim, c->stream));
+  BoxArgs B;
+  B.dim = dim;
+  B.nn = nn;
+  B.m = m;
+  B.n_elem = n_elem;
+  B.n_node = c->n_node;
+  B.PS = PS;
+  B.layer0 = layer0;
+  int64_t n_axes = 0;
+  for (int d = 0; d < 3; ++d) {
+    B.E[d] = d < dim ? (int)nel_local[d] : 1;
+    B.N[d] = d < dim ? (int)lattice[d] : 1;
+    if (d < dim) n_axes += lattice[d];
+  }
+  int32_t *d_loc = nullptr, *d_lplane = nullptr;
+  int64_t* d_planes = nullptr;
+  double* d_axes = nullptr;
+  PYN_TRY(dev_upload(&d_loc, loc, (size_t)nn * dim, c->stream));
+  PYN_TRY(dev_upload(&d_lplane, lplane.data(), (size_t)n_planes, c->stream));
+  PYN_TRY(dev_upload(&d_planes, planes, (size_t)n_planes, c->stream));
+  PYN_TRY(dev_upload(&d_axes, axes, (size_t)n_axes, c->stream));
+  B.loc = d_loc;
+  B.lplane = d_lplane;
+  B.planes = d_planes;
+  B.axes = d_axes;
+  box_conn_kernel<<<(unsigned)((n_elem * nn + 255) / 256), 256, 0, c->stream>>>(B, c->d_conn);
+  box_xyz_kernel<<<(unsigned)((c->n_node + 255) / 256), 256, 0, c->stream>>>(B, c->d_xyz);
+  PYN_HIP(hipGetLastError());
+  PYN_HIP(hipStreamSynchronize(c->stream));   // the uploads above read host memory of this frame
+  (void)hipFree(d_loc);
+  (void)hipFree(d_lplane);
+  (void)hipFree(d_planes);
+  (void)hipFree(d_axes);
+  // the same closed form for the handful of entries the topology detection asks the host for
+  const int E0 = B.E[0], E1 = B.E[1], N0 = B.N[0];
+  std::vector<int32_t> locv(loc, loc + (size_t)nn * dim);
+  return mesh_installed(c, [=](int64_t t) -> int32_t {
+    const int64_t e = t / nn;
+    const int a = (int)(t - e * nn);
+    const int ex = (int)(e % E0);
+    const int64_t r = e / E0;
+    const int ey = dim == 3 ? (int)(r % E1) : 0;
+    const int64_t el = dim == 3 ? r / E1 : r;
+    const int32_t* l = locv.data() + (size_t)a * dim;
+    int64_t id = (int64_t)lplane[m * el + l[dim - 1]] * PS + m * ex + l[0];
+    if (dim == 3) id += (int64_t)(m * ey + l[1]) * N0;
+    return (int32_t)id;
+  });
+}
+
+extern "C" int pyn_mesh_get(pyn_ctx* c, int32_t* conn, double* xyz) {
+  PYN_CHECK(c && c->n_elem > 0, "pyn_mesh_set first");
+  PYN_HIP(hipSetDevice(c->device));
+  if (conn) PYN_HIP(hipMemcpyAsync(conn, c->d_conn, (size_t)c->n_elem * c->nn * sizeof(int32_t), hipMemcpyDeviceToHost, c->stream));
+  if (xyz) PYN_HIP(hipMemcpyAsync(xyz, c->d_xyz, (size_t)c->n_node * c->dim * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+  PYN_HIP(hipStreamSynchronize(c->stream));
   return PYN_OK;
 }
 

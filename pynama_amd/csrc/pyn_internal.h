@@ -5,6 +5,7 @@
 
 #include <cstdint>
 #include <cstdio>
+#include <functional>
 #include <string>
 #include <vector>
 
@@ -307,7 +308,9 @@ void pyn_rhs_release(DMat& M);
 int pyn_rhs_expand(pyn_ctx* c, const DMat& M, double* full);   // full-pattern copy of the values (zeros in the rows not stored)
 int pyn_bc_elements(pyn_ctx* c);                        // c->d_esel / n_esel for the current Dirichlet set
 int64_t pyn_mat_blocks(const pyn_ctx* c, const DMat& M);        // blocks stored by the matrix (graph entries, or the compact count)
-int pyn_lattice_detect(pyn_ctx* c, const int32_t* conn_host);  // pyn_assemble_tiled.hip
+// entry i of the local connectivity as the host sees it: the array handed to pyn_mesh_set, or the closed form of pyn_mesh_box
+using ConnAt = std::function<int32_t(int64_t)>;
+int pyn_lattice_detect(pyn_ctx* c, const ConnAt& at);  // pyn_assemble_lattice.hip
 bool pyn_q1_affine_tables_standard(const double* aff);
 int pyn_mesh_all_affine(pyn_ctx* c, int* out);                        // pyn_assemble_tiled.hip
 // collectives behind one switch: RCCL (product) or the shared-memory test transport
@@ -325,7 +328,7 @@ bool pyn_q1_mixed_tables_standard(const double* w, const double* H, const double
 bool pyn_q1_gauss_tables_standard(const double* w, const double* H, const double* Hrs, const double* HrsCoo);   // pyn_assemble_march.hip
 int pyn_assemble_lattice_march(pyn_ctx* c, void* lat_args, int tile);   // general geometry, z-marching (pyn_assemble_march.hip)
 // second-order (ngl = 3) lattices (pyn_assemble_ho3.hip)
-int pyn_ho3_detect(pyn_ctx* c, const int32_t* conn_host);
+int pyn_ho3_detect(pyn_ctx* c, const ConnAt& at);
 void pyn_ho3_release(pyn_ctx* c);
 int pyn_ho3_tables(pyn_ctx* c, int which, int ngp, const double* w, const double* H, const double* Hrs);
 int pyn_ho3_symbolic(pyn_ctx* c, bool* done);

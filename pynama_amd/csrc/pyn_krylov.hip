@@ -633,7 +633,7 @@ extern "C" int pyn_mat_axpy(pyn_ctx* c, int ym, double a, int xm) {
 }
 
 __global__ void row_scale_kernel(const int32_t* __restrict__ rowptr, double* __restrict__ val, const double* __restrict__ s,
-                                 int64_t n_nodes, int br, int bc) {
+                                 int64_t n_nodes, int br, int bc, bool per_node) {
   // one wave per scalar row
   int lane = threadIdx.x & 63;
   int64_t w = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
@@ -643,7 +643,7 @@ __global__ void row_scale_kernel(const int32_t* __restrict__ rowptr, double* __r
     int p = (int)(r - i * br);
     int lo = rowptr[i], len = rowptr[i + 1] - lo;
     double* v = val + ((int64_t)lo * br + (int64_t)p * len) * bc;
-    double f = s[r];
+    double f = s[per_node ? i : r];
     for (int k = lane; k < len * bc; k += 64) v[k] *= f;
   }
 }
@@ -652,12 +652,13 @@ extern "C" int pyn_mat_row_scale(pyn_ctx* c, int mat_id, int vec_id) {
   PYN_TRY(pyn_check_mat(c, mat_id, "row_scale"));
   PYN_TRY(pyn_check_vec(c, vec_id, "row_scale"));
   DMat& A = c->mats[mat_id];
-  PYN_CHECK(c->vecs[vec_id].bs == A.br, "block size mismatch");
+  const int sbs = c->vecs[vec_id].bs;   // one factor per scalar row, or (block size 1) one per node for all of its rows
+  PYN_CHECK(sbs == A.br || sbs == 1, "block size mismatch");
   PYN_CHECK(!A.rhs_compact, "row_scale: not available for a compact imposed-column matrix");
   int64_t rows = c->n_owned * A.br;
   A.touch();
   int grid = (int)std::max<int64_t>(1, std::min<int64_t>((rows * 64 + 255) / 256, 8192));
-  row_scale_kernel<<<grid, 256, 0, c->stream>>>(c->d_rowptr, A.val, c->vecs[vec_id].d, c->n_owned, A.br, A.bc);
+  row_scale_kernel<<<grid, 256, 0, c->stream>>>(c->d_rowptr, A.val, c->vecs[vec_id].d, c->n_owned, A.br, A.bc, sbs == 1 && A.br != 1);
   return PYN_OK;
 }
 

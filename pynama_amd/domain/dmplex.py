@@ -262,13 +262,14 @@ class DMPlexDom(object):
         self.jitterSeed = int(kwargs.get('jitterSeed', 12345))
         self._graph = None
         self._fullCoordVec = None
+        self._conn = self._xyz = self._lat_idx_ = None
 
     @property
     def ctx(self):
         """Device context of this rank: created, bound to the communicator and loaded with the local
         mesh on first use.  Raises if no MI355X is visible (there is no CPU fallback)."""
         if self._ctx is None:
-            if not hasattr(self, "conn"):
+            if not hasattr(self, "indicesManager"):
                 raise RuntimeError("setFemIndexing(ngl) first")
             ctx = _lib.Context(_lib.default_device())
             if self.comm.size > 1 and os.environ.get("PYNAMA_SHM_TRANSPORT"):
@@ -289,7 +290,14 @@ class DMPlexDom(object):
                 # one rank, but with a real RCCL communicator: the collective code paths of a multi-GPU
                 # run (single-reduction CG, all-reduced scalars) can be timed and tested on one GPU
                 ctx.comm_init(0, 1, _lib.Context.unique_id())
-            ctx.mesh_set(self.dim, self.conn, self.xyz)
+            if self._unstructured or self.jitter > 0.0 or os.environ.get("PYNAMA_HOST_MESH"):
+                ctx.mesh_set(self.dim, self.conn, self.xyz)
+            else:
+                # box mesh: connectivity and coordinates are generated where they are used (pyn_mesh_box); the host copies
+                # (`conn`, `xyz`) are built only if a caller asks for them
+                k0, k1 = self._layers
+                ctx.mesh_box(self.dim, self.ngl, self.nelem[:-1] + [k1 - k0], k0, self.lattice, self._loc,
+                             self._local_plane_ids(), self._axes())
             ctx.row_start = self.rStart
             self._ctx = ctx
         return self._ctx
@@ -353,17 +361,8 @@ class DMPlexDom(object):
         if dim == 2:                      # x ~ -r, y ~ -s in 2D
             loc = m - loc
         self._loc = loc
-        shape = tuple(reversed(self.nelem[:-1] + [k1 - k0]))
-        eidx = np.indices(shape).reshape(dim, -1)[::-1].astype(np.int64)
-        eidx[-1] += k0
-        base = sum(eidx[d] * m * self.strides[d] for d in range(dim))
-        off = sum(loc[:, d] * self.strides[d] for d in range(dim))
-        if self.comm.size == 1 and self.nNodesGlobal < 2 ** 31:      # one rank: local == lattice ids, built in int32 at once
-            self.conn = base.astype(np.int32)[:, None] + off.astype(np.int32)[None, :]
-        else:
-            self.conn = self._global2local(base[:, None] + off[None, :]).astype(np.int32)
-        # coordinates of the local nodes (GLL spaced inside each element)
-        self.xyz = self._lattice_coordinates()
+        # the host copies of connectivity / coordinates are built on first use (`conn`, `xyz`): the device generates its own
+        self._conn = self._xyz = self._lat_idx_ = None
         # ---- device: created lazily (first use of .ctx) so that the host logic runs without a GPU
         if self._ctx is not None:
             self._ctx.close()
@@ -371,6 +370,65 @@ class DMPlexDom(object):
         self._graph = None
         if not self.comm.rank:
             self.logger.debug("FEM/SEM Indexing SetUp")
+
+    # host copies of the local mesh: conn[e, a] = base(e) + offset(a) (vectorised), coordinates GLL spaced inside each element
+    @property
+    def conn(self):
+        if self._conn is None:
+            dim, m = self.dim, self.ngl - 1
+            k0, k1 = self._layers
+            shape = tuple(reversed(self.nelem[:-1] + [k1 - k0]))
+            eidx = np.indices(shape).reshape(dim, -1)[::-1].astype(np.int64)
+            eidx[-1] += k0
+            base = sum(eidx[d] * m * self.strides[d] for d in range(dim))
+            off = sum(self._loc[:, d] * self.strides[d] for d in range(dim))
+            if self.comm.size == 1 and self.nNodesGlobal < 2 ** 31:      # one rank: local == lattice ids, built in int32 at once
+                self._conn = base.astype(np.int32)[:, None] + off.astype(np.int32)[None, :]
+            else:
+                self._conn = self._global2local(base[:, None] + off[None, :]).astype(np.int32)
+        return self._conn
+
+    @conn.setter
+    def conn(self, v):
+        self._conn = v
+
+    @property
+    def xyz(self):
+        if self._xyz is None:
+            self._xyz = self._lattice_coordinates()
+        return self._xyz
+
+    @xyz.setter
+    def xyz(self, v):
+        self._xyz = v
+
+    @property
+    def _lat_idx(self):
+        """lattice index per axis of every local node"""
+        if self._lat_idx_ is None:
+            rem = self._local2global(np.arange(self.nLocal))
+            idx = []
+            for d in reversed(range(self.dim)):
+                q = rem // self.strides[d]
+                rem = rem - q * self.strides[d]
+                idx.append(q)
+            self._lat_idx_ = idx[::-1]
+        return self._lat_idx_
+
+    def _axes(self):
+        """coordinate of every lattice line, per axis (GLL spaced inside each element)"""
+        from pynama_amd.elements.utilities import lobattoPoints
+        m = self.ngl - 1
+        gll, _ = lobattoPoints(self.ngl)
+        axes = []
+        for d in range(self.dim):
+            h = (self.upper[d] - self.lower[d]) / self.nelem[d]
+            e = np.arange(self.nelem[d])
+            ax = np.empty(self.lattice[d])
+            ax[:-1] = (self.lower[d] + h * (e[:, None] + 0.5 * (1.0 + np.asarray(gll)[None, :m]))).ravel()
+            ax[-1] = self.upper[d]
+            axes.append(ax)
+        return axes
 
     def _setUnstructuredIndexing(self, ngl):
         """explicit (Gmsh) mesh: first-order cells.  Nodes are renumbered along a Morton curve (locality for
@@ -557,26 +615,10 @@ class DMPlexDom(object):
                 np.array(recv_ptr, np.int64))
 
     def _lattice_coordinates(self):
-        from pynama_amd.elements.utilities import lobattoPoints
-        dim, m = self.dim, self.ngl - 1
-        gll, _ = lobattoPoints(self.ngl)
-        axes = []
-        for d in range(dim):
-            h = (self.upper[d] - self.lower[d]) / self.nelem[d]
-            ax = np.empty(self.lattice[d])
-            for e in range(self.nelem[d]):
-                ax[e * m:e * m + self.ngl] = self.lower[d] + h * (e + 0.5 * (1.0 + gll))
-            ax[-1] = self.upper[d]
-            axes.append(ax)
-        gids = self._local2global(np.arange(self.nLocal))
+        dim = self.dim
+        axes = self._axes()
+        idx = self._lat_idx
         xyz = np.empty((self.nLocal, dim))
-        rem = gids.copy()
-        idx = []
-        for d in reversed(range(dim)):
-            q = rem // self.strides[d]
-            rem = rem - q * self.strides[d]
-            idx.append(q)
-        idx = idx[::-1]
         for d in range(dim):
             xyz[:, d] = axes[d][idx[d]]
         if self.jitter > 0.0:
@@ -589,18 +631,30 @@ class DMPlexDom(object):
             on = np.zeros(self.nLocal, dtype=bool)
             for d in range(dim):
                 on |= (idx[d] == 0) | (idx[d] == self.lattice[d] - 1)
-            mv = move[gids]
+            mv = move[self._local2global(np.arange(self.nLocal))]
             mv[on] = 0.0
             xyz = xyz + mv
-        self._lat_idx = idx
         return xyz
+
+    def _coords_of_local(self, ln):
+        """coordinates of the local nodes `ln` without the full array (box meshes: from the lattice lines)"""
+        if self._unstructured or self.jitter > 0.0 or self._xyz is not None:
+            return self.xyz[ln]
+        axes = self._axes()
+        rem = self._local2global(np.asarray(ln, dtype=np.int64))
+        out = np.empty((rem.size, self.dim))
+        for d in reversed(range(self.dim)):
+            q = rem // self.strides[d]
+            rem = rem - q * self.strides[d]
+            out[:, d] = axes[d][q]
+        return out
 
     # ------------------------------------------------------------------ coordinates
     def computeFullCoordinates(self, spElem):
         """Nodal coordinates of every (owned) node.  The reference interpolates the corner
         coordinates with HCooOp per cell (dmplex.py:66-95); on a box mesh that is exactly the GLL
         lattice built in setFemIndexing."""
-        self.nodes = list(range(self.rStart, self.rEnd))
+        self.nodes = range(self.rStart, self.rEnd)
 
     def getCellCornersCoords(self, cell):
         if cell + self.cellStart >= self.cellEnd:
@@ -631,7 +685,7 @@ class DMPlexDom(object):
         return self.indicesManager.mapNodesToIndices(nodes, self.dim_s)
 
     def getAllNodes(self):
-        return list(range(self.rStart, self.rEnd))
+        return range(self.rStart, self.rEnd)
 
     def getNodesCoordinates(self, nodes=None, indices=None):
         dim = self.dim
@@ -641,7 +695,7 @@ class DMPlexDom(object):
         loc = self._global2local(np.asarray(nodes, dtype=np.int64))
         if np.any(loc < 0):
             raise IndexError("node not stored on this rank")
-        return self.xyz[loc].reshape((len(nodes), dim))
+        return self._coords_of_local(loc).reshape((len(nodes), dim))
 
     # ------------------------------------------------------------------ borders / labels
     def _on_border_mask(self, name):
@@ -671,7 +725,7 @@ class DMPlexDom(object):
         return self.namingConvention
 
     def getBorderNodes(self, name):
-        return [int(n) for n in self._global_border_nodes(name)]
+        return self._global_border_nodes(name).tolist()
 
     def getBordersNodes(self) -> set:
         nodes = set()
@@ -691,10 +745,16 @@ class DMPlexDom(object):
         """uint8 [nLocal]: 1 on 'External Boundary' nodes (owned + ghost)."""
         if self._unstructured:
             return self._ext_mask.astype(np.uint8)
-        on = np.zeros(self.nLocal, dtype=np.uint8)
-        for name in self.namingConvention:
-            on |= self._on_border_mask(name).astype(np.uint8)
-        return on
+        # local nodes = local planes (owned first, then ghosts) of the lattice's leading axes: the borders are slices
+        planes = np.asarray(self._local_plane_ids())
+        on = np.zeros((planes.size,) + tuple(reversed(self.lattice[:-1])), dtype=np.uint8)
+        on[(planes == 0) | (planes == self.lattice[-1] - 1)] = 1
+        on[:, ..., 0] = 1
+        on[:, ..., -1] = 1
+        if self.dim == 3:
+            on[:, 0, :] = 1
+            on[:, -1, :] = 1
+        return on.reshape(-1)
 
     def getGlobalIndicesDirichlet(self):
         return self.indicesManager.getDirichletNodes()
@@ -770,13 +830,16 @@ class DMPlexDom(object):
         return Vec(self.ctx, bs or self.dim)
 
     def _owned_local(self, nodes):
-        nodes = np.asarray(list(nodes), dtype=np.int64)
+        if isinstance(nodes, range):
+            nodes = np.arange(nodes.start, nodes.stop, nodes.step, dtype=np.int64)
+        else:
+            nodes = np.asarray(list(nodes), dtype=np.int64)
         keep = (nodes >= self.rStart) & (nodes < self.rEnd)
         return nodes[keep], nodes[keep] - self.rStart
 
     def applyFunctionVecToVec(self, nodes, f_vec, vec, dof):
         gn, ln = self._owned_local(nodes)
-        coords = self.xyz[ln]
+        coords = self._coords_of_local(ln)
         values = np.array(list(map(f_vec, coords)), dtype=np.float64).reshape(len(ln), dof)
         inds = (ln[:, None] * dof + np.arange(dof)[None, :]).ravel()
         vec.setValuesLocal(inds, values.ravel(), addv=False)
@@ -784,7 +847,7 @@ class DMPlexDom(object):
 
     def applyFunctionScalarToVec(self, nodes, f_scalar, vec):
         gn, ln = self._owned_local(nodes)
-        values = np.array(list(map(f_scalar, self.xyz[ln])), dtype=np.float64)
+        values = np.array(list(map(f_scalar, self._coords_of_local(ln))), dtype=np.float64)
         vec.setValuesLocal(ln, values, addv=False)
         return vec
 

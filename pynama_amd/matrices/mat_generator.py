@@ -237,11 +237,13 @@ class Operators(Mat):
     The per-cell ``setValues`` loop of the reference (base_problem.py:132-140) is one device pass per
     operator (``pyn_assemble_operator``); unlike the reference, which integrates cell 0 once and reuses
     its blocks for every cell (valid on uniform meshes only), every cell is integrated."""
+    _weights = _wvec = None
 
     def createAll(self, rStart, rEnd, d_nnz_ind, o_nnz_ind, graph=None):
         if graph is not None:
             self.ctx, self.dom = graph.ctx, graph.dom
         self.Curl = self.SrT = self.DivSrT = None
+        self._weights = self._wvec = None
 
     def bind(self, graph):
         self.ctx, self.dom = graph.ctx, graph.dom
@@ -263,15 +265,25 @@ class Operators(Mat):
         ctx.bc_set(1, None)
         mass = DeviceMat(ctx, 1, 1, "nodal-mass")
         ctx.assemble_scalar(_lib.FORM_MASS_NODAL, mass.id, -1, 0)
-        w = mass.getDiagonal().getArray()
-        self.weights = w
-        for m in (self.SrT, self.DivSrT, self.Curl):      # mat_generator.py:172-186
-            wv = Vec(ctx, m.br)
-            wv.setArray(np.repeat(w, m.br))
-            wv.reciprocal()
-            m.diagonalScale(L=wv)
+        self._wvec = mass.getDiagonal()                   # stays on the device; `weights` is its host copy on request
+        self._weights = None
+        rec = self._wvec.copy()                           # device copy
+        rec.reciprocal()
+        for m in (self.SrT, self.DivSrT, self.Curl):      # mat_generator.py:172-186: one factor per node for all of its rows
+            m.diagonalScale(L=rec)
             m.assemble()
+        mass.destroy()
         self.mats = [self.Curl, self.DivSrT, self.SrT]
+
+    @property
+    def weights(self):
+        if self._weights is None:
+            self._weights = self._wvec.getArray()
+        return self._weights
+
+    @weights.setter
+    def weights(self, w):
+        self._weights = w
 
     def lumpedWeights(self, bs):
         """The lumped nodal weights repeated per DOF (the reference keeps their reciprocal in `weigCurl` etc.,

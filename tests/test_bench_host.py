@@ -41,7 +41,10 @@ def test_traffic_is_quoted_only_for_the_measured_sources(tmp_path, monkeypatch):
         {"source_hash": "aaaa", "kernels": {"csrl_spmv_kernel": {"hbm_bytes_per_launch": 3.0e9}, "other": {"launches": 1}}}))
     (prof / "r09_pmc_assembly.json").write_text(json.dumps(
         {"source_hash": "bbbb", "kernels": {"assemble_q1_hex_lattice_kernel": {"hbm_bytes_per_launch": 2.5e9}}}))
-    (prof / "r09_pmc_broken.json").write_text("{not json")
+    (prof / "r08_pmc_traffic.json").write_text("{not json")
+    # another configuration's pass holds kernels of the same name at another size: never mixed into the headline's figures
+    (prof / "r09_pmc_zz_other_config.json").write_text(json.dumps(
+        {"source_hash": "aaaa", "kernels": {"csrl_spmv_kernel": {"hbm_bytes_per_launch": 1.0e9}}}))
     monkeypatch.setattr(bench, "ROOT", str(tmp_path))
     t = bench.Traffic("aaaa")
     assert t.get("csrl_spmv_kernel") == (3.0e9, "r09_pmc_traffic.json")

@@ -6,4 +6,5 @@ exec(open("tools/api_case.py").read())
 pr.disable()
 s = io.StringIO()
 pstats.Stats(pr, stream=s).sort_stats("cumulative").print_stats(45)
+pstats.Stats(pr, stream=s).sort_stats("tottime").print_stats(25)
 print(s.getvalue())

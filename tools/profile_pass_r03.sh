@@ -26,6 +26,8 @@ sq() {      # sq <tag> <kernel substring> <command...>
   $S counters $(db $O/p_c) $O/${TAG}_${t}_sq_cycles.json $k
   rm -rf $O/p_c
 }
+PART=${PART:-all}     # gpurun calls are limited to 20 minutes: PART=a (bench, headline traffic), b (second-order legs), c (C3, C5)
+if [ "$PART" = all ] || [ "$PART" = a ]; then
 # headline alone, then the whole default run
 rocprofv3 --kernel-trace --stats -d $O/p_s -o s -- python3 bench.py --no-cpu-baseline --no-extra > $O/${TAG}_bench_10Mdof.json 2> $O/${TAG}_bench.err
 $S stats $(db $O/p_s) $O/${TAG}_bench_10Mdof_kernel_stats.csv $O/${TAG}_bench_10Mdof_summary.md; rm -rf $O/p_s
@@ -36,6 +38,8 @@ traffic traffic 1 python3 tools/prof_case.py cg 215 3
 traffic assembly 1 python3 tools/prof_case.py asm 215 3
 PYNAMA_JITTER=0.2 traffic assembly_general 1 python3 tools/prof_case.py asm 215 3
 echo "headline traffic done"
+fi
+if [ "$PART" = all ] || [ "$PART" = b ]; then
 # second-order legs: kernel statistics of the whole case, traffic per kernel family (one matrix shape per process)
 stats ho3_2d python3 tools/ho3_case.py 2 1024 3
 stats ho3_3d python3 tools/ho3_case.py 3 64 3
@@ -48,6 +52,8 @@ traffic ho3_3d_cg 1 python3 tools/prof_case.py ho3cg 3 64 3
 sq ho3_3d_K assemble_ho3 python3 tools/prof_case.py ho3k 3 64 3
 sq ho3_2d_K assemble_ho3 python3 tools/prof_case.py ho3k 2 1024 3
 echo "ho3 done"
+fi
+if [ "$PART" = all ] || [ "$PART" = c ]; then
 # C3 (128^3 KLE, compact Krhs)
 stats kle128 python3 tools/prof_case.py kle 128 3
 traffic kle128 1 python3 tools/prof_case.py kle 128 3
@@ -57,4 +63,5 @@ echo "kle done"
 stats tet5M python3 tools/tet_case.py
 traffic tet5M 1 python3 tools/tet_case.py
 sq tet5M assemble_p1_tet python3 tools/tet_case.py
+fi
 echo "all done"
