@@ -278,7 +278,10 @@ def config_kle(_lib, DMPlexDom, Spectral, n, cg_iters, jitter=0.0):
                  "kernel": "lattice_matfree_kle_kernel (Laplacian per component + rank-9 penalty correction per cell, no matrix values)",
                  "check": {"cg_iters_to_rtol_1e-10": int(mc.iters), "reason": int(mc.reason), "true_residual_vs_assembled_matrix": float(mc.true_resid),
                            "solve_ms": float(mc.solve_ms)},
-                 "note": "opt-in (-pynama_mat_free); refused unless the shell reproduces the assembled product on b"}
+                 "default_path": True,
+                 "note": "what KspSolver multiplies with by default when Mat.K carries the shell (structured Q1 hexahedra; CG and the "
+                         "symmetric preonly substitute; -pynama_mat_free 0 for the assembled product): the library refuses the shell unless "
+                         "it reproduces the assembled product on b, the facade then warns and uses the assembled matrix"}
     except _lib.PynamaHipError as e:
         mfree = {"error": str(e)}
     # operator chain of evalRHS after the solve (base_problem.py:216-232): v(x)v, SrT v, axpy, DivSrT, scale, Curl
@@ -414,17 +417,20 @@ def config_ho3(_lib, DMPlexDom, Spectral, dim, nel, cg_iters):
                             f"{8.0 * dim * dim * kr_blocks / 1e9:.2f} GB): {B3 / 1e9:.2f} GB = the bytes every call moves",
            "assembly_ms_K_alone": med_k, "assembly_frac_K_alone": b_asm(dim, dim) / (med_k * 1e-3) / 1e9 / HBM_PEAK_GBS,
            "assembly_ms_Rw_alone": med_rw, "assembly_frac_Rw_alone": b_asm(dim, dw) / (med_rw * 1e-3) / 1e9 / HBM_PEAK_GBS,
-           "kernel": "assemble_ho3_lattice_kernel (one workgroup per run of consecutive node rows of an x-line: LDS image of that piece of "
-                     "the block-CSR values, (row, element, column node) triples one per lane, closed-form blocks on parallelepipeds, "
-                     "ds_add_f64, one coalesced copy out; no HBM atomics, nothing integrated twice)",
+           "kernel": "assemble_ho3_lattice_kernel (persistent workgroups walk runs of consecutive node rows of an x-line: LDS image of that "
+                     "piece of the block-CSR values, (row, element, column node) triples one per lane, closed-form blocks (diagonal J^-1 forms "
+                     "on axis-aligned boxes), ds_add_f64, one coalesced copy out; the next run's prologue through the scalar cache / closed "
+                     "forms one run ahead; no HBM atomics, nothing integrated twice)",
            "cg_iters_per_s": cg_iters / (info.solve_ms * 1e-3), "block_spmv_ms_in_cg": info.spmv_ms,
            "spmv_frac_of_hbm_peak": B_spmv / (info.spmv_ms * 1e-3) / 1e9 / HBM_PEAK_GBS if info.spmv_ms > 0 else None,
            "cg_iteration_frac_of_hbm_peak": B_cg / (info.solve_ms / cg_iters * 1e-3) / 1e9 / HBM_PEAK_GBS,
            "product_ms_one_off": {"K": float(np.median(t_k[1:])), "Krhs": float(np.median(t_kr[1:])), "Rw": float(np.median(t_rw[1:]))},
            "format": ("block-CSR values read directly (bcsr_spmv_kernel: 16 lanes per node row)"
                       if avg_row >= 128 else
-                      "CG: block SELL-64 image (lane per scalar row), refreshed once per assembly; one-off products (Krhs v, Rw w): block-CSR "
-                      "values read directly (bcsr_spmv_kernel)") + "; byte model: 8 B per value + 4 B per block of column index + vectors",
+                      "CG and K v: block-CSR values read directly by csrlb_spmv_kernel (lane per scalar row, the 64 rows of a slice are one "
+                      "contiguous run of the values: global -> LDS by LDS-DMA, x entries through the node-level column-pattern dictionary, the two "
+                      "entries of a column node by one 16-byte load); Krhs v, Rw w: bcsr_spmv_kernel; no image") +
+                     "; byte model: 8 B per value + 4 B per block of column index + vectors",
            "algorithmic_bytes": {"assembly_3_matrices": B3, "spmv": B_spmv, "cg_iteration": B_cg},
            "check": {"cg_iters_to_rtol_1e-10": int(chk.iters), "reason": int(chk.reason), "true_residual": float(chk.true_resid),
                      "max_error_vs_exact_uniform_flow": err}}

@@ -13,7 +13,7 @@ import sys
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libpynama_hip.so")
+LIB_PATH = os.environ.get("PYNAMA_LIB_PATH") or os.path.join(_HERE, "libpynama_hip.so")   # (the override: A/B of two builds, tools/)
 CSRC = os.path.join(_HERE, "csrc")
 
 # enums of include/pynama_hip.h

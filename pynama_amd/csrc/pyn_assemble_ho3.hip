@@ -63,6 +63,7 @@ struct Ho3Args {
   const int32_t* P;
   const int32_t* rowptr;
   const uint8_t* nbits;   // per local node: bit p = DOF p imposed; null = nothing imposed
+  const uint8_t* runflag; // per owned node that starts a run: OR of nbits over the run's node box (ho3_runflag_kernel); null with nbits
   const double* geom;     // [n_elem][GS]
   const double* tabs;
   const double* tabs1d;   // [8][NGL][NGL] 1-D factors (Mf Df Sf Mr Dr Sr Mn Dn) when the records are verified tensor products, else null
@@ -73,9 +74,13 @@ struct Ho3Args {
   const int32_t* rcrow;   // Arhs is a COMPACT imposed-column matrix (pyn_rhs.hip): first block of every owned node row in it, -1 = not stored
   int par_y, par_z;       // class of the x-lines of this launch (parity of the local y / z index)
   int nruns, nly;         // runs per x-line, lines of this class per plane (3-D)
+  int nwork;              // runs of this launch (the workgroups walk them)
   int so0;                // first owned plane (3-D) / line (2-D), as an owned index, whose local index has the parity of the class
   int img_len;            // doubles of LDS behind the kernel
-  int ablate;             // diagnostics (PYNAMA_HO3_ABLATE): 1 no unit loop (zero + copy out only), 2 no copy out, 4 no LDS adds
+  int pstd;               // P[j] follows the slab numbering's closed form
+  int diag;               // every element's J^-1 is diagonal (axis-aligned boxes): the blocks' diagonal forms apply
+  int ablate;             // diagnostics (PYNAMA_HO3_ABLATE): 1 no unit loop (zero + copy out only), 2 no copy out, 4 no LDS adds; 8 one double per store,
+                          // 16 no run is flagged (no Dirichlet bits are read: WRONG matrices, timing only), 32 one geometry address for all elements
   int step;               // distance (owned index) between two lines of a class along the slow axis: 2 (ngl 3), 1 (ngl 2)
   // first-order operator form (M_OP): block shape and the (row component, column component, derivative axis, coefficient) terms
   int obr, obc, nterms;
@@ -88,6 +93,14 @@ __device__ __forceinline__ void axis_range(int c, int N, int& lo, int& n) {
   const int h = NGL == 2 ? 1 : ((c & 1) ? 1 : 2);
   lo = max(0, c - h);
   n = min(N - 1, c + h) - lo + 1;
+}
+
+// sum of the x-extents n_x(x') of the rows x' < x of an x-line (n_x as axis_range gives it): the row offsets inside a line in closed form
+template <int NGL>
+__device__ __forceinline__ int x_prefix(int x, int NX) {
+  if (x <= 0) return 0;
+  if (NGL == 2) return 2 + 3 * (x - 1) - (x == NX ? 1 : 0);
+  return 3 + 3 * (x >> 1) + 5 * ((x - 1) >> 1) - (x == NX ? 2 : 0);
 }
 
 // exact k / n for 0 <= k < 2048, n in {2, 3, 4, 5, 6, 9, 15, 25}
@@ -192,6 +205,17 @@ __global__ void __launch_bounds__(256) ho3_geom_kernel(const int32_t* __restrict
         if (bits[cn] == NC - 1) h2 = fma(X[cn][x] - X[o][x], X[cn][x] - X[o][x], h2);
       }
     if (!(na <= 1e-25 * h2) || !(det > 0.0)) *not_affine = 1;   // round-off of the coordinates only (as element_is_affine, pyn_q1_hex.h)
+    // axis-aligned boxes (every box mesh the reference makes, src/domain/dmplex.py:16-21): J is diagonal up to the round-off of its
+    // cancelling sums; the kernels then take the diagonal forms of the blocks
+    double dmax = 0.0, omax = 0.0;
+#pragma unroll
+    for (int r = 0; r < DIM; ++r)
+#pragma unroll
+      for (int x = 0; x < DIM; ++x) {
+        if (r == x) dmax = fmax(dmax, fabs(J[r * DIM + x]));
+        else omax = fmax(omax, fabs(J[r * DIM + x]));
+      }
+    if (!(omax <= 1e-14 * dmax)) not_affine[1] = 1;
   }
 }
 
@@ -280,6 +304,118 @@ __device__ __forceinline__ void ho3_record_1d(const double* __restrict__ t1, con
       rec[TR_::UN + x] = pn;
     }
   }
+}
+
+// The same block for an element whose J^-1 is DIAGONAL (axis-aligned boxes), straight from the 1-D factors: with j_d = Ji[d][d],
+//   Y_pq = j_p j_q Tr_pq,  Tr_pp = sR_p prod_{d != p} mR_d,  Tr_pq = dabR_p dbaR_q mR_t (t the third axis),  lap = sum_r j_r^2 Tf_rr,
+// i.e. ~65 FP64 operations per 3-D K block instead of ~280 (the dense J^-1 Tr J^-T products and the full 18-entry record).
+template <int DIM, int NGL, int MAT>
+__device__ __forceinline__ void ho3_block_diag(const double* __restrict__ g, const double* __restrict__ t1, const int (&la)[3], const int (&lb)[3],
+                                               double alpha_d, double alpha_w, double (&v)[3][3]) {
+  constexpr int DD = DIM * DIM, N1 = NGL * NGL;
+  auto fac = [&](int tab, int d, bool tr) { return t1[tab * N1 + (tr ? lb[d] * NGL + la[d] : la[d] * NGL + lb[d])]; };
+  double j[DIM];
+#pragma unroll
+  for (int d = 0; d < DIM; ++d) j[d] = g[d * DIM + d];
+  const double det = g[DD];
+#pragma unroll
+  for (int p = 0; p < 3; ++p)
+#pragma unroll
+    for (int q = 0; q < 3; ++q) v[p][q] = 0.0;
+  // prod_{d != x} m_d for the mass factors of rule `tab0 / 3`
+  auto others = [&](int tab0, double (&po)[DIM], double (&m)[DIM]) {
+#pragma unroll
+    for (int d = 0; d < DIM; ++d) m[d] = fac(tab0, d, false);
+    if (DIM == 2) {
+      po[0] = m[1];
+      po[1] = m[0];
+    } else {
+      po[0] = m[1] * m[DIM - 1];
+      po[1] = m[0] * m[DIM - 1];
+      po[DIM - 1] = m[0] * m[1];
+    }
+  };
+  if (MAT == M_OP) {   // v[0][d] = detJ j_d Un_d[a][b]
+    double po[DIM], m[DIM];
+    others(6, po, m);
+#pragma unroll
+    for (int d = 0; d < DIM; ++d) v[0][d] = det * j[d] * fac(7, d, true) * po[d];
+    return;
+  }
+  if (MAT == M_RW) {   // gU_d = detJ j_d Uf_d[a][b], gR_d = alpha_w detJ j_d Ur_d[b][a]
+    double pf[DIM], pr[DIM], m[DIM];
+    others(0, pf, m);
+    others(3, pr, m);
+    double gU[DIM], gR[DIM];
+#pragma unroll
+    for (int d = 0; d < DIM; ++d) {
+      const double dj = det * j[d];
+      gU[d] = dj * fac(1, d, true) * pf[d];
+      gR[d] = alpha_w * dj * fac(4, d, false) * pr[d];
+    }
+    if (DIM == 2) {
+      v[0][0] = gU[1] - gR[1];
+      v[1][0] = -gU[0] + gR[0];
+    } else {
+      constexpr int CURL3[6][4] = {{0, 2, 1, 1}, {0, 1, 2, -1}, {1, 0, 2, 1}, {1, 2, 0, -1}, {2, 1, 0, 1}, {2, 0, 1, -1}};
+#pragma unroll
+      for (int i = 0; i < 6; ++i) {
+        const int r = CURL3[i][0], cp = CURL3[i][1], d = CURL3[i][2];
+        const double sg = (double)CURL3[i][3];
+        const double u = d == 0 ? gU[0] : (d == 1 ? gU[1] : gU[DIM - 1]);
+        const double w = d == 0 ? gR[0] : (d == 1 ? gR[1] : gR[DIM - 1]);
+#pragma unroll
+        for (int p = 0; p < 3; ++p)
+#pragma unroll
+          for (int q = 0; q < 3; ++q) {
+            if (p == r && q == cp) v[p][q] += sg * u;
+            if (p == cp && q == r) v[p][q] += sg * w;
+          }
+      }
+    }
+    return;
+  }
+  double jj[DIM];
+#pragma unroll
+  for (int d = 0; d < DIM; ++d) jj[d] = j[d] * j[d];
+  double lap = 0.0;
+  {
+    double po[DIM], m[DIM];
+    others(0, po, m);
+#pragma unroll
+    for (int r = 0; r < DIM; ++r) lap = fma(jj[r], fac(2, r, false) * po[r], lap);
+  }
+  if (MAT == M_LAP) {
+    v[0][0] = det * lap;
+    return;
+  }
+  double po[DIM], m[DIM], dab[DIM], dba[DIM];
+  others(3, po, m);
+#pragma unroll
+  for (int d = 0; d < DIM; ++d) {
+    dab[d] = fac(4, d, false);
+    dba[d] = fac(4, d, true);
+  }
+  double trd[DIM], trY = 0.0;
+#pragma unroll
+  for (int p = 0; p < DIM; ++p) {
+    trd[p] = fac(5, p, false) * po[p];
+    trY = fma(jj[p], trd[p], trY);
+  }
+  const double dg = det * fma(alpha_w, trY, lap);
+  const double cd = det * (alpha_d - alpha_w);
+#pragma unroll
+  for (int p = 0; p < DIM; ++p) v[p][p] = fma(cd * jj[p], trd[p], dg);
+#pragma unroll
+  for (int p = 0; p < DIM; ++p)
+#pragma unroll
+    for (int q = p + 1; q < DIM; ++q) {
+      const double mt = DIM == 2 ? 1.0 : m[3 - p - q];     // the axis that is neither p nor q
+      const double c = det * j[p] * j[q] * mt;
+      const double tpq = dab[p] * dba[q], tqp = dab[q] * dba[p];   // Tr_pq / m_t, Tr_qp / m_t
+      v[p][q] = c * (alpha_d * tpq - alpha_w * tqp);
+      v[q][p] = c * (alpha_d * tqp - alpha_w * tpq);
+    }
 }
 
 // one block of the element matrix of element `g` (J^-1, detJ) for the node pair whose table record is `tb`
@@ -409,256 +545,391 @@ __device__ __forceinline__ void ho3_block(const double* __restrict__ g, const do
   }
 }
 
-template <int DIM, int NGL, int MAT, int R>
-__global__ void __launch_bounds__(256) assemble_ho3_lattice_kernel(Ho3Args T) {
+// A workgroup walks runs w = blockIdx.x, blockIdx.x + gridDim.x, ... of one class of x-lines.  What a run needs from memory before it can
+// start (row offsets, Dirichlet bits of its node box, J^-1 / detJ of its elements, first ids of its planes) is requested one run AHEAD,
+// right after the barrier that opens the triple loop of the current run, and parked in the second set of small LDS arrays when that
+// loop is over: the loads have a whole run to arrive, nothing waits for the stores of the run before (they drain while the next run
+// is zeroed and integrated), and a run's own phases no longer depend on four other workgroups of the CU to be overlapped.
+struct Ho3Run {
+  int x0, nrows, cy, cz, ylo, n_y, zlo, n_z;
+  int64_t row0;
+};
+
+template <int DIM, int NGL, int MAT, int R, bool DG>
+__global__ void __launch_bounds__(256, 4) assemble_ho3_lattice_kernel(Ho3Args T) {
   constexpr int M = NGL - 1, NN = DIM == 3 ? NGL * NGL * NGL : NGL * NGL, GS = DIM == 3 ? 10 : 6;
   constexpr int BRc = MAT == M_LAP ? 1 : DIM;
   constexpr int BCc = MAT == M_K ? DIM : (MAT == M_RW ? (DIM == 3 ? 3 : 1) : 1);
   const int BR = MAT == M_OP ? T.obr : BRc, BC = MAT == M_OP ? T.obc : BCc;   // compile-time constants except for the operators
   const int BB = BR * BC;
   constexpr int BXW = R + 2 * M, BYW = 2 * M + 1, BZW = DIM == 3 ? 2 * M + 1 : 1;   // node box around the run: M nodes on every side
-  extern __shared__ double img[];
-  __shared__ int rowoff[R + 1];
-  __shared__ int srank[5], splane[5];   // slow axis: sorted position of neighbour plane j, and its inverse
-  __shared__ unsigned char nb[BXW * BYW * BZW];
-  __shared__ double t1d[8 * NGL * NGL];
-  // J^-1, detJ of the elements the run touches, requested in the prologue with the row offsets (one memory latency for both): the
-  // triple loop then makes no global load at all when the table records come from the 1-D factors
+  constexpr int BOX = BXW * BYW * BZW;
+  // J^-1, detJ of the elements the run touches: the triple loop makes no global load at all when the table records come from the
+  // 1-D factors
   constexpr int GEX = NGL == 3 ? R / 2 + 1 : R + 1, GEL = GEX * (DIM == 3 ? 4 : 2);
-  __shared__ double gl[GEL * GS];
+  constexpr int NBR = (BOX + 255) / 256, NGR = (GEL * GS + 255) / 256;   // lanes' shares of the Dirichlet bits / the geometry
+  static_assert(R + 1 <= 256, "one row offset per lane");
+  extern __shared__ double img[];
+  __shared__ int srank[2][5], splane[2][5];  // slow axis: sorted position of neighbour plane j, and its inverse
+  __shared__ unsigned char nb[BOX];          // Dirichlet bits of the node box (filled in runs that see an imposed DOF only)
+  __shared__ double gl[2][GEL * GS];
+  __shared__ double t1d[8 * NGL * NGL];
+  __shared__ int rcs[R];                     // first block of the run's rows in a compact Krhs (runs with an imposed DOF only)
   const int tid = threadIdx.x;
   const bool tens = T.tabs1d != nullptr;
   if (tens && tid < 8 * NGL * NGL) t1d[tid] = T.tabs1d[tid];
-  int bid = blockIdx.x;
-  const int run = bid % T.nruns;
-  bid /= T.nruns;
-  const int NX = T.NX, x0 = run * R;
-  const int nrows = min(R, NX - x0);
-  int cy, cz = 0, so;   // local y / z index of the line, owned index along the slow axis
-  if (DIM == 3) {
-    const int iy = bid % T.nly;
-    so = T.so0 + T.step * (bid / T.nly);
-    cy = NGL == 3 ? 2 * iy + T.par_y : iy;
-    cz = T.p_own0 + so;
-  } else {
-    so = T.so0 + T.step * bid;
-    cy = T.p_own0 + so;
-  }
+  const int NX = T.NX;
   const int NYL = DIM == 3 ? T.NY : T.npl;   // extent of the y axis
-  int ylo, n_y, zlo = 0, n_z = 1;
-  axis_range<NGL>(cy, NYL, ylo, n_y);
-  if (DIM == 3) axis_range<NGL>(cz, T.npl, zlo, n_z);
-  const int slo = DIM == 3 ? zlo : ylo, n_s = DIM == 3 ? n_z : n_y;
-  const int64_t row0 = DIM == 3 ? ((int64_t)so * T.NY + cy) * NX + x0 : (int64_t)so * NX + x0;
-  const int rp0 = T.rowptr[row0];
-  if (tid <= nrows) rowoff[tid] = T.rowptr[row0 + tid] - rp0;
-  if (tid < n_s) {
-    const int pj = T.P[slo + tid];
-    int rk = 0;
-    for (int j = 0; j < n_s; ++j) rk += T.P[slo + j] < pj;
-    srank[tid] = rk;
-    splane[rk] = slo + tid;
-  }
-  // Dirichlet bits of the node box around the run
-  int any = 0;
-  if (T.nbits) {
-    for (int i = tid; i < BXW * BYW * BZW; i += 256) {
-      const int bx = i % BXW, by = (i / BXW) % BYW, bz = i / (BXW * BYW);
-      const int x = x0 - M + bx, y = cy - M + by, z = cz - M + bz;
-      int m = 0;
-      if (x >= 0 && x < NX && y >= 0 && y < NYL && (DIM == 2 || (z >= 0 && z < T.npl))) {
-        const int64_t id = DIM == 3 ? (int64_t)T.P[z] + (int64_t)y * NX + x : (int64_t)T.P[y] + x;
-        m = T.nbits[id];
-      }
-      nb[i] = (unsigned char)m;
-      any |= m;
-    }
-  }
-  const int ny_e = (NGL == 2 || !(cy & 1)) ? 2 : 1, nz_e = DIM == 3 ? ((NGL == 2 || !(cz & 1)) ? 2 : 1) : 1;
-  const int ex0 = NGL == 3 ? (x0 >> 1) - 1 : x0 - 1;             // first element column the run can touch
-  for (int i = tid; i < GEX * ny_e * nz_e * GS && !(T.ablate & 1); i += 256) {
-    const int ge = i / GS, w = i - ge * GS;
-    const int gx = ge % GEX, gyz = ge / GEX, ys = gyz % ny_e, zs = gyz / ny_e;
-    const int ex = ex0 + gx;
-    const int ey = NGL == 2 ? cy - 1 + ys : ((cy & 1) ? (cy >> 1) : (cy >> 1) - 1 + ys);
-    const int ez = DIM == 3 ? (NGL == 2 ? cz - 1 + zs : ((cz & 1) ? (cz >> 1) : (cz >> 1) - 1 + zs)) : 0;
-    double v = 0.0;
-    if (ex >= 0 && ex < T.EX && ey >= 0 && ey < T.EY && (DIM == 2 || (ez >= 0 && ez < T.EZ)))
-      v = T.geom[(ex + (int64_t)T.EX * (ey + (int64_t)T.EY * ez)) * GS + w];
-    gl[i] = v;
-  }
-  for (int i = tid; i < T.img_len; i += 256) img[i] = 0.0;
-  const int routed = __syncthreads_or(any);
-
-  // ---- the (row, element, column node) triples of the run.  ngl 3: rows alternate vertex-like (two elements along x) / mid-node
-  //      (one), enumerated per row pair with three x-slots; ngl 2: every row has two elements along x
+  // lines of one launch are of one class: the number of elements around a line along y / z is the launch's
+  const int ny_e = (NGL == 2 || !T.par_y) ? 2 : 1, nz_e = DIM == 3 ? ((NGL == 2 || !T.par_z) ? 2 : 1) : 1;
   const int nyz = ny_e * nz_e, sh = nyz == 4 ? 2 : (nyz == 2 ? 1 : 0);
+
+  auto locate = [&](int w) {
+    Ho3Run q;
+    const int run = w % T.nruns;
+    int bid = w / T.nruns, so;
+    q.x0 = run * R;
+    q.nrows = min(R, NX - q.x0);
+    q.cz = 0;
+    if (DIM == 3) {
+      const int iy = bid % T.nly;
+      so = T.so0 + T.step * (bid / T.nly);
+      q.cy = NGL == 3 ? 2 * iy + T.par_y : iy;
+      q.cz = T.p_own0 + so;
+    } else {
+      so = T.so0 + T.step * bid;
+      q.cy = T.p_own0 + so;
+    }
+    q.zlo = 0;
+    q.n_z = 1;
+    axis_range<NGL>(q.cy, NYL, q.ylo, q.n_y);
+    if (DIM == 3) axis_range<NGL>(q.cz, T.npl, q.zlo, q.n_z);
+    q.row0 = DIM == 3 ? ((int64_t)so * T.NY + q.cy) * NX + q.x0 : (int64_t)so * NX + q.x0;
+    return q;
+  };
+  // first node id of plane (x-line in 2-D) j: in closed form for the numbering of a rank's slab (owned planes, ghost planes below,
+  // ghost planes above; verified on the host), from memory otherwise
+  const int PSZ = DIM == 3 ? NX * T.NY : NX;
+  auto pbase = [&](int j) -> int {
+    if (!T.pstd) return T.P[j];
+    const int p0 = T.p_own0, no = T.n_own;
+    return (j < p0 ? no + j : (j >= p0 + no ? j : j - p0)) * PSZ;
+  };
+  // requests (registers) ...
+  // (the offset of the line's first row comes through the scalar cache: the vector-memory path is busy with the stores of the runs
+  // before; the offsets of the other rows follow in closed form: x_prefix)
+  typedef const __attribute__((address_space(4))) int32_t* scalar_i32;
+  typedef const __attribute__((address_space(4))) uint32_t* scalar_u32;
+  int f_rpl = 0, f_flag = 0, f_p = 0;   // f_p: lane j < n_s of the first wave holds the first id of neighbour plane j
+  double f_gl[NGR];
+  auto fetch = [&](const Ho3Run& q) {
+    const int slo = DIM == 3 ? q.zlo : q.ylo, n_s = DIM == 3 ? q.n_z : q.n_y;
+    f_rpl = ((scalar_i32)T.rowptr)[q.row0 - q.x0];
+    if (tid < 64) f_p = tid < n_s ? pbase(slo + tid) : INT32_MAX;
+    // does the run see an imposed DOF?  (one byte of the flag array, through the scalar cache)
+    f_flag = 0;
+    if (T.runflag && !(T.ablate & 16)) f_flag = (((scalar_u32)T.runflag)[q.row0 >> 2] >> (8 * (int)(q.row0 & 3))) & 0xff;
+#pragma unroll
+    for (int u = 0; u < NGR; ++u) {
+      const int i = tid + 256 * u;
+      f_gl[u] = 0.0;
+      if (i < GEX * nyz * GS && !(T.ablate & 1)) {
+        const int ge = i / GS, w = i - ge * GS;
+        const int gx = ge % GEX, gyz = ge / GEX, ys = gyz % ny_e, zs = gyz / ny_e;
+        const int ex = (NGL == 3 ? (q.x0 >> 1) - 1 : q.x0 - 1) + gx;
+        const int ey = NGL == 2 ? q.cy - 1 + ys : ((q.cy & 1) ? (q.cy >> 1) : (q.cy >> 1) - 1 + ys);
+        const int ez = DIM == 3 ? (NGL == 2 ? q.cz - 1 + zs : ((q.cz & 1) ? (q.cz >> 1) : (q.cz >> 1) - 1 + zs)) : 0;
+        if (ex >= 0 && ex < T.EX && ey >= 0 && ey < T.EY && (DIM == 2 || (ez >= 0 && ez < T.EZ)))
+          f_gl[u] = T.geom[((T.ablate & 32) ? 0 : (ex + (int64_t)T.EX * (ey + (int64_t)T.EY * ez)) * GS) + w];
+      }
+    }
+  };
+  // ... and their place in LDS set `set`
+  auto stash = [&](int set, const Ho3Run& q) {
+    const int slo = DIM == 3 ? q.zlo : q.ylo, n_s = DIM == 3 ? q.n_z : q.n_y;
+    if (tid < 64) {   // (the whole first wave: readlane needs no particular lane alive)
+      int rk = 0;
+#pragma unroll
+      for (int j = 0; j < 5; ++j) rk += __builtin_amdgcn_readlane(f_p, j) < f_p;
+      if (tid < n_s) {
+        srank[set][tid] = rk;
+        splane[set][rk] = slo + tid;
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < NGR; ++u)
+      if (tid + 256 * u < GEX * nyz * GS) gl[set][tid + 256 * u] = f_gl[u];
+  };
+
+  int w = blockIdx.x;
+  if (w >= T.nwork) return;
+  Ho3Run q = locate(w);
+  fetch(q);
+  stash(0, q);
+  int flag_cur = f_flag, cur = 0, rpl_cur = f_rpl;
   // a lane keeps ONE column node b of the element (its lattice offsets are loop invariants); the 256 / NN groups of NN lanes walk the
   // (row, element) slots of the run
-  const int nslot = (NGL == 3 ? ((nrows + 1) >> 1) * 3 : nrows * 2) * nyz;
   constexpr int NG = 256 / NN;
   const int grp = tid / NN, b = tid - grp * NN;
   const int lbx = b % NGL, lby = (b / NGL) % NGL, lbz = b / (NGL * NGL);
   const int EYL = T.EY;
-  for (int t0 = grp; t0 < nslot && grp < NG && !(T.ablate & 1); t0 += NG) {
-    const int yz = t0 & (nyz - 1), t1 = t0 >> sh;
-    int cx, ex, la_x;
-    if (NGL == 3) {
-      const int pr = t1 / 3, xs = t1 - pr * 3;
-      cx = x0 + 2 * pr + (xs == 2);
-      ex = (x0 >> 1) + pr - (xs == 0);
-      la_x = xs == 0 ? 2 : (xs == 1 ? 0 : 1);
-    } else {
-      const int pr = t1 >> 1, xs = t1 & 1;
-      cx = x0 + pr;
-      ex = cx - 1 + xs;
-      la_x = 1 - xs;
-    }
-    if (cx >= NX || ex < 0 || ex >= T.EX) continue;
-    const int ys = yz & (ny_e - 1), zs = ny_e == 2 ? yz >> 1 : yz;
-    int ey, la_y, ez = 0, la_z = 0;
-    if (NGL == 2) {
-      ey = cy - 1 + ys;
-      la_y = 1 - ys;
-    } else if (cy & 1) {
-      ey = cy >> 1;
-      la_y = 1;
-    } else {
-      ey = (cy >> 1) - 1 + ys;
-      la_y = ys ? 0 : 2;
-    }
-    if (ey < 0 || ey >= EYL) continue;
-    if (DIM == 3) {
-      if (NGL == 2) {
-        ez = cz - 1 + zs;
-        la_z = 1 - zs;
-      } else if (cz & 1) {
-        ez = cz >> 1;
-        la_z = 1;
-      } else {
-        ez = (cz >> 1) - 1 + zs;
-        la_z = zs ? 0 : 2;
-      }
-      if (ez < 0 || ez >= T.EZ) continue;
-    }
-    const double* __restrict__ ge = gl + ((zs * ny_e + ys) * GEX + (ex - ex0)) * GS;
-    const int a = (la_z * NGL + la_y) * NGL + la_x;
-    int xlo, n_x;
-    axis_range<NGL>(cx, NX, xlo, n_x);
-    const int kx = M * ex + lbx - xlo, ky = M * ey + lby - ylo;
-    int k;
-    if (DIM == 3)
-      k = (srank[M * ez + lbz - zlo] * n_y + ky) * n_x + kx;
-    else
-      k = srank[ky] * n_x + kx;
-    const int r = cx - x0;
-    const int base = rowoff[r] * BB, len = rowoff[r + 1] - rowoff[r];
-    double v[3][3];
-    if (tens) {   // the record from the 1-D factors in LDS: the loop's only global loads are the element's J^-1, detJ
-      double rec[TabRec<DIM>::TS];
-      const int la[3] = {la_x, la_y, la_z}, lb[3] = {lbx, lby, lbz};
-      ho3_record_1d<DIM, NGL, MAT>(t1d, la, lb, rec);
-      ho3_block<DIM, MAT>(ge, rec, T.alpha_d, T.alpha_w, v);
-    } else {
-      ho3_block<DIM, MAT>(ge, T.tabs + (a * NN + b) * TabRec<DIM>::TS, T.alpha_d, T.alpha_w, v);
-    }
-    if (T.ablate & 4) {
-      if (v[0][0] == 1.2345e-300) img[0] = v[1][1] + v[2][2] + v[0][1] + v[1][0] + v[0][2] + v[2][0] + v[1][2] + v[2][1];
-      continue;
-    }
-    if (MAT == M_OP) {
-      for (int t = 0; t < T.nterms; ++t) {
-        const int d = T.t_der[t];
-        const double g = d == 0 ? v[0][0] : (d == 1 ? v[0][1] : v[0][2]);
-        atomicAdd(&img[base + (T.t_row[t] * len + k) * BC + T.t_col[t]], T.t_coef[t] * g);
-      }
-    } else {
+  for (;;) {
+    for (int i = tid; i < T.img_len; i += 256) img[i] = 0.0;
+    const bool routed = flag_cur != 0;
+    // a run that sees an imposed DOF: the Dirichlet bits of its node box and the places of its rows in a compact Krhs are asked for
+    // now and used after the triple loop (which needs neither)
+    int r_nb[NBR], r_rc = -1;
+    const bool compact = MAT != M_RW && T.Arhs && T.rcrow;
+    if (routed) {
 #pragma unroll
-      for (int p = 0; p < BRc; ++p)
-#pragma unroll
-        for (int q = 0; q < BCc; ++q) atomicAdd(&img[base + (p * len + k) * BCc + q], v[p][q]);
+      for (int u = 0; u < NBR; ++u) {
+        const int i = tid + 256 * u;
+        r_nb[u] = 0;
+        if (i < BOX) {
+          const int bx = i % BXW, by = (i / BXW) % BYW, bz = i / (BXW * BYW);
+          const int x = q.x0 - M + bx, y = q.cy - M + by, z = q.cz - M + bz;
+          if (x >= 0 && x < NX && y >= 0 && y < NYL && (DIM == 2 || (z >= 0 && z < T.npl))) {
+            const int64_t pz = pbase(DIM == 3 ? z : y);
+            r_nb[u] = T.nbits[DIM == 3 ? pz + (int64_t)y * NX + x : pz + x];
+          }
+        }
+      }
+      if (compact && tid < q.nrows) r_rc = T.rcrow[q.row0 + tid];
     }
-  }
-  __syncthreads();
+    __syncthreads();   // set `cur` is in place, the image is clear
+    const int wn = w + (int)gridDim.x;
+    const bool more = wn < T.nwork;
+    if (more) fetch(locate(wn));
+    const int x0 = q.x0, nrows = q.nrows, cy = q.cy, cz = q.cz, ylo = q.ylo, n_y = q.n_y, zlo = q.zlo;
+    // row offsets of the run relative to its first block: (x_prefix(x0 + r) - x_prefix(x0)) n_y n_z
+    const int nyzc = n_y * q.n_z, px0 = x_prefix<NGL>(x0, NX);
+    const int rp0 = rpl_cur + px0 * nyzc;
+    auto rel = [&](int r) { return (x_prefix<NGL>(x0 + r, NX) - px0) * nyzc; };
+    const int ex0 = NGL == 3 ? (x0 >> 1) - 1 : x0 - 1;             // first element column the run can touch
 
-  // ---- the piece of the value array(s) this run owns
-  if (T.ablate & 2) return;
-  const int64_t gbase = (int64_t)rp0 * BB;
-  double* __restrict__ outA = T.A;
-  double* __restrict__ outR = T.Arhs;
-  if (!routed) {
-    const int total = rowoff[nrows] * BB;
-    const bool zr = outR && !T.rhs_clean && !T.rcrow;   // (a compact matrix stores no row of a run without imposed DOFs)
-    if (T.ablate & 8) {   // A/B: one double per lane and store
-      for (int i = tid; i < total; i += 256) {
-        outA[gbase + i] = img[i];
-        if (zr) outR[gbase + i] = 0.0;
+    // ---- the (row, element, column node) triples of the run.  ngl 3: rows alternate vertex-like (two elements along x) / mid-node
+    //      (one), enumerated per row pair with three x-slots; ngl 2: every row has two elements along x
+    const int nslot = (NGL == 3 ? ((nrows + 1) >> 1) * 3 : nrows * 2) * nyz;
+    for (int t0 = grp; t0 < nslot && grp < NG && !(T.ablate & 1); t0 += NG) {
+      const int yz = t0 & (nyz - 1), t1 = t0 >> sh;
+      int cx, ex, la_x;
+      if (NGL == 3) {
+        const int pr = t1 / 3, xs = t1 - pr * 3;
+        cx = x0 + 2 * pr + (xs == 2);
+        ex = (x0 >> 1) + pr - (xs == 0);
+        la_x = xs == 0 ? 2 : (xs == 1 ? 0 : 1);
+      } else {
+        const int pr = t1 >> 1, xs = t1 & 1;
+        cx = x0 + pr;
+        ex = cx - 1 + xs;
+        la_x = 1 - xs;
       }
-      return;
-    }
-    // two doubles per lane and store (1 KiB per wave instruction; the piece starts on any double: 8-byte aligned pairs)
-    typedef double __attribute__((ext_vector_type(2), aligned(8))) d2u;
-    for (int i = 2 * tid; i + 1 < total; i += 512) {
-      d2u v2;
-      v2.x = img[i];
-      v2.y = img[i + 1];
-      *reinterpret_cast<d2u*>(outA + gbase + i) = v2;
-      if (zr) {
-        d2u z2;
-        z2.x = z2.y = 0.0;
-        *reinterpret_cast<d2u*>(outR + gbase + i) = z2;
+      if (cx >= NX || ex < 0 || ex >= T.EX) continue;
+      const int ys = yz & (ny_e - 1), zs = ny_e == 2 ? yz >> 1 : yz;
+      int ey, la_y, ez = 0, la_z = 0;
+      if (NGL == 2) {
+        ey = cy - 1 + ys;
+        la_y = 1 - ys;
+      } else if (cy & 1) {
+        ey = cy >> 1;
+        la_y = 1;
+      } else {
+        ey = (cy >> 1) - 1 + ys;
+        la_y = ys ? 0 : 2;
       }
-    }
-    if ((total & 1) && tid == 0) {
-      outA[gbase + total - 1] = img[total - 1];
-      if (zr) outR[gbase + total - 1] = 0.0;
-    }
-    return;
-  }
-  for (int r = 0; r < nrows; ++r) {   // (never the operators: they carry no Dirichlet elimination, mat_generator.py:157-170)
-    const int cx = x0 + r;
-    int xlo, n_x;
-    axis_range<NGL>(cx, NX, xlo, n_x);
-    const int base = rowoff[r] * BB, len = rowoff[r + 1] - rowoff[r], L1 = len * BC;
-    const int rowbits = nb[((BZW >> 1) * BYW + M) * BXW + r + M];
-    const int nxy = n_x * n_y;
-    // Arhs: same place as in A for a matrix with the graph's pattern, the row's own start in a compact one
-    int64_t rbase = gbase + base;
-    if (MAT != M_RW && outR && T.rcrow) {
-      const int rr = T.rcrow[row0 + r];
-      rbase = rr >= 0 ? (int64_t)rr * BB : -1;
-    }
-    for (int j = tid; j < len * BB; j += 256) {
-      const int p = BRc == 1 ? 0 : (j >= L1) + (BRc == 3 ? (j >= 2 * L1) : 0);
-      const int rem = j - p * L1;
-      const int k = rem / BCc, q = rem - k * BCc;
-      int dx, dy, dz = 0;
+      if (ey < 0 || ey >= EYL) continue;
       if (DIM == 3) {
-        const int kz = small_div(k, nxy), r2 = k - kz * nxy;
-        const int ky = small_div(r2, n_x);
-        dx = xlo + (r2 - ky * n_x) - cx;
-        dy = ylo + ky - cy;
-        dz = splane[kz] - cz;
-      } else {
-        const int ks = small_div(k, n_x);
-        dx = xlo + (k - ks * n_x) - cx;
-        dy = splane[ks] - cy;
+        if (NGL == 2) {
+          ez = cz - 1 + zs;
+          la_z = 1 - zs;
+        } else if (cz & 1) {
+          ez = cz >> 1;
+          la_z = 1;
+        } else {
+          ez = (cz >> 1) - 1 + zs;
+          la_z = zs ? 0 : 2;
+        }
+        if (ez < 0 || ez >= T.EZ) continue;
       }
-      const double v = img[base + j];
-      double va, vr;
-      if ((rowbits >> p) & 1) {   // imposed row: unit diagonal in K and Krhs (mat_generator.py:113-118), nothing in Rw
-        va = vr = (MAT != M_RW && dx == 0 && dy == 0 && dz == 0 && q == p) ? 1.0 : 0.0;
-      } else if (MAT != M_RW && ((nb[((dz + (BZW >> 1)) * BYW + dy + M) * BXW + r + M + dx] >> q) & 1)) {
-        va = 0.0;                  // imposed column of a free row: -K_e[free, bc] goes to Krhs (base_problem.py:531-533)
-        vr = -v;
+      const double* __restrict__ ge = gl[cur] + ((zs * ny_e + ys) * GEX + (ex - ex0)) * GS;
+      const int a = (la_z * NGL + la_y) * NGL + la_x;
+      int xlo, n_x;
+      axis_range<NGL>(cx, NX, xlo, n_x);
+      const int kx = M * ex + lbx - xlo, ky = M * ey + lby - ylo;
+      int k;
+      if (DIM == 3)
+        k = (srank[cur][M * ez + lbz - zlo] * n_y + ky) * n_x + kx;
+      else
+        k = srank[cur][ky] * n_x + kx;
+      const int r = cx - x0;
+      const int base = rel(r) * BB, len = n_x * nyzc;
+      double v[3][3];
+      if (DG) {   // axis-aligned boxes (and 1-D factors): the block straight from them
+        const int la[3] = {la_x, la_y, la_z}, lb[3] = {lbx, lby, lbz};
+        ho3_block_diag<DIM, NGL, MAT>(ge, t1d, la, lb, T.alpha_d, T.alpha_w, v);
+      } else if (tens) {   // the record from the 1-D factors in LDS: the loop makes no global load
+        double rec[TabRec<DIM>::TS];
+        const int la[3] = {la_x, la_y, la_z}, lb[3] = {lbx, lby, lbz};
+        ho3_record_1d<DIM, NGL, MAT>(t1d, la, lb, rec);
+        ho3_block<DIM, MAT>(ge, rec, T.alpha_d, T.alpha_w, v);
       } else {
-        va = v;
-        vr = 0.0;
+        ho3_block<DIM, MAT>(ge, T.tabs + (a * NN + b) * TabRec<DIM>::TS, T.alpha_d, T.alpha_w, v);
       }
-      outA[gbase + base + j] = va;
-      if (MAT != M_RW && outR && rbase >= 0) outR[rbase + j] = vr;
+      if (T.ablate & 4) {
+        if (v[0][0] == 1.2345e-300) img[0] = v[1][1] + v[2][2] + v[0][1] + v[1][0] + v[0][2] + v[2][0] + v[1][2] + v[2][1];
+        continue;
+      }
+      if (MAT == M_OP) {
+        for (int t = 0; t < T.nterms; ++t) {
+          const int d = T.t_der[t];
+          const double g = d == 0 ? v[0][0] : (d == 1 ? v[0][1] : v[0][2]);
+          atomicAdd(&img[base + (T.t_row[t] * len + k) * BC + T.t_col[t]], T.t_coef[t] * g);
+        }
+      } else {
+#pragma unroll
+        for (int p = 0; p < BRc; ++p)
+#pragma unroll
+          for (int q2 = 0; q2 < BCc; ++q2) atomicAdd(&img[base + (p * len + k) * BCc + q2], v[p][q2]);
+      }
+    }
+    __syncthreads();
+    if (more) {   // (requested a whole triple loop ago; the run's position is recomputed rather than kept in registers)
+      int w2 = wn;
+      asm volatile("" : "+s"(w2));
+      stash(cur ^ 1, locate(w2));
+    }
+
+    // ---- the piece of the value array(s) this run owns
+    const int64_t gbase = (int64_t)rp0 * BB;
+    double* __restrict__ outA = T.A;
+    double* __restrict__ outR = T.Arhs;
+    if (routed && !(T.ablate & 2)) {
+      // Dirichlet elimination of a run with an imposed DOF in its node box, applied IN the image one (row, column node) pair at a
+      // time -- most pairs have neither an imposed row nor an imposed column and are left alone; the Krhs entries go straight to
+      // memory (all of a stored row's entries, zeros included: a compact matrix is written in full by every assembly).  The image
+      // then leaves through the same coalesced copy as every other run.  (Never the operators: they carry no elimination,
+      // mat_generator.py:157-170.)
+#pragma unroll
+      for (int u = 0; u < NBR; ++u)
+        if (tid + 256 * u < BOX) nb[tid + 256 * u] = (unsigned char)r_nb[u];
+      if (compact && tid < nrows) rcs[tid] = r_rc;
+      __syncthreads();
+      const int npairs = rel(nrows);
+      for (int pr = tid; pr < npairs; pr += 256) {
+        int r = 0;
+        while (r + 1 < nrows && pr >= rel(r + 1)) ++r;
+        const int k = pr - rel(r);
+        const int cx = x0 + r;
+        int xlo, n_x;
+        axis_range<NGL>(cx, NX, xlo, n_x);
+        const int base = rel(r) * BB, len = n_x * nyzc;
+        int dx, dy, dz = 0;
+        if (DIM == 3) {
+          const int nxy = n_x * n_y;
+          const int kz = small_div(k, nxy), r2 = k - kz * nxy;
+          const int ky = small_div(r2, n_x);
+          dx = xlo + (r2 - ky * n_x) - cx;
+          dy = ylo + ky - cy;
+          dz = splane[cur][kz] - cz;
+        } else {
+          const int ks = small_div(k, n_x);
+          dx = xlo + (k - ks * n_x) - cx;
+          dy = splane[cur][ks] - cy;
+        }
+        const int rowbits = nb[((BZW >> 1) * BYW + M) * BXW + r + M];
+        const int colbits = MAT == M_RW ? 0 : nb[((dz + (BZW >> 1)) * BYW + dy + M) * BXW + r + M + dx];
+        // Arhs: same place as in A for a matrix with the graph's pattern, the row's own start in a compact one (-1: row not stored)
+        int64_t rbase = -1;
+        if (MAT != M_RW && outR) rbase = compact ? (rcs[r] >= 0 ? (int64_t)rcs[r] * BB : -1) : gbase + base;
+        if (!(rowbits | colbits) && rbase < 0) continue;
+        const bool diag = dx == 0 && dy == 0 && dz == 0;
+#pragma unroll
+        for (int p = 0; p < BRc; ++p)
+#pragma unroll
+          for (int q2 = 0; q2 < BCc; ++q2) {
+            const int idx = (p * len + k) * BCc + q2;
+            const double v = img[base + idx];
+            double va, vr;
+            if ((rowbits >> p) & 1) {   // imposed row: unit diagonal in K and Krhs (mat_generator.py:113-118), nothing in Rw
+              va = vr = (MAT != M_RW && diag && q2 == p) ? 1.0 : 0.0;
+            } else if ((colbits >> q2) & 1) {
+              va = 0.0;                  // imposed column of a free row: -K_e[free, bc] goes to Krhs (base_problem.py:531-533)
+              vr = -v;
+            } else {
+              va = v;
+              vr = 0.0;
+            }
+            if (rowbits | colbits) img[base + idx] = va;
+            if (rbase >= 0) outR[rbase + idx] = vr;
+          }
+      }
+      __syncthreads();
+    }
+    if (!(T.ablate & 2)) {
+      const int total = rel(nrows) * BB;
+      const bool zr = !routed && outR && !T.rhs_clean && !T.rcrow;   // (a compact matrix stores no row of a run without imposed DOFs)
+      if (T.ablate & 8) {   // A/B: one double per lane and store
+        for (int i = tid; i < total; i += 256) {
+          outA[gbase + i] = img[i];
+          if (zr) outR[gbase + i] = 0.0;
+        }
+      } else {
+        // two doubles per lane and store (1 KiB per wave instruction; the piece starts on any double: 8-byte aligned pairs)
+        typedef double __attribute__((ext_vector_type(2), aligned(8))) d2u;
+        for (int i = 2 * tid; i + 1 < total; i += 512) {
+          d2u v2;
+          v2.x = img[i];
+          v2.y = img[i + 1];
+          *reinterpret_cast<d2u*>(outA + gbase + i) = v2;
+          if (zr) {
+            d2u z2;
+            z2.x = z2.y = 0.0;
+            *reinterpret_cast<d2u*>(outR + gbase + i) = z2;
+          }
+        }
+        if ((total & 1) && tid == 0) {
+          outA[gbase + total - 1] = img[total - 1];
+          if (zr) outR[gbase + total - 1] = 0.0;
+        }
+      }
+    }
+    if (!more) break;
+    __syncthreads();   // the image and set `cur` have been read: the next run may clear / replace them
+    w = wn;
+    asm volatile("" : "+s"(w));
+    q = locate(w);
+    cur ^= 1;
+    flag_cur = f_flag;
+    rpl_cur = f_rpl;
+  }
+}
+
+// Which runs see an imposed DOF at all?  One byte per owned node that starts a run of R rows: the OR of the Dirichlet bits over the
+// node box around the run (M nodes on every side).  Once per Dirichlet set and run length; the assembly reads it through the scalar
+// cache and touches the bits themselves only in the runs that need the elimination.
+__global__ void ho3_runflag_kernel(Ho3Args T, int dim, int M, int R, int64_t n_owned, uint8_t* __restrict__ flag) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n_owned) return;
+  const int NX = T.NX, NYL = dim == 3 ? T.NY : T.npl;
+  const int x0 = (int)(i % NX);
+  if (x0 % R) return;
+  int cy, cz = 0;
+  if (dim == 3) {
+    cy = (int)((i / NX) % T.NY);
+    cz = T.p_own0 + (int)(i / ((int64_t)NX * T.NY));
+  } else {
+    cy = T.p_own0 + (int)(i / NX);
+  }
+  int any = 0;
+  for (int z = (dim == 3 ? cz - M : 0); z <= (dim == 3 ? cz + M : 0); ++z) {
+    if (dim == 3 && (z < 0 || z >= T.npl)) continue;
+    for (int y = cy - M; y <= cy + M; ++y) {
+      if (y < 0 || y >= NYL) continue;
+      const int64_t base = dim == 3 ? (int64_t)T.P[z] + (int64_t)y * NX : (int64_t)T.P[y];
+      for (int x = max(0, x0 - M); x <= min(NX - 1, x0 + R - 1 + M); ++x) any |= T.nbits[base + x];
     }
   }
+  flag[i] = (uint8_t)any;
 }
 
 // ---- symbolic phase in closed form: row lengths -> scan -> sorted columns
@@ -737,6 +1008,7 @@ void fill_lattice_args(const pyn_ctx* c, Ho3Args& T) {
   T.P = L.d_P;
   T.rowptr = c->d_rowptr;
   T.nbits = nullptr;
+  T.runflag = nullptr;
   T.geom = L.d_geom;
   T.tabs = c->d_ho3_tabs;
   T.tabs1d = c->ho3_tens_ok ? c->d_ho3_t1d : nullptr;
@@ -745,10 +1017,20 @@ void fill_lattice_args(const pyn_ctx* c, Ho3Args& T) {
   T.rhs_clean = 0;
   T.rcrow = nullptr;
   T.par_y = T.par_z = 0;
-  T.nruns = T.nly = 0;
+  T.nruns = T.nly = T.nwork = 0;
   T.so0 = 0;
   T.img_len = 0;
   T.step = L.ngl == 3 ? 2 : 1;
+  T.diag = L.diag == 1 && !getenv("PYNAMA_HO3_NO_DIAG");
+  {
+    const int64_t PS = L.dim == 3 ? (int64_t)L.NX * L.NY : L.NX;
+    bool std_p = !getenv("PYNAMA_HO3_NO_PSTD") && PS * L.npl < (int64_t)INT32_MAX;
+    for (int j = 0; j < L.npl && std_p; ++j) {
+      const int64_t want = (j < L.p_own0 ? L.n_own + j : (j >= L.p_own0 + L.n_own ? j : j - L.p_own0)) * PS;
+      std_p = L.P[j] == want;
+    }
+    T.pstd = std_p;
+  }
   {
     const char* ab = getenv("PYNAMA_HO3_ABLATE");
     T.ablate = ab ? atoi(ab) : 0;
@@ -757,17 +1039,28 @@ void fill_lattice_args(const pyn_ctx* c, Ho3Args& T) {
   T.nterms = 0;
 }
 
-template <int DIM, int NGL, int MAT, int R>
-int launch_ho3(pyn_ctx* c, Ho3Args T) {
+template <int DIM, int NGL, int MAT, int R, bool DG>
+int launch_ho3_g(pyn_ctx* c, Ho3Args T) {
   const int BR = MAT == M_OP ? T.obr : (MAT == M_LAP ? 1 : DIM);
   const int BC = MAT == M_OP ? T.obc : (MAT == M_K ? DIM : (MAT == M_RW ? (DIM == 3 ? 3 : 1) : 1));
-  const Ho3Lattice& L = c->ho3;
+  Ho3Lattice& L = c->ho3;
   T.nruns = (L.NX + R - 1) / R;
   static bool attr_done = false;
   if (!attr_done) {
-    PYN_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(assemble_ho3_lattice_kernel<DIM, NGL, MAT, R>),
+    PYN_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(assemble_ho3_lattice_kernel<DIM, NGL, MAT, R, DG>),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));
     attr_done = true;
+  }
+  T.runflag = nullptr;
+  if (T.nbits) {   // which runs see an imposed DOF: once per Dirichlet set and run length
+    if (L.runflag_stamp != c->bc_stamp || L.runflag_R != R) {
+      if (!L.d_runflag) PYN_HIP(hipMalloc((void**)&L.d_runflag, (size_t)c->n_owned + 8));
+      ho3_runflag_kernel<<<(int)((c->n_owned + 255) / 256), 256, 0, c->stream>>>(T, DIM, NGL - 1, R, c->n_owned, L.d_runflag);
+      PYN_HIP(hipGetLastError());
+      L.runflag_stamp = c->bc_stamp;
+      L.runflag_R = R;
+    }
+    T.runflag = L.d_runflag;
   }
   // ngl 3: one launch per class of x-lines (parity of y, z), its LDS sized for that class; ngl 2: every line is of one class
   const int ncls = NGL == 3 ? 2 : 1;
@@ -797,10 +1090,30 @@ int launch_ho3(pyn_ctx* c, Ho3Args T) {
       }
       const size_t lds = (size_t)T.img_len * sizeof(double);
       PYN_CHECK(lds <= 128 * 1024, "lattice row-run assembly: %zu B of LDS per run", lds);
-      assemble_ho3_lattice_kernel<DIM, NGL, MAT, R><<<(int)grid, 256, lds, c->stream>>>(T);
+      // as many workgroups as the device holds at once; each walks its share of the runs (PYNAMA_HO3_WGS_PER_CU: fewer / more)
+      static size_t occ_lds[4] = {0, 0, 0, 0};
+      static int occ_wgs[4] = {0, 0, 0, 0};
+      const int cls = 2 * pz + py;
+      if (occ_lds[cls] != lds || !occ_wgs[cls]) {
+        PYN_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ_wgs[cls], assemble_ho3_lattice_kernel<DIM, NGL, MAT, R, DG>, 256, lds));
+        occ_lds[cls] = lds;
+      }
+      int per_cu = std::max(1, occ_wgs[cls]);
+      if (const char* e = getenv("PYNAMA_HO3_WGS_PER_CU")) per_cu = std::max(1, atoi(e));
+      T.nwork = (int)grid;
+      int64_t launch = std::min<int64_t>(grid, (int64_t)per_cu * 256);   // 256 CUs (gfx950)
+      if (const char* e = getenv("PYNAMA_HO3_GRID")) launch = std::min<int64_t>(grid, std::max(1, atoi(e)));   // tests: many runs per workgroup
+      assemble_ho3_lattice_kernel<DIM, NGL, MAT, R, DG><<<(int)launch, 256, lds, c->stream>>>(T);
     }
   PYN_HIP(hipGetLastError());
   return PYN_OK;
+}
+
+// axis-aligned boxes with verified 1-D factors take the kernels that build the blocks straight from them
+template <int DIM, int NGL, int MAT, int R>
+int launch_ho3(pyn_ctx* c, const Ho3Args& T) {
+  if (T.diag && T.tabs1d) return launch_ho3_g<DIM, NGL, MAT, R, true>(c, T);
+  return launch_ho3_g<DIM, NGL, MAT, R, false>(c, T);
 }
 
 // rows per run: tuned on 1024^2 / 64^3 (ngl 3); PYNAMA_HO3_RUN overrides (tests walk every length)
@@ -835,8 +1148,8 @@ int ho3_prepare(pyn_ctx* c, bool* ok) {
   DevTmp flag;
   int* d_flag = nullptr;
   if (L.affine < 0) {   // once per mesh
-    PYN_HIP(flag.alloc(sizeof(int)));
-    PYN_HIP(hipMemsetAsync(flag.p, 0, sizeof(int), s));
+    PYN_HIP(flag.alloc(2 * sizeof(int)));   // [0] some cell is not affine, [1] some J is not diagonal
+    PYN_HIP(hipMemsetAsync(flag.p, 0, 2 * sizeof(int), s));
     d_flag = flag.as<int>();
   }
   // J^-1, detJ of every element (part of the numeric phase: runs inside the timed region of every assembly)
@@ -846,10 +1159,11 @@ int ho3_prepare(pyn_ctx* c, bool* ok) {
     ho3_geom_kernel<2><<<ge, 256, 0, s>>>(c->d_conn, c->d_xyz, c->n_elem, c->nn, c->quad[0].HrsCoo, L.d_geom, d_flag);
   PYN_HIP(hipGetLastError());
   if (d_flag) {
-    int h = 1;
-    PYN_HIP(hipMemcpyAsync(&h, d_flag, sizeof(int), hipMemcpyDeviceToHost, s));
+    int h[2] = {1, 1};
+    PYN_HIP(hipMemcpyAsync(h, d_flag, 2 * sizeof(int), hipMemcpyDeviceToHost, s));
     PYN_HIP(hipStreamSynchronize(s));
-    L.affine = h ? 0 : 1;
+    L.affine = h[0] ? 0 : 1;
+    L.diag = (h[0] || h[1]) ? 0 : 1;
   }
   *ok = L.affine == 1 && !getenv("PYNAMA_NO_HO3_LATTICE");
   return PYN_OK;
@@ -862,6 +1176,7 @@ void pyn_ho3_release(pyn_ctx* c) {
   (void)hipFree(L.d_P);
   (void)hipFree(L.d_geom);
   (void)hipFree(L.d_nbits);
+  (void)hipFree(L.d_runflag);
   L = Ho3Lattice();
 }
 

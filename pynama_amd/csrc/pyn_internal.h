@@ -153,9 +153,13 @@ struct Ho3Lattice {
   int32_t* d_P = nullptr;       // [npl]
   std::vector<int32_t> P;
   int affine = -1;              // every element a parallelogram / parallelepiped? (-1: not checked yet)
+  int diag = 0;                 // ... and axis-aligned (J diagonal): set with `affine`
   double* d_geom = nullptr;     // [n_elem][6 | 10]: J^-1 (row = physical axis) and det J, rewritten by every assembly
   uint8_t* d_nbits = nullptr;   // per local node: bit p = DOF p imposed (packed copy of d_bcmask)
   int64_t nbits_stamp = -1;     // pyn_ctx::bc_stamp the packed copy belongs to
+  uint8_t* d_runflag = nullptr; // per owned node that starts a run: does the run's node box hold an imposed DOF?
+  int64_t runflag_stamp = -1;   // ... for this Dirichlet set
+  int runflag_R = 0;            // ... and this run length
 };
 
 struct SellShape {

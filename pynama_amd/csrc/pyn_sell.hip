@@ -460,8 +460,17 @@ __global__ void __launch_bounds__(64 * CSRLB_WAVES) csrlb_spmv_kernel(const int3
           __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(v + e),
                                            (__attribute__((address_space(3))) void*)(buf + 128 * j), 16, 0, 0);
       }
+      if (BC == 2 && W % 2 == 0) {   // the two x entries of a column node by one 16-byte load
 #pragma unroll
-      for (int k = 0; k < W; ++k) xg[k] = x[(nb + (k < L1 ? t[k / BC] : 0)) * BC + (k < L1 ? k % BC : 0)];
+        for (int kk = 0; kk < W / 2; ++kk) {
+          const double2 xv = *reinterpret_cast<const double2*>(x + (nb + (2 * kk < L1 ? t[kk] : 0)) * 2);
+          xg[2 * kk] = xv.x;
+          xg[2 * kk + 1] = xv.y;
+        }
+      } else {
+#pragma unroll
+        for (int k = 0; k < W; ++k) xg[k] = x[(nb + (k < L1 ? t[k / BC] : 0)) * BC + (k < L1 ? k % BC : 0)];
+      }
       if ((total & 1) && lane == 0) buf[total - 1] = v[total - 1];
       __builtin_amdgcn_s_waitcnt(0x0070);   // vmcnt(0) lgkmcnt(0): the DMA writes and the one plain LDS write have landed
     } else {

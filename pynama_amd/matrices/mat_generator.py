@@ -97,18 +97,21 @@ class DeviceMat:
             raise NotImplementedError("Mat.setValues with global indices on more than one rank: use the fused assemblies")
         self.ctx.mat_add_values(self.id, rows, cols, values, insert=not addv)
         self._host_values = True
+        self.matfree = None              # no longer the operator a fused assembly tagged (KspSolver would multiply with its shell)
 
     def setValue(self, row, col, value, addv=None):
         self.setValues([row], [col], [value], addv)
 
     def zeroEntries(self):
         self.ctx.mat_zero(self.id)
+        self.matfree = None
 
     def diagonalScale(self, L=None, R=None):
         if R is not None:
             raise NotImplementedError("column scaling is not used by the reference path")
         if L is not None:
             self.ctx.mat_row_scale(self.id, L.id)
+            self.matfree = None
 
     def getDiagonal(self, result=None):
         v = result or Vec(self.ctx, self.br)

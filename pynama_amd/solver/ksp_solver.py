@@ -9,7 +9,10 @@ Mirrors ``src/solver/ksp_solver.py:6-19`` (``KspSolver(KSP)``: ``createSolver(ma
 (GMRES orthogonalisation; default as in PETSc: classical Gram-Schmidt without refinement).
 ``-pynama_mat_free`` (not a PETSc name; PETSc's analogue is KSPSetOperators(Amat = MATSHELL, Pmat = assembled)): CG multiplies
 with the matrix-free form of the operator when the matrix carries one (``Mat.K`` on structured Q1 hex meshes) -- the
-assembled matrix then only supplies the Jacobi diagonal and the exit check; the library verifies that both agree.
+assembled matrix then only supplies the Jacobi diagonal and the exit check; the library verifies that both agree on ``b``
+before it iterates.  Without the option the choice is automatic: CG (and the symmetric ``preonly`` substitute) take the shell
+whenever the matrix carries one -- 4 x the iteration rate of the assembled product at 128^3 -- and go back to the assembled
+product, with a warning, if the library finds that the two differ; ``-pynama_mat_free 0`` keeps the assembled product.
 
 The reference's hard-wired default is ``preonly`` + ``lu`` (:13-16).  Systems of up to ``-pynama_direct_max_rows`` rows
 (default 8192 = the library's limit; one rank) ARE solved directly: ``pyn_solve_direct`` factors the matrix densely with partial pivoting once
@@ -44,7 +47,7 @@ class KspSolver(object):
         self.restart = 30
         self.gmres_orthog = 1            # KSPGMRES default: classical Gram-Schmidt, refine_never
         self.norm_type = "preconditioned"
-        self.mat_free = False
+        self.mat_free = None             # None: automatic (the shell when the matrix carries one); True / False: -pynama_mat_free
         self.direct_max_rows = 8192      # preonly/lu: dense LU up to this many rows (the library's limit), the Krylov substitute above
         self.info = None
         self._symmetric = None
@@ -76,7 +79,8 @@ class KspSolver(object):
         self.max_it = o.getInt('ksp_max_it', self.max_it)
         self.restart = o.getInt('ksp_gmres_restart', self.restart)
         self.norm_type = o.getString('ksp_norm_type', self.norm_type)
-        self.mat_free = o.hasName('pynama_mat_free') and str(o.getString('pynama_mat_free', '1')).lower() not in ('0', 'false', 'no')
+        self.mat_free = (str(o.getString('pynama_mat_free', '1')).lower() not in ('0', 'false', 'no')
+                         if o.hasName('pynama_mat_free') else None)
         self.direct_max_rows = o.getInt('pynama_direct_max_rows', self.direct_max_rows)
         if o.hasName('ksp_gmres_modifiedgramschmidt'):
             self.gmres_orthog = 2
@@ -124,13 +128,25 @@ class KspSolver(object):
 
     def solve(self, b, x):
         A = self.mat
-        ctx = A.ctx
         mf = _lib.MATFREE_OFF
+        tag = getattr(A, 'matfree', None)              # set by the assembly that built the matrix (Mat.assembleKLE)
         if self.mat_free:
-            tag = getattr(A, 'matfree', None)          # set by the assembly that built the matrix (Mat.assembleKLE)
             if tag is None:
                 raise ValueError("-pynama_mat_free: this operator has no matrix-free form (structured Q1 hex meshes only)")
             mf = tag
+        elif self.mat_free is None and tag is not None and self.ksp_type in ('cg', 'preonly'):
+            try:                                       # automatic: the shell, unless the library finds it differs from A
+                return self._solve(A, b, x, tag)
+            except _lib.PynamaHipError as e:
+                if "matrix-free operator differs" not in str(e):
+                    raise
+                self.logger and self.logger.warning(f"{e}; solving with the assembled matrix")
+                A.matfree = None
+        return self._solve(A, b, x, mf)
+
+    def _solve(self, A, b, x, mf):
+        ctx = A.ctx
+        self.shell_used = bool(mf)                     # which product the Krylov loop multiplies with
         n_rows = ctx.n_owned * A.br
         if (self.ksp_type == 'preonly' and not self.mat_free and A.br == A.bc and ctx.nranks == 1 and ctx.n_ghost == 0
                 and n_rows <= min(self.direct_max_rows, ctx.direct_max_rows())):

@@ -128,5 +128,9 @@ def test_ksp_solver_options_host():
         k = KspSolver()
         k.createSolver(None, None)
         assert (k.ksp_type, k.pc_type, k.mat_free) == ("gmres", "none", False)
+        Options(["-ksp_type", "cg", "-pc_type", "jacobi"])
+        k = KspSolver()
+        k.createSolver(None, None)
+        assert k.mat_free is None                              # automatic: the shell when the matrix carries one
     finally:
         Options([])

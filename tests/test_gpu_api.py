@@ -71,21 +71,43 @@ def test_solveKLE_matrix_free_option(jitter):
     from common.options import Options
     base = ["-ksp_type", "cg", "-pc_type", "jacobi", "-ksp_rtol", "1e-11", "-ksp_norm_type", "unpreconditioned"]
     try:
-        Options(base)
+        Options(base + ["-pynama_mat_free", "0"])                 # the assembled product
         kw = dict(lower=[0, 0, 0], upper=[1, 1, 1], nelem=[9, 8, 7], ngl=2, jitter=jitter)
         fem = setFemProblem('uniform', **kw)
         exactVel, exactVort = fem.generateExactVecs()
         fem.solveKLE(time=0.0, vort=exactVort)
+        assert fem.solver.mat_free is False and not fem.solver.shell_used
         v0, it0 = fem.vel.getArray().copy(), fem.solver.getIterationNumber()
+        for opts in (["-pynama_mat_free"], []):                   # asked for / chosen automatically (the default)
+            Options(base + opts)
+            fem = setFemProblem('uniform', **kw)
+            assert fem.solver.mat_free is (True if opts else None) and fem.mat.K.matfree is not None
+            exactVel, exactVort = fem.generateExactVecs()
+            fem.solveKLE(time=0.0, vort=exactVort)
+            assert fem.solver.shell_used
+            assert fem.solver.getConvergedReason() == 2 and abs(fem.solver.getIterationNumber() - it0) <= 3
+            assert fem.solver.info.true_resid <= 1e-10
+            assert np.abs(fem.vel.getArray() - v0).max() < 1e-9
+            assert (exactVel - fem.vel).norm(norm_type=3) < 1e-8
+        # automatic choice, but K was changed behind the tag's back (scaled rows): the library finds that shell and matrix differ on b,
+        # the facade warns and solves with the assembled matrix -- (D K) v = D b has the solution of K v = b
+        from pynama_amd.vectors import Vec
+        K = fem.mat.K
+        d = Vec(K.ctx, 3)
+        d.setArray(np.random.default_rng(2).uniform(0.5, 2.0, K.ctx.n_owned * 3))
+        K.ctx.mat_row_scale(K.id, d.id)
+        assert K.matfree is not None
+        rhs = K * exactVel
+        out = exactVel.duplicate()
+        assert fem.solver.mat is K and fem.solver.ksp_type == 'cg'
+        fem.solver.rtol = 1e-30
+        fem.solver.max_it = 5                                      # only the choice of the product is under test
+        fem.solver(rhs, out)
+        assert not fem.solver.shell_used and K.matfree is None
+        fem2d = setFemProblem('uniform')                           # no shell: automatic = assembled, asking for it = error
+        fem2d.solveKLE(time=0.0, vort=fem2d.generateExactVecs()[1])
+        assert not fem2d.solver.shell_used
         Options(base + ["-pynama_mat_free"])
-        fem = setFemProblem('uniform', **kw)
-        assert fem.solver.mat_free and fem.mat.K.matfree is not None
-        exactVel, exactVort = fem.generateExactVecs()
-        fem.solveKLE(time=0.0, vort=exactVort)
-        assert fem.solver.getConvergedReason() == 2 and abs(fem.solver.getIterationNumber() - it0) <= 3
-        assert fem.solver.info.true_resid <= 1e-10
-        assert np.abs(fem.vel.getArray() - v0).max() < 1e-9
-        assert (exactVel - fem.vel).norm(norm_type=3) < 1e-8
         fem2d = setFemProblem('uniform')
         with pytest.raises(ValueError, match="no matrix-free form"):
             fem2d.solveKLE(time=0.0, vort=fem2d.generateExactVecs()[1])

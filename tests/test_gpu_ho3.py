@@ -23,11 +23,11 @@ def lib():
     return _lib
 
 
-def make_ctx(lib, mesh, mask=None, ndof=None):
+def make_ctx(lib, mesh, mask=None, ndof=None, ngl=3):
     from pynama_amd.elements.spectral import Spectral
     ctx = lib.Context(0)
     ctx.mesh_set(mesh.dim, mesh.conn, mesh.xyz)
-    for t in Spectral(3, mesh.dim).deviceTables():
+    for t in Spectral(ngl, mesh.dim).deviceTables():
         ctx.tables_set(*t)
     if mask is not None:
         ctx.bc_set(ndof, mask)
@@ -35,11 +35,11 @@ def make_ctx(lib, mesh, mask=None, ndof=None):
     return ctx
 
 
-def oracle_kle(mesh, mask):
+def oracle_kle(mesh, mask, ngl=3):
     """assemble_kle_freeslip with a per-DOF mask [n_node, dim] (the oracle's own routine takes node sets)"""
     import scipy.sparse as sp
     dim = mesh.dim
-    tb = fo.Tables(3, dim)
+    tb = fo.Tables(ngl, dim)
     dw = tb.dim_w
     Ke, Rwe, _ = fo.elem_kle_matrices(tb, mesh.corners())
     n = mesh.n_node
@@ -122,6 +122,34 @@ def test_run_lengths(lib, nelem, run):
     finally:
         del os.environ["PYNAMA_HO3_RUN"]
     ref = fo.assemble_kle_freeslip(mesh, fo.Tables(3, dim))
+    assert sp_rel_err(mat_to_scipy(ctx, K, dim, dim), ref["K"]) < FP_TOL
+    assert sp_rel_err(mat_to_scipy(ctx, Krhs, dim, dim), ref["Krhs"]) < FP_TOL
+    assert sp_rel_err(mat_to_scipy(ctx, Rw, dim, dw), ref["Rw"]) < FP_TOL
+    ctx.close()
+
+
+@pytest.mark.parametrize("nelem,ngl,grid", [([19, 6], 3, 1), ([19, 6], 3, 3), ([5, 4, 3], 3, 2), ([5, 4, 3], 3, 7), ([11, 9], 2, 2)])
+def test_workgroups_walk_many_runs(lib, nelem, ngl, grid):
+    """the row-run kernel is persistent: a workgroup handles runs w, w + grid, ... with the next run's row offsets, Dirichlet bits and
+    geometry requested one run ahead.  PYNAMA_HO3_GRID forces 1 / 2 / 3 / 7 workgroups per launch, i.e. tens of runs each (odd and even
+    counts, so both LDS sets end a launch), with imposed DOFs scattered inside the mesh: the matrices are the oracle's"""
+    dim = len(nelem)
+    dw = 1 if dim == 2 else 3
+    mesh = fo.box_mesh(nelem, [0.0] * dim, [1.0, 0.7, 1.3][:dim], ngl)
+    mask = boundary_mask(mesh)
+    rng = np.random.default_rng(17)
+    mask[rng.choice(mesh.n_node, max(3, mesh.n_node // 40), replace=False), rng.integers(0, dim)] = 1
+    ctx = make_ctx(lib, mesh, boundary_mask(mesh), dim, ngl=ngl)
+    ctx.bc_set(dim, mask)
+    K, Krhs, Rw = ctx.mat_create(dim, dim), ctx.mat_create_rhs(dim, dim), ctx.mat_create(dim, dw)
+    os.environ["PYNAMA_HO3_GRID"] = str(grid)
+    os.environ["PYNAMA_HO3_REQUIRE"] = "1"
+    try:
+        ctx.assemble_kle(1e3, 1e2, K, Krhs, Rw, -1)
+        ctx.assemble_kle(1e3, 1e2, K, Krhs, Rw, -1)
+    finally:
+        del os.environ["PYNAMA_HO3_GRID"], os.environ["PYNAMA_HO3_REQUIRE"]
+    ref = oracle_kle(mesh, mask, ngl=ngl)
     assert sp_rel_err(mat_to_scipy(ctx, K, dim, dim), ref["K"]) < FP_TOL
     assert sp_rel_err(mat_to_scipy(ctx, Krhs, dim, dim), ref["Krhs"]) < FP_TOL
     assert sp_rel_err(mat_to_scipy(ctx, Rw, dim, dw), ref["Rw"]) < FP_TOL
