@@ -479,6 +479,7 @@ def config_tets(_lib, DMPlexDom, n, gmres_iters):
     ctx.assemble_scalar(_lib.FORM_LAPLACE, A)
     med, best = median_assembly(ctx, lambda: ctx.assemble_scalar(_lib.FORM_LAPLACE, A), 5)
     ne = conn.shape[0]
+    npatch, maxrows, maxlen, npe = ctx.patch_plan_info(0)
     B_asm, B_spmv, _ = algorithmic_bytes(ne, n_rows, nnz, nn=4)
     vb, vx, vy = ctx.vec_create(1), ctx.vec_create(1), ctx.vec_create(1)
     ctx.vec_set(vb, smooth_load(dom.xyz[:dom.nOwned], 1.0 / n ** 3, bm[:dom.nOwned]))
@@ -499,6 +500,10 @@ def config_tets(_lib, DMPlexDom, n, gmres_iters):
            "n_elem": ne, "n_dof": n_rows, "nnz": nnz, "assembly_ms": med, "element_dofs_per_s": ne * 4 / (med * 1e-3),
            "assembly_frac_of_hbm_peak": B_asm / (med * 1e-3) / 1e9 / HBM_PEAK_GBS,
            "kernel": "assemble_p1_tet_tiled_kernel (patches of 343 consecutive rows, LDS adds, rows written once)",
+           # the automatic plan: every element that touches a patch's rows is integrated by that patch -- (patch, element) pairs / elements
+           # is the redundancy of the integration AND of the 84 B of plan record + connectivity read per pair
+           "plan": {"patches": npatch, "rows_per_patch_max": maxrows, "row_length_max": maxlen, "patch_element_pairs": npe,
+                    "redundancy": npe / ne},
            "spmv_ms": spmv_ms, "spmv_algorithmic_GBs": B_spmv / (spmv_ms * 1e-3) / 1e9,
            "gmres_iters_per_s": gmres_iters / (info.solve_ms * 1e-3),
            "gmres_iteration_algorithmic_GBs": B_gmres / (info.solve_ms / gmres_iters * 1e-3) / 1e9,

@@ -166,7 +166,7 @@ int pyn_patch_plan_set(pyn_ctx* ctx, int n_patch, const int32_t* patch_ptr, cons
  * assembly (3x3 blocks: <= 36 rows per patch, e.g. 4x3x3 node tiles).  Both may coexist. */
 int pyn_patch_plan_set_kind(pyn_ctx* ctx, int kind, int n_patch, const int32_t* patch_ptr, const int32_t* patch_rows);
 /* The plan in use (the caller's, or the automatic one an assembly built): info[4] = patches, longest patch (rows), longest
- * element list of a patch, (patch, element) pairs -- pairs / elements is the factor by which elements on patch borders are
+ * row of the graph (entries), (patch, element) pairs -- pairs / elements is the factor by which elements on patch borders are
  * integrated more than once (diagnostics; no counterpart in the reference). */
 int pyn_patch_plan_info(pyn_ctx* ctx, int kind, int64_t* info);
 

@@ -312,7 +312,7 @@ class Context:
         return cn, xy
 
     def patch_plan_info(self, kind=0):
-        """(patches, longest patch, longest element list, patch-element pairs) of the plan in use"""
+        """(patches, longest patch in rows, longest row in entries, patch-element pairs) of the plan in use"""
         info = np.zeros(4, np.int64)
         _check(self.lib.pyn_patch_plan_info(self.h, kind, info.ctypes.data_as(_P)))
         return tuple(int(v) for v in info)

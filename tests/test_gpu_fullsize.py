@@ -54,6 +54,9 @@ def test_c2_poisson_128cubed_properties():
     n_rows, nnz = ctx.csr_symbolic()
     assert n_rows == (n + 1) ** 3 and nnz == (3 * n + 1) ** 3
     ctx.patch_plan_set(*dom.patchPlan((7, 7, 7)))
+    npatch, maxrows, maxlen, npe = ctx.patch_plan_info(0)
+    assert npatch == 19 ** 3 and maxrows == 343 and maxlen == 27                   # 129 = 18 x 7 + 3 rows per axis; 27-point rows
+    assert 1.0 < npe / n ** 3 < 1.6                                                 # elements on tile faces are integrated once per tile
     A, B = ctx.mat_create(1, 1), ctx.mat_create(1, 1)
     # (1) no mask: the two independent kernels (LDS-tiled vs HBM-atomic) agree entry by entry
     ctx.assemble_scalar(_lib.FORM_LAPLACE, A, -1, variant=1)

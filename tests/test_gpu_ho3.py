@@ -206,6 +206,58 @@ def test_sheared_mesh_and_nonaffine_fallback(lib, dim):
         ctx.close()
 
 
+@pytest.mark.parametrize("nelem", [[7, 5], [3, 4, 3]])
+@pytest.mark.parametrize("switch", ["PYNAMA_HO3_NO_DIAG", "PYNAMA_HO3_NO_PSTD", "PYNAMA_HO3_DENSE_TABLES"])
+def test_general_forms_on_box_meshes(lib, nelem, switch):
+    """what an axis-aligned box mesh normally skips -- the dense J^-1 contraction, plane ids read from memory, table records per node
+    pair instead of the 1-D factors -- gives the same matrices as the default (diagonal forms, closed-form plane ids, 1-D factors)"""
+    dim = len(nelem)
+    dw = 1 if dim == 2 else 3
+    mesh = fo.box_mesh(nelem, [0.0] * dim, [1.0, 0.6, 1.4][:dim], 3)
+    ctx = make_ctx(lib, mesh, boundary_mask(mesh), dim)
+    K, Krhs, Rw = ctx.mat_create(dim, dim), ctx.mat_create_rhs(dim, dim), ctx.mat_create(dim, dw)
+    K1, Kr1, Rw1 = ctx.mat_create(dim, dim), ctx.mat_create_rhs(dim, dim), ctx.mat_create(dim, dw)
+    os.environ["PYNAMA_HO3_REQUIRE"] = "1"
+    try:
+        ctx.assemble_kle(1e3, 1e2, K, Krhs, Rw, -1)
+        os.environ[switch] = "1"
+        ctx.assemble_kle(1e3, 1e2, K1, Kr1, Rw1, -1)
+    finally:
+        os.environ.pop(switch, None)
+        del os.environ["PYNAMA_HO3_REQUIRE"]
+    ref = fo.assemble_kle_freeslip(mesh, fo.Tables(3, dim))
+    for a, b, name, bc in ((K, K1, "K", dim), (Krhs, Kr1, "Krhs", dim), (Rw, Rw1, "Rw", dw)):
+        assert sp_rel_err(mat_to_scipy(ctx, a, dim, bc), ref[name]) < FP_TOL, name
+        assert sp_rel_err(mat_to_scipy(ctx, b, dim, bc), ref[name]) < FP_TOL, name
+    ctx.close()
+
+
+def test_run_flags_follow_the_dirichlet_set_and_the_run_length(lib):
+    """the per-run flags (which runs see an imposed DOF) are rebuilt when the Dirichlet set or the run length changes"""
+    dim, dw = 3, 3
+    mesh = fo.box_mesh([5, 3, 3], [0.0] * dim, [1.0] * dim, 3)
+    ctx = make_ctx(lib, mesh, boundary_mask(mesh), dim)
+    K, Krhs = ctx.mat_create(dim, dim), ctx.mat_create_rhs(dim, dim)
+    ref = fo.assemble_kle_freeslip(mesh, fo.Tables(3, dim))
+    ctx.assemble_kle(1e3, 1e2, K, Krhs, -1, -1)
+    assert sp_rel_err(mat_to_scipy(ctx, K, dim, dim), ref["K"]) < FP_TOL
+    mask = np.zeros((mesh.n_node, dim), np.uint8)                      # another set: a few interior nodes, one component each
+    rng = np.random.default_rng(23)
+    mask[rng.choice(mesh.n_node, 9, replace=False), rng.integers(0, dim, 9)] = 1
+    ctx.bc_set(dim, mask)
+    ref2 = oracle_kle(mesh, mask)
+    for run in (None, "8", "2", None):
+        if run:
+            os.environ["PYNAMA_HO3_RUN"] = run
+        try:
+            ctx.assemble_kle(1e3, 1e2, K, Krhs, -1, -1)
+        finally:
+            os.environ.pop("PYNAMA_HO3_RUN", None)
+        assert sp_rel_err(mat_to_scipy(ctx, K, dim, dim), ref2["K"]) < FP_TOL, run
+        assert sp_rel_err(mat_to_scipy(ctx, Krhs, dim, dim), ref2["Krhs"]) < FP_TOL, run
+    ctx.close()
+
+
 @pytest.mark.parametrize("dim", [2, 3])
 def test_single_cell_mesh_reproduces_reference_element(lib, golden, dim):
     """the row-run kernels on a ONE-cell mesh against the reference's own K_e / Rw_e (tests/golden/g3_elem.npz, written by

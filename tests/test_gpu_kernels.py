@@ -549,6 +549,13 @@ def test_operators_global_vs_oracle(lib, nelem, ngl):
         ctx.vec_set(vs, np.repeat(1.0 / w, br))
         ctx.mat_row_scale(m, vs)
         assert sp_rel_err(mat_to_scipy(ctx, m, br, bc), ref[name]) < FP_TOL, name
+        # the same scaling from ONE factor per node (a vector of block size 1 serves all rows of the node: what Operators keeps on the device)
+        m1 = ctx.mat_create(br, bc)
+        ctx.assemble_operator(lib.Q_NODAL, terms, coef, m1)
+        v1 = ctx.vec_create(1)
+        ctx.vec_set(v1, 1.0 / w)
+        ctx.mat_row_scale(m1, v1)
+        assert rel_err(ctx.mat_values(m1, br, bc), ctx.mat_values(m, br, bc)) < 1e-14, name      # (two assemblies: LDS adds in any order)
         # SpMV through the block SELL image of the rectangular operator
         x = np.random.default_rng(2).standard_normal(mesh.n_node * bc)
         vx, vy = ctx.vec_create(bc), ctx.vec_create(br)
