@@ -88,7 +88,8 @@ int pyn_comm_allreduce_f64(pyn_ctx* ctx, double* inout, int n, int op /*0 sum, 1
  * of 1 and of the rank, one halo exchange of a rank-stamped vector on the main stream, one on the communication stream (the
  * overlapped form of the CG), and one on the communication stream WHILE an all-reduce is queued on the main stream, each checked on
  * the receiver.  info[6]: ranks counted by RCCL (0: the shared-memory test transport), sum(1), sum(rank), ghosts checked (main /
- * communication stream), sum(rank + 1) of the all-reduce that ran beside an exchange.  The
+ * communication stream), sum(rank + 1) of the all-reduce that ran beside an exchange, [6] 1 = the halo exchanges have a communicator of
+ * their own, 2 = they share the all-reduces' (RCCL refused the split; reported on stderr).  The
  * reference's analogue is implicit: PETSc checks its communicator at KSPSetUp / MatAssemblyEnd (src/solver/ksp_solver.py:19,
  * src/matrices/mat_generator.py:14-17).  Call after pyn_halo_set. */
 int pyn_comm_selftest(pyn_ctx* ctx, double* info, int ninfo);

@@ -261,6 +261,7 @@ class Context:
                "allreduce_beside_exchange_sum_ranks_plus_1": info[5]}
         if info[0] > 0:
             out["nranks_seen_by_rccl"] = int(info[0])      # counted by RCCL itself (ncclCommCount of both communicators)
+            out["halo_communicator"] = "own (ncclCommSplit)" if info[6] == 1 else "shared with the all-reduces (split refused)"
         return out
 
     def halo_set(self, n_owned, n_ghost, neigh, send_ptr, send_idx, recv_ptr):

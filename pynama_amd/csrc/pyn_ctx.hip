@@ -128,7 +128,7 @@ extern "C" int pyn_ctx_destroy(pyn_ctx* c) {
   if (!c) return PYN_OK;
   (void)hipSetDevice(c->device);
   (void)hipStreamSynchronize(c->stream);
-  if (c->comm_halo) ncclCommDestroy(c->comm_halo);
+  if (c->comm_halo && c->comm_halo != c->comm) ncclCommDestroy(c->comm_halo);
   if (c->comm) ncclCommDestroy(c->comm);
   if (c->shm) {
     (void)hipStreamSynchronize(c->comm_stream);
@@ -342,8 +342,15 @@ extern "C" int pyn_comm_init(pyn_ctx* c, int rank, int nranks, const void* uid, 
   // a SECOND communicator for the halo exchanges: the overlapped CG issues them on the communication stream while an all-reduce of
   // the previous step may still be queued on the main stream -- with their own communicator nothing rests on how RCCL orders the
   // operations of ONE communicator across streams
-  PYN_NCCL(ncclCommSplit(c->comm, 0, rank, &c->comm_halo, nullptr));
-  PYN_CHECK(c->comm_halo != nullptr, "ncclCommSplit returned no communicator for the halo exchanges");
+  // (a collective: it succeeds or fails on every rank alike.  Should this RCCL refuse it, the exchanges share the first communicator as
+  // they did in round 2 -- correct as long as RCCL keeps one communicator's operations in issue order -- and say so on stderr)
+  c->comm_halo = nullptr;
+  const ncclResult_t sr = getenv("PYNAMA_NO_COMM_SPLIT") ? ncclInvalidUsage : ncclCommSplit(c->comm, 0, rank, &c->comm_halo, nullptr);
+  if (sr != ncclSuccess || !c->comm_halo) {
+    fprintf(stderr, "[pynama_hip] rank %d: no second communicator for the halo exchanges (%s): sharing the first one\n", rank,
+            sr != ncclSuccess ? ncclGetErrorString(sr) : "ncclCommSplit returned none");
+    c->comm_halo = c->comm;
+  }
   return PYN_OK;
 }
 
@@ -389,6 +396,7 @@ extern "C" int pyn_comm_selftest(pyn_ctx* c, double* info, int ninfo) {
     PYN_CHECK(seen_h == seen && rank_h == c->rank, "halo communicator: %d ranks / rank %d, want %d / %d", seen_h, rank_h, seen, c->rank);
   }
   info[0] = c->comm ? seen : 0;      // ranks counted by RCCL itself; 0 = the shared-memory test transport is in use
+  if (ninfo >= 7) info[6] = c->comm ? (c->comm_halo != c->comm ? 1.0 : 2.0) : 0.0;   // halo exchanges: 1 own communicator, 2 shared
   PYN_CHECK(seen == c->nranks, "RCCL communicator has %d ranks, the launcher declared %d", seen, c->nranks);
   double v[2] = {1.0, (double)c->rank};
   PYN_TRY(pyn_comm_allreduce_f64(c, v, 2, 0));

@@ -622,9 +622,21 @@ def test_rccl_one_rank_halo_exchange_and_collectives(lib):
     # start-up self-test (what bench.py --gpus N runs first): both communicators counted by RCCL, rank-stamped exchanges on either
     # stream, and an all-reduce queued on the main stream while an exchange is in flight on the communication stream
     st = ctx.comm_selftest()
-    assert st["transport"] == "rccl" and st["nranks_seen_by_rccl"] == 1
+    assert st["transport"] == "rccl" and st["nranks_seen_by_rccl"] == 1 and st["halo_communicator"].startswith("own")
     assert st["allreduce_sum_ones"] == 1.0 and st["allreduce_beside_exchange_sum_ranks_plus_1"] == 1.0
     assert st["halo_ghosts_checked_main_stream"] == per_plane == st["halo_ghosts_checked_comm_stream"]
+    # should RCCL refuse the split, the exchanges share the first communicator (reported, not fatal): same checks pass
+    os.environ["PYNAMA_NO_COMM_SPLIT"] = "1"
+    try:
+        c2 = lib.Context(0)
+        c2.comm_init(0, 1, lib.Context.unique_id())
+    finally:
+        del os.environ["PYNAMA_NO_COMM_SPLIT"]
+    c2.halo_set(N, per_plane, [0], [0, per_plane], plane.astype(np.int32), [0, per_plane])
+    c2.mesh_set(3, cut.conn, cut.xyz)
+    st2 = c2.comm_selftest()
+    assert st2["halo_communicator"].startswith("shared") and st2["halo_ghosts_checked_comm_stream"] == per_plane
+    c2.close()
     A = ctx.mat_create(1, 1)
     ctx.assemble_scalar(lib.FORM_LAPLACE, A)
     assert sp_rel_err(mat_to_scipy(ctx, A, 1, 1), ref) < FP_TOL
