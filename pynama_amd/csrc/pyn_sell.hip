@@ -325,6 +325,15 @@ __global__ void __launch_bounds__(256) sellp_spmv_kernel(const int64_t* __restri
 // every lane then walks its own row there (row offsets differ by the row length: odd for the 27-point stencil, i.e. free of bank
 // conflicts).  The gathers of x depend only on the column pattern, not on the values: they are issued together with the value loads.
 // Traffic = 8 B per stored entry (no slice padding) + 4 B pattern id + x, y per row.
+// The matrix values of the lane-per-row kernels that stage a slice's run through LDS are read ONCE per product, in whole contiguous
+// runs: non-temporal loads, so that they pass through L2 / the Infinity Cache without pushing out the x entries every row gathers
+// (same-box A/B: 10 M-row CSR product 0.541 -> 0.522 ms, CG +3 %; 1024^2 second-order 2x2 blocks 0.548 -> 0.483-0.507 ms).  NOT in
+// bcsr_spmv_kernel (several lanes per node row, three value rows per lane: 2.20 -> 2.65 ms with them) nor on the SELL images (+-0).
+template <typename T_>
+__device__ __forceinline__ T_ ld_stream(const T_* p) {
+  return __builtin_nontemporal_load(p);
+}
+
 constexpr int CSRL_WAVES = 4;   // waves per workgroup (LDS: W x 512 B per wave): two workgroups = eight waves per CU measured best
 template <int W, bool DOT>
 __global__ void __launch_bounds__(64 * CSRL_WAVES) csrl_spmv_kernel(const int32_t* __restrict__ rowptr, const int32_t* __restrict__ pid,
@@ -370,7 +379,7 @@ __global__ void __launch_bounds__(64 * CSRL_WAVES) csrl_spmv_kernel(const int32_
     // the run of the 64 rows, coalesced; zero beyond its end
     double vr[W];
 #pragma unroll
-    for (int j = 0; j < W; ++j) vr[j] = (64 * j + lane < total) ? v[64 * j + lane] : 0.0;
+    for (int j = 0; j < W; ++j) vr[j] = (64 * j + lane < total) ? ld_stream(v + 64 * j + lane) : 0.0;
     // the row's x entries (pattern table: column = row + t[k])
     const int32_t* __restrict__ t = ltab + (live ? pid[row] : npat) * PAT_W;
     const int64_t rb = live ? row : 0;
@@ -458,7 +467,7 @@ __global__ void __launch_bounds__(64 * CSRLB_WAVES) csrlb_spmv_kernel(const int3
         const int e = 128 * j + 2 * lane;
         if (e + 1 < total)
           __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(v + e),
-                                           (__attribute__((address_space(3))) void*)(buf + 128 * j), 16, 0, 0);
+                                           (__attribute__((address_space(3))) void*)(buf + 128 * j), 16, 0, 2);   // aux 2: nt
       }
       if (BC == 2 && W % 2 == 0) {   // the two x entries of a column node by one 16-byte load
 #pragma unroll
@@ -476,7 +485,7 @@ __global__ void __launch_bounds__(64 * CSRLB_WAVES) csrlb_spmv_kernel(const int3
     } else {
       double vr[W];
 #pragma unroll
-      for (int j = 0; j < W; ++j) vr[j] = (64 * j + lane < total) ? v[64 * j + lane] : 0.0;
+      for (int j = 0; j < W; ++j) vr[j] = (64 * j + lane < total) ? ld_stream(v + 64 * j + lane) : 0.0;
 #pragma unroll
       for (int k = 0; k < W; ++k) xg[k] = x[(nb + (k < L1 ? t[k / BC] : 0)) * BC + (k < L1 ? k % BC : 0)];
 #pragma unroll
