@@ -134,3 +134,28 @@ def test_ksp_solver_options_host():
         assert k.mat_free is None                              # automatic: the shell when the matrix carries one
     finally:
         Options([])
+
+
+@pytest.mark.parametrize("nelem,ngl,size", [([5, 4], 2, 1), ([4, 6], 3, 2), ([3, 4, 5], 2, 1), ([3, 2, 6], 3, 3), ([2, 2, 4], 4, 2)])
+def test_boundary_mask_slices_equal_the_per_node_lattice_indices(nelem, ngl, size):
+    """boundaryMaskLocal marks the borders as slices of the (planes, y, x) lattice of the local nodes (owned planes first, then the
+    ghosts); the per-node lattice indices give the same mask, and host conn / xyz exist only once somebody asks for them"""
+    from pynama_amd.common.comm import Comm
+    from pynama_amd.domain.dmplex import DMPlexDom
+    dim = len(nelem)
+    for r in range(size):
+        dom = DMPlexDom(boxMesh={'nelem': nelem, 'lower': [0.0] * dim, 'upper': [1.0, 2.0, 0.5][:dim]}, comm=Comm(r, size))
+        dom.setFemIndexing(ngl)
+        assert dom._conn is None and dom._xyz is None
+        bm = dom.boundaryMaskLocal()
+        assert dom._conn is None and dom._xyz is None and bm.shape == (dom.nLocal,)
+        on = np.zeros(dom.nLocal, bool)
+        for d in range(dim):
+            on |= (dom._lat_idx[d] == 0) | (dom._lat_idx[d] == dom.lattice[d] - 1)
+        assert np.array_equal(bm.astype(bool), on)
+        # coordinates of a few nodes without the full array == rows of the full array
+        ln = np.array([0, dom.nLocal - 1, dom.nLocal // 2])
+        X = dom._coords_of_local(ln)
+        assert dom._xyz is None
+        assert np.array_equal(X, dom.xyz[ln])
+        assert dom.conn.shape == ((dom._layers[1] - dom._layers[0]) * int(np.prod(nelem[:-1])), ngl ** dim)
